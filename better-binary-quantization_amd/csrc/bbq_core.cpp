@@ -1,0 +1,860 @@
+// bbq_core.cpp - device-resident index shard, segment plan, pipelined search, C ABI (see include/bbq.h).
+//
+// Search of one query = a short sequence of launches over row SEGMENTS of the index:
+//   segment 0   rows [0, s0)           dense: every f32 score is written; the finalize kernel lists all of
+//                                      them (the reference heap is still filling / changing fast here) and
+//                                      selects theta_1 = k-th largest key
+//   segment j   rows [b_j, b_{j+1})    sparse: rows with key > theta_j go to per-chunk candidate slots; the
+//                                      finalize kernel compacts them into the list and selects theta_{j+1}
+// theta_j only depends on rows before b_j, so it is a lower bound of the reference heap's minimum while the
+// reference walks segment j: rows at or below it can never enter the heap (bbq_replay.cpp).
+// Queries are processed in sub-batches (grid.y = queries, each query sweeps the index on its own), and
+// sub-batches are pipelined over NSLOT streams so the host replay of one overlaps the scan of the next.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <memory>
+#include <thread>
+#include <vector>
+#include "bbq_internal.h"
+#include "bbq_launch.h"
+
+using namespace bbq;
+
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail(BBQ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+namespace {
+
+constexpr int kMaxSlots = 4;
+constexpr int64_t kMaxFastK = 2048;  // beyond this the dense path is used (finalize LDS key buffer)
+
+struct Storage {
+  uint8_t *d_tiles = nullptr;
+  IndexView view{};
+  int64_t row_id_base = 0;
+  int64_t n_chunks() const { return (view.n_rows + kChunkRows - 1) / kChunkRows; }
+};
+
+struct Segment {
+  int storage;  // 0 = pilot replica, 1 = main
+  int64_t chunk_begin, n_chunks, rows;
+  bool dense, emit, need_theta, dominant;
+  int cap;
+};
+
+struct Plan {
+  int64_t k = -1;
+  std::vector<Segment> segs;
+  int64_t s0 = 0;
+  int64_t list_cap = 0;
+  int64_t max_slots = 0;  // max over sparse segments of n_chunks*cap
+  int64_t max_chunks = 0;
+};
+
+struct Slot {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
+  // capacities the buffers below were allocated for
+  int q_cap = 0;
+  int64_t qbuf_bytes = 0, chunks_cap = 0, slots_cap = 0, dense_cap = 0, list_cap = 0, k_cap = 0, hprefix = 0;
+  uint8_t *d_qbuf = nullptr, *h_qbuf = nullptr;
+  uint32_t *d_theta = nullptr, *d_flags = nullptr, *d_counts = nullptr, *d_topk = nullptr;
+  int32_t *d_topk_counts = nullptr, *d_list_counts = nullptr, *h_list_counts = nullptr;
+  uint64_t *d_entries = nullptr, *d_lists = nullptr, *h_lists = nullptr;
+  float *d_dense0 = nullptr;
+  // in-flight sub-batch
+  bool busy = false;
+  int nq = 0;
+  int64_t q_first = 0;
+  bool timed = false;
+  int64_t timed_rows = 0, timed_bytes = 0;
+};
+
+}  // namespace
+
+struct bbq_index {
+  int device = 0;
+  int32_t dim = 0, pb = 0, w16 = 0, tile_stride = 0, has_x1 = 0, bytes_per_row = 0;
+  int64_t n_rows = 0, row_base = 0;
+  double centroid_dp = 0;
+  bool has_pilot = false;
+  Storage pilot, main;
+  Plan plan;
+  Slot slots[kMaxSlots];
+  // dense path / bbq_score_rows: own stream and staging so that it never touches an in-flight slot
+  hipStream_t aux_stream = nullptr;
+  uint8_t *d_aux_qbuf = nullptr;
+  uint32_t *d_aux_flags = nullptr;
+  float *d_dense_all = nullptr;
+  int64_t dense_all_cap = 0;
+  // options
+  int opt_batch = 16, opt_slots = 2, opt_growth = 8, opt_tpw = 1, opt_replay_threads = 1, opt_force_dense = 0;
+  int64_t opt_s0 = 4096;
+  bbq_stats stats{};
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ storage
+
+int make_storage(bbq_index *ix, Storage &st, const uint8_t *codes, const double *corr, int64_t n_rows, int64_t row_id_base,
+                 bool check_x1) {
+  const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
+  const int64_t pb = ix->pb;
+  uint8_t *d_codes = nullptr;
+  double *d_corr = nullptr;
+  uint32_t *d_mis = nullptr;
+  hipStream_t s = ix->slots[0].stream;
+  if (n_rows > 0) {
+    HIPCHK(hipMalloc((void **)&d_codes, (size_t)(n_rows * pb)));
+    HIPCHK(hipMalloc((void **)&d_corr, (size_t)n_rows * 32));
+    HIPCHK(hipMemcpyAsync(d_codes, codes, (size_t)(n_rows * pb), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_corr, corr, (size_t)n_rows * 32, hipMemcpyHostToDevice, s));
+  }
+  if (check_x1) {
+    // quantizedComponentSum of a 1-bit row is its popcount (src/optimizedScalarQuantizer.ts:204-209); if that
+    // holds for every row the 8 bytes need not be stored or read.  Decided once per index, over all storages.
+    uint32_t mis = 0;
+    HIPCHK(hipMalloc((void **)&d_mis, 4));
+    HIPCHK(hipMemsetAsync(d_mis, 0, 4, s));
+    HIPCHK(launch_check_x1(d_codes, d_corr, n_rows, (int32_t)pb, d_mis, s));
+    HIPCHK(hipMemcpyAsync(&mis, d_mis, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(d_mis));
+    if (mis) ix->has_x1 = 1;
+  }
+  ix->tile_stride = ix->w16 * 1024 + 1536 + (ix->has_x1 ? 512 : 0);
+  ix->bytes_per_row = ix->tile_stride / kTileRows;
+  st.row_id_base = row_id_base;
+  st.view.n_rows = n_rows;
+  st.view.w16 = ix->w16;
+  st.view.tile_stride = ix->tile_stride;
+  st.view.has_x1 = ix->has_x1;
+  st.view.dim = ix->dim;
+  if (n_tiles > 0) {
+    HIPCHK(hipMalloc((void **)&st.d_tiles, (size_t)(n_tiles * ix->tile_stride)));
+    HIPCHK(launch_retile(d_codes, d_corr, n_rows, (int32_t)pb, st.d_tiles, ix->w16, ix->tile_stride, ix->has_x1, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  st.view.tiles = st.d_tiles;
+  if (d_codes) HIPCHK(hipFree(d_codes));
+  if (d_corr) HIPCHK(hipFree(d_corr));
+  return BBQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ plan
+
+int cap_for(int64_t k, int64_t rows_before) {
+  const double lam = (double)k * kChunkRows / (double)std::max<int64_t>(rows_before, 1);
+  int64_t c = (int64_t)ceil(lam + 8.0 * sqrt(lam) + 16.0);
+  c = (c + 7) / 8 * 8;
+  return (int)std::min<int64_t>(std::max<int64_t>(c, 16), kChunkRows);
+}
+
+// have_theta: a threshold derived from earlier rows (the pilot replica) already exists when this storage starts;
+// otherwise the storage's own first rows form the dense segment (for a shard without a replica that gives
+// thresholds from the shard's local prefix: weaker than global ones, still valid)
+void add_storage_segments(const bbq_index *ix, Plan &p, int storage, const Storage &st, int64_t rows_before, bool have_theta,
+                          bool emit, double &expected) {
+  const int64_t R = st.view.n_rows;
+  if (R <= 0) return;
+  int64_t b = 0;
+  if (!have_theta) {
+    rows_before = 0;
+    const int64_t rows = std::min(p.s0, R);
+    p.segs.push_back(Segment{storage, 0, (rows + kChunkRows - 1) / kChunkRows, rows, true, emit, true, false, 0});
+    expected += (double)rows;
+    b = rows;
+  }
+  while (b < R) {
+    const int64_t before = rows_before + b;
+    int64_t e = R;
+    const int64_t nb = (b == 0 ? p.s0 : b) * ix->opt_growth;
+    if (b > 0 && nb <= R / 2) e = nb;
+    if (b == 0) e = R;  // shard behind a pilot replica: one sweep
+    const int cap = cap_for(p.k, before);
+    const int64_t rows = e - b;
+    p.segs.push_back(Segment{storage, b / kChunkRows, (rows + kChunkRows - 1) / kChunkRows, rows, false, emit, true, false, cap});
+    expected += (double)p.k * (double)rows / (double)before;
+    b = e;
+  }
+}
+
+void build_plan(bbq_index *ix, int64_t k) {
+  Plan &p = ix->plan;
+  if (p.k == k) return;
+  p = Plan();
+  p.k = k;
+  p.s0 = std::max<int64_t>(ix->opt_s0, (4 * k + kChunkRows - 1) / kChunkRows * kChunkRows);
+  p.s0 = std::min<int64_t>(p.s0, 8192);
+  double expected_emit = 0, dummy = 0;
+  if (ix->has_pilot) {
+    add_storage_segments(ix, p, 0, ix->pilot, 0, false, false, dummy);
+    add_storage_segments(ix, p, 1, ix->main, ix->pilot.view.n_rows, true, true, expected_emit);
+  } else {
+    add_storage_segments(ix, p, 1, ix->main, 0, false, true, expected_emit);
+  }
+  if (!p.segs.empty()) p.segs.back().need_theta = false;
+  int64_t best = -1;
+  for (size_t i = 0; i < p.segs.size(); ++i) {
+    Segment &s = p.segs[i];
+    if (!s.dense) {
+      p.max_slots = std::max(p.max_slots, s.n_chunks * (int64_t)s.cap);
+      p.max_chunks = std::max(p.max_chunks, s.n_chunks);
+    }
+    if (best < 0 || s.rows > p.segs[best].rows) best = (int64_t)i;
+  }
+  if (best >= 0) p.segs[best].dominant = true;
+  // list capacity: everything dense + 4x the expected sparse candidates + slack
+  double sparse = 0;
+  int64_t dense_rows = 0;
+  for (const Segment &s : p.segs)
+    if (s.emit && s.dense) dense_rows += s.rows;
+  sparse = expected_emit - (double)dense_rows;
+  if (sparse < 0) sparse = 0;
+  p.list_cap = dense_rows + (int64_t)(4.0 * sparse) + 4096;
+  p.list_cap = (p.list_cap + 1023) / 1024 * 1024;
+}
+
+// ------------------------------------------------------------------------------------------------ slots
+
+void free_slot_buffers(Slot &s) {
+  if (s.d_qbuf) (void)hipFree(s.d_qbuf);
+  if (s.h_qbuf) (void)hipHostFree(s.h_qbuf);
+  if (s.d_theta) (void)hipFree(s.d_theta);
+  if (s.d_flags) (void)hipFree(s.d_flags);
+  if (s.d_counts) (void)hipFree(s.d_counts);
+  if (s.d_topk) (void)hipFree(s.d_topk);
+  if (s.d_topk_counts) (void)hipFree(s.d_topk_counts);
+  if (s.d_list_counts) (void)hipFree(s.d_list_counts);
+  if (s.h_list_counts) (void)hipHostFree(s.h_list_counts);
+  if (s.d_entries) (void)hipFree(s.d_entries);
+  if (s.d_lists) (void)hipFree(s.d_lists);
+  if (s.h_lists) (void)hipHostFree(s.h_lists);
+  if (s.d_dense0) (void)hipFree(s.d_dense0);
+  s.d_qbuf = s.h_qbuf = nullptr;
+  s.d_theta = s.d_flags = s.d_counts = s.d_topk = nullptr;
+  s.d_topk_counts = s.d_list_counts = s.h_list_counts = nullptr;
+  s.d_entries = s.d_lists = s.h_lists = nullptr;
+  s.d_dense0 = nullptr;
+  s.q_cap = 0;
+}
+
+int64_t qbuf_bytes_per_query(const bbq_index *ix) { return (int64_t)ix->w16 * 8 * 16 + (int64_t)sizeof(QueryParams); }
+
+int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
+  const Plan &p = ix->plan;
+  const int64_t qb = qbuf_bytes_per_query(ix);
+  const int64_t hprefix = std::min<int64_t>(p.list_cap, 16384);
+  const bool ok = s.q_cap >= nq && s.qbuf_bytes >= qb && s.chunks_cap >= p.max_chunks && s.slots_cap >= p.max_slots &&
+                  s.dense_cap >= p.s0 && s.list_cap >= p.list_cap && s.k_cap >= p.k && s.hprefix >= hprefix &&
+                  (!own_lists || s.d_lists != nullptr);
+  if (ok) return BBQ_OK;
+  free_slot_buffers(s);
+  const int Q = std::max(nq, ix->opt_batch);
+  s.qbuf_bytes = qb;
+  s.chunks_cap = std::max<int64_t>(p.max_chunks, 1);
+  s.slots_cap = std::max<int64_t>(p.max_slots, 1);
+  s.dense_cap = p.s0;
+  s.list_cap = p.list_cap;
+  s.k_cap = std::max<int64_t>(p.k, 1);
+  s.hprefix = hprefix;
+  HIPCHK(hipMalloc((void **)&s.d_qbuf, (size_t)(Q * qb)));
+  HIPCHK(hipHostMalloc((void **)&s.h_qbuf, (size_t)(Q * qb), hipHostMallocDefault));
+  HIPCHK(hipMalloc((void **)&s.d_theta, (size_t)Q * 4));
+  HIPCHK(hipMalloc((void **)&s.d_flags, (size_t)Q * 4));
+  HIPCHK(hipMalloc((void **)&s.d_counts, (size_t)(Q * s.chunks_cap) * 4));
+  HIPCHK(hipMalloc((void **)&s.d_topk, (size_t)(Q * s.k_cap) * 4));
+  HIPCHK(hipMalloc((void **)&s.d_topk_counts, (size_t)Q * 4));
+  HIPCHK(hipMalloc((void **)&s.d_list_counts, (size_t)Q * 8));
+  HIPCHK(hipHostMalloc((void **)&s.h_list_counts, (size_t)Q * 8, hipHostMallocDefault));
+  HIPCHK(hipMalloc((void **)&s.d_entries, (size_t)(Q * s.slots_cap) * 8));
+  HIPCHK(hipMalloc((void **)&s.d_dense0, (size_t)(Q * s.dense_cap) * 4));
+  if (own_lists) {
+    HIPCHK(hipMalloc((void **)&s.d_lists, (size_t)(Q * s.list_cap) * 8));
+    HIPCHK(hipHostMalloc((void **)&s.h_lists, (size_t)(Q * s.hprefix) * 8, hipHostMallocDefault));
+  }
+  s.q_cap = Q;
+  return BBQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ query prep
+
+struct PreparedQueries {
+  int planes = 4;
+  int one_bit = 0;
+};
+
+int planes_for(const uint8_t *q, int64_t count) {
+  uint8_t m = 0;
+  for (int64_t i = 0; i < count; ++i) m |= q[i];
+  if (m <= 1) return 1;
+  if (m <= 3) return 2;
+  if (m <= 15) return 4;
+  return 8;
+}
+
+// writes the bit-planes ([j][p] 16-byte blocks, packed like the rows: dim d -> byte d>>3, bit 7-(d&7)) and the
+// score uniforms of one query into the staging buffer
+void fill_query(const bbq_index *ix, uint8_t *planes_dst, QueryParams *pp, const uint8_t *q, const double *qc, int planes,
+                int one_bit, int sim) {
+  const int w16 = ix->w16;
+  memset(planes_dst, 0, (size_t)w16 * planes * 16);
+  for (int d = 0; d < ix->dim; ++d) {
+    const uint8_t v = q[d];
+    if (!v) continue;
+    const int byte = d >> 3, j = byte >> 4, b = byte & 15;
+    const uint8_t bit = (uint8_t)(0x80u >> (d & 7));
+    for (int p = 0; p < planes; ++p)
+      if ((v >> p) & 1) planes_dst[((size_t)j * planes + p) * 16 + b] |= bit;
+  }
+  const double FBS = 1.0 / 15.0;  // src/constants.ts:20
+  pp->ay = qc[0];
+  pp->ly = one_bit ? (qc[1] - qc[0]) : (qc[1] - qc[0]) * FBS;  // src/batchDotProduct.ts:498 / :574
+  pp->y1 = qc[3];
+  pp->qadd = qc[2];
+  pp->cdp = ix->centroid_dp;
+  pp->dimd = (double)ix->dim;
+  pp->sim = sim;
+  pp->one_bit = one_bit;
+}
+
+int validate_query_args(const bbq_index *ix, int32_t nq, const uint8_t *qquant, const double *qcorr, int32_t query_bits,
+                        int32_t sim, int64_t k) {
+  if (!ix) return fail(BBQ_ERR_INVALID_ARG, "目标向量集合不能为空");
+  if (nq < 0) return fail(BBQ_ERR_INVALID_ARG, "n_queries < 0");
+  if (nq > 0 && (!qquant || !qcorr)) return fail(BBQ_ERR_INVALID_ARG, "查询向量不能为空");
+  if (k < 0) return fail(BBQ_ERR_NEGATIVE_K, "k值不能为负数");
+  if (query_bits < 1 || query_bits > 8) return fail(BBQ_ERR_INVALID_ARG, "queryBits必须在1-8之间");
+  if (sim < 0 || sim > 2) return fail(BBQ_ERR_INVALID_ARG, "不支持的相似性函数: %d", sim);
+  if (query_bits == 1)
+    for (int64_t i = 0; i < (int64_t)nq * ix->dim; ++i)
+      if (qquant[i] > 1) return fail(BBQ_ERR_INVALID_ARG, "1位量化值必须为0或1");
+  return BBQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ enqueue / complete
+
+struct BatchCtx {
+  bbq_index *ix;
+  const uint8_t *qquant;
+  const double *qcorr;
+  int planes, one_bit, sim;
+  int64_t k;
+};
+
+int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64_t *d_lists_ext, int64_t list_cap_ext,
+                     int32_t *d_counts_ext) {
+  bbq_index *ix = c.ix;
+  const Plan &p = ix->plan;
+  const int64_t qb = (int64_t)ix->w16 * c.planes * 16;
+  uint8_t *hp = s.h_qbuf;
+  QueryParams *hq = reinterpret_cast<QueryParams *>(s.h_qbuf + (size_t)nq * qb);
+  for (int i = 0; i < nq; ++i)
+    fill_query(ix, hp + (size_t)i * qb, hq + i, c.qquant + (size_t)(q_first + i) * ix->dim, c.qcorr + (size_t)(q_first + i) * 4,
+               c.planes, c.one_bit, c.sim);
+  const size_t bytes = (size_t)nq * qb + (size_t)nq * sizeof(QueryParams);
+  hipStream_t st = s.stream;
+  HIPCHK(hipMemcpyAsync(s.d_qbuf, s.h_qbuf, bytes, hipMemcpyHostToDevice, st));
+  uint64_t *d_lists = d_lists_ext ? d_lists_ext : s.d_lists;
+  const int64_t list_cap = d_lists_ext ? list_cap_ext : s.list_cap;
+  int32_t *d_list_counts = d_counts_ext ? d_counts_ext : s.d_list_counts;
+  HIPCHK(hipMemsetAsync(s.d_theta, 0, (size_t)nq * 4, st));
+  HIPCHK(hipMemsetAsync(s.d_flags, 0, (size_t)nq * 4, st));
+  HIPCHK(hipMemsetAsync(s.d_topk_counts, 0, (size_t)nq * 4, st));
+  HIPCHK(hipMemsetAsync(d_list_counts, 0, (size_t)nq * 8, st));
+
+  s.timed = false;
+  for (const Segment &g : p.segs) {
+    const Storage &sto = g.storage == 0 ? ix->pilot : ix->main;
+    ScanArgs a{};
+    a.idx = sto.view;
+    a.qplanes = reinterpret_cast<const uint4 *>(s.d_qbuf);
+    a.qparams = reinterpret_cast<const QueryParams *>(s.d_qbuf + (size_t)nq * qb);
+    a.chunk_begin = g.chunk_begin;
+    a.row_id_base = sto.row_id_base;
+    a.theta = s.d_theta;
+    a.counts = s.d_counts;
+    a.entries = s.d_entries;
+    a.flags = s.d_flags;
+    a.cap = g.cap;
+    a.n_chunks = (int32_t)g.n_chunks;
+    a.dense_score32 = g.dense ? s.d_dense0 : nullptr;
+    a.dense_stride = s.dense_cap;
+    if (g.dominant) HIPCHK(hipEventRecord(s.ev0, st));
+    HIPCHK(launch_scan(a, c.planes, g.dense, nq, (int)g.n_chunks, ix->opt_tpw, st));
+    if (g.dominant) {
+      HIPCHK(hipEventRecord(s.ev1, st));
+      s.timed = true;
+      s.timed_rows = g.rows * nq;
+      s.timed_bytes = g.rows * nq * (int64_t)ix->bytes_per_row;
+    }
+    FinalizeArgs f{};
+    f.counts = s.d_counts;
+    f.entries = s.d_entries;
+    f.dense_score32 = s.d_dense0;
+    f.dense_stride = s.dense_cap;
+    f.dense_rows = g.dense ? (int32_t)g.rows : 0;
+    f.dense_row_id_base = sto.row_id_base + g.chunk_begin * kChunkRows;
+    f.n_chunks = (int32_t)g.n_chunks;
+    f.cap = g.cap;
+    f.lists = d_lists;
+    f.list_counts = d_list_counts;
+    f.list_cap = list_cap;
+    f.emit = g.emit ? 1 : 0;
+    f.topk_keys = s.d_topk;
+    f.topk_counts = s.d_topk_counts;
+    f.theta = s.d_theta;
+    f.flags = s.d_flags;
+    f.k = (int32_t)c.k;
+    f.need_theta = g.need_theta ? 1 : 0;
+    HIPCHK(launch_finalize(f, nq, st));
+  }
+  if (!d_lists_ext) {
+    HIPCHK(hipMemcpyAsync(s.h_list_counts, s.d_list_counts, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpy2DAsync(s.h_lists, (size_t)s.hprefix * 8, s.d_lists, (size_t)s.list_cap * 8, (size_t)s.hprefix * 8, (size_t)nq,
+                            hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(hipEventRecord(s.ev_done, st));
+  s.busy = true;
+  s.nq = nq;
+  s.q_first = q_first;
+  return BBQ_OK;
+}
+
+void account_timing(bbq_index *ix, Slot &s) {
+  if (!s.timed) return;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, s.ev0, s.ev1) == hipSuccess) {
+    ix->stats.last_scan_ms = ms;
+    ix->stats.last_scan_rows = s.timed_rows;
+    ix->stats.last_scan_bytes = s.timed_bytes;
+    ix->stats.total_scan_ms += ms;
+    ix->stats.total_scan_bytes += s.timed_bytes;
+    ix->stats.total_scan_launches += 1;
+  }
+}
+
+// dense path for one query: every f32 score to the host, full replay of the reference loop
+int dense_search_one(const BatchCtx &c, int64_t qi, int32_t *out_idx, float *out_score, int64_t *out_n) {
+  bbq_index *ix = c.ix;
+  const int64_t n = ix->main.view.n_rows;
+  const int64_t chunks = ix->main.n_chunks();
+  if (ix->dense_all_cap < n) {
+    if (ix->d_dense_all) HIPCHK(hipFree(ix->d_dense_all));
+    ix->d_dense_all = nullptr;
+    HIPCHK(hipMalloc((void **)&ix->d_dense_all, (size_t)std::max<int64_t>(n, 1) * 4));
+    ix->dense_all_cap = n;
+  }
+  const int64_t qb = (int64_t)ix->w16 * c.planes * 16;
+  std::vector<uint8_t> hb((size_t)qb + sizeof(QueryParams));
+  fill_query(ix, hb.data(), reinterpret_cast<QueryParams *>(hb.data() + qb), c.qquant + (size_t)qi * ix->dim, c.qcorr + (size_t)qi * 4,
+             c.planes, c.one_bit, c.sim);
+  hipStream_t st = ix->aux_stream;
+  HIPCHK(hipMemcpyAsync(ix->d_aux_qbuf, hb.data(), hb.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  ScanArgs a{};
+  a.idx = ix->main.view;
+  a.qplanes = reinterpret_cast<const uint4 *>(ix->d_aux_qbuf);
+  a.qparams = reinterpret_cast<const QueryParams *>(ix->d_aux_qbuf + qb);
+  a.chunk_begin = 0;
+  a.row_id_base = ix->main.row_id_base;
+  a.flags = ix->d_aux_flags;
+  a.dense_score32 = ix->d_dense_all;
+  a.dense_stride = n;
+  // gridDim.x is limited to 2^31-1: fine for any index that fits in HBM
+  HIPCHK(launch_scan(a, c.planes, true, 1, (int)chunks, ix->opt_tpw, st));
+  std::vector<float> h((size_t)std::max<int64_t>(n, 1));
+  HIPCHK(hipMemcpyAsync(h.data(), ix->d_dense_all, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  HeapReplay hr(c.k, n);
+  for (int64_t i = 0; i < n; ++i) hr.offer(h[(size_t)i], (int32_t)(ix->main.row_id_base + i));
+  *out_n = hr.finish(out_idx, out_score);
+  ix->stats.dense_fallbacks += 1;
+  ix->stats.candidates += n;
+  return BBQ_OK;
+}
+
+int complete_subbatch(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score, int64_t *out_n) {
+  bbq_index *ix = c.ix;
+  HIPCHK(hipEventSynchronize(s.ev_done));
+  s.busy = false;
+  account_timing(ix, s);
+  const int nq = s.nq;
+  std::vector<int> dense_q;
+  std::vector<std::vector<uint64_t>> tails((size_t)nq);
+  for (int i = 0; i < nq; ++i) {
+    const int32_t cnt = s.h_list_counts[2 * i], flags = s.h_list_counts[2 * i + 1];
+    if (flags != 0) { dense_q.push_back(i); continue; }
+    if (cnt > s.hprefix) {  // rare: fetch what the prefix copy did not cover
+      tails[(size_t)i].resize((size_t)(cnt - s.hprefix));
+      HIPCHK(hipMemcpy(tails[(size_t)i].data(), s.d_lists + (size_t)i * s.list_cap + s.hprefix, (size_t)(cnt - s.hprefix) * 8,
+                       hipMemcpyDeviceToHost));
+    }
+  }
+  const int64_t k = c.k, n_total = ix->main.row_id_base + ix->main.view.n_rows;
+  auto replay_range = [&](int lo, int hi) {
+    for (int i = lo; i < hi; ++i) {
+      const int32_t cnt = s.h_list_counts[2 * i], flags = s.h_list_counts[2 * i + 1];
+      if (flags != 0) continue;
+      HeapReplay hr(k, n_total);
+      const uint64_t *l = s.h_lists + (size_t)i * s.hprefix;
+      const int64_t head = std::min<int64_t>(cnt, s.hprefix);
+      for (int64_t j = 0; j < head; ++j) {
+        const uint32_t bits = (uint32_t)l[j];
+        float sc;
+        memcpy(&sc, &bits, 4);
+        hr.offer(sc, (int32_t)(uint32_t)(l[j] >> 32));
+      }
+      for (uint64_t e : tails[(size_t)i]) {
+        const uint32_t bits = (uint32_t)e;
+        float sc;
+        memcpy(&sc, &bits, 4);
+        hr.offer(sc, (int32_t)(uint32_t)(e >> 32));
+      }
+      const int64_t qi = s.q_first + i;
+      out_n[qi] = hr.finish(out_idx + qi * k, out_score + qi * k);
+    }
+  };
+  const int T = std::min(ix->opt_replay_threads, nq);
+  if (T <= 1) {
+    replay_range(0, nq);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(replay_range, (int)((int64_t)nq * t / T), (int)((int64_t)nq * (t + 1) / T));
+    for (auto &x : th) x.join();
+  }
+  for (int i = 0; i < nq; ++i)
+    if (s.h_list_counts[2 * i + 1] == 0) ix->stats.candidates += s.h_list_counts[2 * i];
+  for (int i : dense_q) {
+    const int64_t qi = s.q_first + i;
+    int rc = dense_search_one(c, qi, out_idx + qi * k, out_score + qi * k, out_n + qi);
+    if (rc != BBQ_OK) return rc;
+  }
+  return BBQ_OK;
+}
+
+int drain(bbq_index *ix) {
+  for (int i = 0; i < kMaxSlots; ++i)
+    if (ix->slots[i].stream) HIPCHK(hipStreamSynchronize(ix->slots[i].stream));
+  return BBQ_OK;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+
+extern "C" {
+
+int bbq_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int bbq_index_create_shard(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim, int32_t index_bits,
+                           double centroid_dp, int64_t row_base, const uint8_t *pilot_codes, const double *pilot_corr,
+                           int64_t n_pilot, int32_t device, bbq_index **out) {
+  clear_error();
+  if (!out) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_create: out is null");
+  *out = nullptr;
+  if (n_rows < 0 || dim <= 0 || row_base < 0 || n_pilot < 0) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_create: bad size");
+  if (n_rows > 0 && (!codes || !corr)) return fail(BBQ_ERR_INVALID_ARG, "目标向量集合不能为空");
+  if (index_bits < 1 || index_bits > 8) return fail(BBQ_ERR_INVALID_ARG, "indexBits必须在1-8之间");
+  if (index_bits != 1)
+    return fail(BBQ_ERR_UNSUPPORTED,
+                "indexBits=%d: the reference has no working batch scorer for multi-bit indexes (SURVEY A.7); only indexBits=1 is scored",
+                index_bits);
+  if (n_pilot > 0 && (!pilot_codes || !pilot_corr)) return fail(BBQ_ERR_INVALID_ARG, "pilot arrays are null");
+  if (n_pilot > 0 && row_base == 0) return fail(BBQ_ERR_INVALID_ARG, "the shard that owns row 0 takes no pilot replica");
+  if (n_pilot > 0 && n_pilot > row_base) return fail(BBQ_ERR_INVALID_ARG, "pilot rows must precede the shard (n_pilot <= row_base)");
+  if (n_pilot > 0 && n_pilot != row_base && n_pilot % kChunkRows != 0)
+    return fail(BBQ_ERR_INVALID_ARG, "n_pilot must be a multiple of %d", kChunkRows);
+  if (row_base + n_rows > 0xFFFFFFFFll) return fail(BBQ_ERR_UNSUPPORTED, "more than 2^32 rows");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(BBQ_ERR_NO_DEVICE, "no HIP device available: libbbq has no CPU fallback (hipGetDeviceCount found %d)", ndev);
+  if (device < 0 || device >= ndev) return fail(BBQ_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+  HIPCHK(hipSetDevice(device));
+
+  std::unique_ptr<bbq_index> ix(new bbq_index());
+  ix->device = device;
+  ix->dim = dim;
+  ix->pb = (dim + 7) / 8;
+  ix->w16 = (ix->pb + 15) / 16;
+  ix->n_rows = n_rows;
+  ix->row_base = row_base;
+  ix->centroid_dp = centroid_dp;
+  ix->has_pilot = n_pilot > 0;
+  for (int i = 0; i < kMaxSlots; ++i) {
+    HIPCHK(hipStreamCreateWithFlags(&ix->slots[i].stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&ix->slots[i].ev0));
+    HIPCHK(hipEventCreate(&ix->slots[i].ev1));
+    HIPCHK(hipEventCreateWithFlags(&ix->slots[i].ev_done, hipEventDisableTiming));
+  }
+  HIPCHK(hipStreamCreateWithFlags(&ix->aux_stream, hipStreamNonBlocking));
+  HIPCHK(hipMalloc((void **)&ix->d_aux_qbuf, (size_t)qbuf_bytes_per_query(ix.get())));
+  HIPCHK(hipMalloc((void **)&ix->d_aux_flags, 4));
+  HIPCHK(hipMemset(ix->d_aux_flags, 0, 4));
+  int rc;
+  if (ix->has_pilot) {
+    rc = make_storage(ix.get(), ix->pilot, pilot_codes, pilot_corr, n_pilot, 0, true);
+    if (rc != BBQ_OK) { bbq_index_destroy(ix.release()); return rc; }
+    const int had = ix->has_x1;
+    rc = make_storage(ix.get(), ix->main, codes, corr, n_rows, row_base, true);
+    if (rc != BBQ_OK) { bbq_index_destroy(ix.release()); return rc; }
+    if (ix->has_x1 != had) {  // main needs explicit sums but pilot was built without: rebuild the pilot
+      if (ix->pilot.d_tiles) (void)hipFree(ix->pilot.d_tiles);
+      ix->pilot.d_tiles = nullptr;
+      rc = make_storage(ix.get(), ix->pilot, pilot_codes, pilot_corr, n_pilot, 0, false);
+      if (rc != BBQ_OK) { bbq_index_destroy(ix.release()); return rc; }
+    }
+  } else {
+    rc = make_storage(ix.get(), ix->main, codes, corr, n_rows, row_base, true);
+    if (rc != BBQ_OK) { bbq_index_destroy(ix.release()); return rc; }
+  }
+  *out = ix.release();
+  return BBQ_OK;
+}
+
+int bbq_index_create(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim, int32_t index_bits,
+                     double centroid_dp, int32_t device, bbq_index **out) {
+  return bbq_index_create_shard(codes, corr, n_rows, dim, index_bits, centroid_dp, 0, nullptr, nullptr, 0, device, out);
+}
+
+void bbq_index_destroy(bbq_index *ix) {
+  if (!ix) return;
+  (void)hipSetDevice(ix->device);
+  for (int i = 0; i < kMaxSlots; ++i) {
+    Slot &s = ix->slots[i];
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    free_slot_buffers(s);
+    if (s.ev0) (void)hipEventDestroy(s.ev0);
+    if (s.ev1) (void)hipEventDestroy(s.ev1);
+    if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+  }
+  if (ix->pilot.d_tiles) (void)hipFree(ix->pilot.d_tiles);
+  if (ix->main.d_tiles) (void)hipFree(ix->main.d_tiles);
+  if (ix->d_dense_all) (void)hipFree(ix->d_dense_all);
+  if (ix->d_aux_qbuf) (void)hipFree(ix->d_aux_qbuf);
+  if (ix->d_aux_flags) (void)hipFree(ix->d_aux_flags);
+  if (ix->aux_stream) (void)hipStreamDestroy(ix->aux_stream);
+  delete ix;
+}
+
+int64_t bbq_index_size(const bbq_index *ix) { return ix ? ix->n_rows : 0; }
+int32_t bbq_index_dimension(const bbq_index *ix) { return ix ? ix->dim : 0; }
+int32_t bbq_index_bytes_per_row(const bbq_index *ix) { return ix ? ix->bytes_per_row : 0; }
+
+int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, const double *qcorr, int32_t query_bits,
+                     int32_t sim, int64_t k, int32_t *out_idx, float *out_score, int64_t *out_n) {
+  clear_error();
+  int rc = validate_query_args(ix, n_queries, qquant, qcorr, query_bits, sim, k);
+  if (rc != BBQ_OK) return rc;
+  if (n_queries > 0 && !out_n) return fail(BBQ_ERR_INVALID_ARG, "out_n is null");
+  for (int32_t i = 0; i < n_queries; ++i) out_n[i] = 0;
+  if (k == 0 || n_queries == 0) return BBQ_OK;  // src/binaryQuantizationFormat.ts:332-334
+  if (!out_idx || !out_score) return fail(BBQ_ERR_INVALID_ARG, "output arrays are null");
+  if (ix->has_pilot || ix->row_base != 0)
+    return fail(BBQ_ERR_INVALID_ARG, "bbq_search on a non-root shard: use bbq_shard_scan + bbq_replay");
+  HIPCHK(hipSetDevice(ix->device));
+  ix->stats.candidates = 0;
+  ix->stats.dense_fallbacks = 0;
+  if (ix->n_rows == 0) return BBQ_OK;
+
+  BatchCtx c{ix, qquant, qcorr, planes_for(qquant, (int64_t)n_queries * ix->dim), query_bits == 1 ? 1 : 0, sim, k};
+  if (c.one_bit) c.planes = 1;
+  const int64_t keff = std::min<int64_t>(k, ix->n_rows);
+  c.k = k;
+  if (keff > kMaxFastK || ix->opt_force_dense) {
+    for (int32_t i = 0; i < n_queries; ++i) {
+      rc = dense_search_one(c, i, out_idx + (int64_t)i * k, out_score + (int64_t)i * k, out_n + i);
+      if (rc != BBQ_OK) return rc;
+    }
+    return BBQ_OK;
+  }
+  // thresholds are order statistics of rank k2 = min(k, N): selecting with a larger k would be wrong.
+  // cs drives the device (k2); c (the caller's k) strides the outputs and sizes the replayed heap.
+  BatchCtx cs = c;
+  cs.k = keff;
+  build_plan(ix, keff);
+  const int Q = std::max(1, ix->opt_batch);
+  const int nslots = std::min(std::max(1, ix->opt_slots), kMaxSlots);
+  const int64_t nsub = ((int64_t)n_queries + Q - 1) / Q;
+  auto complete = [&](Slot &s) -> int { return complete_subbatch(c, s, out_idx, out_score, out_n); };
+  for (int64_t i = 0; i < nsub; ++i) {
+    Slot &s = ix->slots[i % nslots];
+    if (s.busy) {
+      rc = complete(s);
+      if (rc != BBQ_OK) { drain(ix); return rc; }
+    }
+    const int nq = (int)std::min<int64_t>(Q, n_queries - i * Q);
+    rc = ensure_slot(ix, s, nq, true);
+    if (rc != BBQ_OK) { drain(ix); return rc; }
+    rc = enqueue_subbatch(cs, s, i * Q, nq, nullptr, 0, nullptr);
+    if (rc != BBQ_OK) { drain(ix); return rc; }
+  }
+  for (int64_t i = std::max<int64_t>(0, nsub - nslots); i < nsub; ++i) {
+    Slot &s = ix->slots[i % nslots];
+    if (s.busy) {
+      rc = complete(s);
+      if (rc != BBQ_OK) { drain(ix); return rc; }
+    }
+  }
+  return BBQ_OK;
+}
+
+int bbq_search(bbq_index *ix, const uint8_t *qquant, const double *qcorr, int32_t query_bits, int32_t sim, int64_t k,
+               int32_t *out_idx, float *out_score, int64_t *out_n) {
+  return bbq_search_batch(ix, 1, qquant, qcorr, query_bits, sim, k, out_idx, out_score, out_n);
+}
+
+int bbq_score_rows(bbq_index *ix, const uint8_t *qquant, const double *qcorr, int32_t query_bits, int32_t sim,
+                   int64_t row_begin, int64_t row_count, int32_t *out_qcdist, double *out_score64, float *out_score32) {
+  clear_error();
+  int rc = validate_query_args(ix, 1, qquant, qcorr, query_bits, sim, 0);
+  if (rc != BBQ_OK) return rc;
+  if (row_begin < 0 || row_count < 0 || row_begin + row_count > ix->n_rows)
+    return fail(BBQ_ERR_INVALID_ARG, "向量索引 %lld 不存在", (long long)(row_begin + row_count - 1));
+  if (row_count == 0) return BBQ_OK;
+  HIPCHK(hipSetDevice(ix->device));
+  BatchCtx c{ix, qquant, qcorr, planes_for(qquant, ix->dim), query_bits == 1 ? 1 : 0, sim, 0};
+  if (c.one_bit) c.planes = 1;
+  const int64_t qb = (int64_t)ix->w16 * c.planes * 16;
+  std::vector<uint8_t> hb((size_t)qb + sizeof(QueryParams));
+  fill_query(ix, hb.data(), reinterpret_cast<QueryParams *>(hb.data() + qb), qquant, qcorr, c.planes, c.one_bit, sim);
+  hipStream_t st = ix->aux_stream;
+  HIPCHK(hipMemcpyAsync(ix->d_aux_qbuf, hb.data(), hb.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const int64_t piece_chunks = 1024;  // 1M rows per piece
+  const int64_t c_first = row_begin / kChunkRows, c_last = (row_begin + row_count + kChunkRows - 1) / kChunkRows;
+  float *d32 = nullptr;
+  int32_t *dqc = nullptr;
+  double *d64 = nullptr;
+  const int64_t piece_rows = piece_chunks * kChunkRows;
+  HIPCHK(hipMalloc((void **)&d32, (size_t)piece_rows * 4));
+  HIPCHK(hipMalloc((void **)&dqc, (size_t)piece_rows * 4));
+  HIPCHK(hipMalloc((void **)&d64, (size_t)piece_rows * 8));
+  std::vector<float> h32((size_t)piece_rows);
+  std::vector<int32_t> hqc((size_t)piece_rows);
+  std::vector<double> h64((size_t)piece_rows);
+  rc = BBQ_OK;
+  for (int64_t cb = c_first; cb < c_last && rc == BBQ_OK; cb += piece_chunks) {
+    const int64_t nc = std::min(piece_chunks, c_last - cb);
+    ScanArgs a{};
+    a.idx = ix->main.view;
+    a.qplanes = reinterpret_cast<const uint4 *>(ix->d_aux_qbuf);
+    a.qparams = reinterpret_cast<const QueryParams *>(ix->d_aux_qbuf + qb);
+    a.chunk_begin = cb;
+    a.row_id_base = ix->main.row_id_base;
+    a.flags = ix->d_aux_flags;
+    a.dense_score32 = d32;
+    a.dense_qcdist = dqc;
+    a.dense_score64 = d64;
+    a.dense_stride = piece_rows;
+    hipError_t e = launch_scan(a, c.planes, true, 1, (int)nc, ix->opt_tpw, st);
+    const int64_t r0 = cb * kChunkRows, r1 = std::min((cb + nc) * kChunkRows, ix->main.view.n_rows);
+    if (e == hipSuccess) e = hipMemcpyAsync(h32.data(), d32, (size_t)(r1 - r0) * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(hqc.data(), dqc, (size_t)(r1 - r0) * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(h64.data(), d64, (size_t)(r1 - r0) * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { rc = fail(BBQ_ERR_HIP, "bbq_score_rows: %s", hipGetErrorString(e)); break; }
+    const int64_t lo = std::max(r0, row_begin), hi = std::min(r1, row_begin + row_count);
+    for (int64_t r = lo; r < hi; ++r) {
+      if (out_score32) out_score32[r - row_begin] = h32[(size_t)(r - r0)];
+      if (out_qcdist) out_qcdist[r - row_begin] = hqc[(size_t)(r - r0)];
+      if (out_score64) out_score64[r - row_begin] = h64[(size_t)(r - r0)];
+    }
+  }
+  (void)hipFree(d32);
+  (void)hipFree(dqc);
+  (void)hipFree(d64);
+  return rc;
+}
+
+int64_t bbq_shard_list_cap(const bbq_index *cix, int64_t k) {
+  if (!cix || k <= 0) return 0;
+  bbq_index *ix = const_cast<bbq_index *>(cix);
+  const int64_t keff = std::min<int64_t>(k, kMaxFastK);
+  build_plan(ix, keff);
+  return ix->plan.list_cap;
+}
+
+int bbq_shard_scan(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, const double *qcorr, int32_t query_bits,
+                   int32_t sim, int64_t k, void *dev_lists, int64_t list_cap, void *dev_counts) {
+  clear_error();
+  int rc = validate_query_args(ix, n_queries, qquant, qcorr, query_bits, sim, k);
+  if (rc != BBQ_OK) return rc;
+  if (n_queries == 0) return BBQ_OK;
+  if (!dev_lists || !dev_counts || list_cap <= 0) return fail(BBQ_ERR_INVALID_ARG, "bbq_shard_scan: null list buffers");
+  if (k == 0 || k > kMaxFastK) return fail(BBQ_ERR_UNSUPPORTED, "bbq_shard_scan: k must be in 1..%lld", (long long)kMaxFastK);
+  HIPCHK(hipSetDevice(ix->device));
+  BatchCtx c{ix, qquant, qcorr, planes_for(qquant, (int64_t)n_queries * ix->dim), query_bits == 1 ? 1 : 0, sim, k};
+  if (c.one_bit) c.planes = 1;
+  build_plan(ix, k);
+  const int Q = std::max(1, ix->opt_batch);
+  const int nslots = std::min(std::max(1, ix->opt_slots), kMaxSlots);
+  const int64_t nsub = ((int64_t)n_queries + Q - 1) / Q;
+  for (int64_t i = 0; i < nsub; ++i) {
+    Slot &s = ix->slots[i % nslots];
+    if (s.busy) {
+      HIPCHK(hipEventSynchronize(s.ev_done));
+      s.busy = false;
+      account_timing(ix, s);
+    }
+    const int nq = (int)std::min<int64_t>(Q, n_queries - i * Q);
+    rc = ensure_slot(ix, s, nq, false);
+    if (rc != BBQ_OK) { drain(ix); return rc; }
+    rc = enqueue_subbatch(c, s, i * Q, nq, reinterpret_cast<uint64_t *>(dev_lists) + (size_t)(i * Q) * list_cap, list_cap,
+                          reinterpret_cast<int32_t *>(dev_counts) + (size_t)(i * Q) * 2);
+    if (rc != BBQ_OK) { drain(ix); return rc; }
+  }
+  for (int i = 0; i < nslots; ++i) {
+    Slot &s = ix->slots[i];
+    if (s.busy) {
+      HIPCHK(hipEventSynchronize(s.ev_done));
+      s.busy = false;
+      account_timing(ix, s);
+    }
+  }
+  return BBQ_OK;
+}
+
+int bbq_get_stats(bbq_index *ix, bbq_stats *out) {
+  if (!ix || !out) return fail(BBQ_ERR_INVALID_ARG, "bbq_get_stats: null");
+  *out = ix->stats;
+  return BBQ_OK;
+}
+int bbq_reset_stats(bbq_index *ix) {
+  if (!ix) return fail(BBQ_ERR_INVALID_ARG, "bbq_reset_stats: null");
+  ix->stats = bbq_stats{};
+  return BBQ_OK;
+}
+
+int bbq_set_option(bbq_index *ix, const char *name, int64_t v) {
+  if (!ix || !name) return fail(BBQ_ERR_INVALID_ARG, "bbq_set_option: null");
+  const std::string n(name);
+  if (n == "batch_queries" && v >= 1 && v <= 1024) ix->opt_batch = (int)v;
+  else if (n == "pipeline_slots" && v >= 1 && v <= kMaxSlots) ix->opt_slots = (int)v;
+  else if (n == "segment_growth" && v >= 2 && v <= 1024) { ix->opt_growth = (int)v; ix->plan.k = -1; }
+  else if (n == "first_segment_rows" && v >= 1024 && v <= 8192 && v % kChunkRows == 0) { ix->opt_s0 = v; ix->plan.k = -1; }
+  else if (n == "tiles_per_wave" && (v == 1 || v == 2 || v == 4)) ix->opt_tpw = (int)v;
+  else if (n == "replay_threads" && v >= 1 && v <= 256) ix->opt_replay_threads = (int)v;
+  else if (n == "force_dense" && (v == 0 || v == 1)) ix->opt_force_dense = (int)v;
+  else return fail(BBQ_ERR_INVALID_ARG, "bbq_set_option: unknown option or value out of range: %s=%lld", name, (long long)v);
+  // buffers are sized per plan/batch: drop them so the next call reallocates
+  (void)hipSetDevice(ix->device);
+  for (int i = 0; i < kMaxSlots; ++i) {
+    if (ix->slots[i].stream) (void)hipStreamSynchronize(ix->slots[i].stream);
+    free_slot_buffers(ix->slots[i]);
+  }
+  return BBQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+// bbq_device.h - structs shared by the HIP kernels and the host orchestration (gfx950 only).
+#pragma once
+#include <stdint.h>
+
+namespace bbq {
+
+constexpr int kTileRows = 64;        // one wavefront = one tile: lane r owns row r of the tile
+constexpr int kChunkRows = 1024;     // one workgroup = 16 tiles; candidate slots are per chunk
+constexpr int kTilesPerChunk = kChunkRows / kTileRows;
+constexpr uint32_t kFlagOverflow = 1u;   // a candidate slot / list / key buffer overflowed
+constexpr uint32_t kFlagNaN = 2u;        // a NaN score was produced: order statistics are meaningless
+
+// Device layout of one index storage (DESIGN.md "HBM layout").  A tile record holds 64 rows:
+//   [w16][64] uint4    16-byte code chunk j of row r at (j*64 + r)*16      -> 1 KiB coalesced per wave load
+//   [64] double2       {lowerInterval, upperInterval}                      -> 1 KiB
+//   [64] double        additionalCorrection                                -> 512 B
+//   [64] double        quantizedComponentSum (only if has_x1)              -> 512 B
+struct IndexView {
+  const uint8_t *tiles;
+  int64_t n_rows;       // valid rows in this storage
+  int32_t w16;          // 16-byte chunks per row = ceil(ceil(dim/8)/16)
+  int32_t tile_stride;  // bytes per tile record
+  int32_t has_x1;       // 0: quantizedComponentSum == popcount(row), recomputed on the fly
+  int32_t dim;
+};
+
+// Per-query uniforms of the score formula (src/batchDotProduct.ts:478-617)
+struct QueryParams {
+  double ay;     // query lowerInterval
+  double ly;     // (upper-lower) [* FOUR_BIT_SCALE for every queryBits != 1]
+  double y1;     // query quantizedComponentSum
+  double qadd;   // query additionalCorrection
+  double cdp;    // centroid . centroid
+  double dimd;   // dimension as a double
+  int32_t sim;   // BBQ_EUCLIDEAN / BBQ_COSINE / BBQ_MAXIMUM_INNER_PRODUCT
+  int32_t one_bit;
+};
+
+struct ScanArgs {
+  IndexView idx;
+  const uint4 *qplanes;        // [Q][w16][QB] bit-planes of the quantized query, packed like the rows
+  const QueryParams *qparams;  // [Q]
+  int64_t chunk_begin;         // first chunk of this launch inside idx
+  int64_t row_id_base;         // global row id of idx row 0
+  // sparse output (candidates above the per-query threshold)
+  const uint32_t *theta;       // [Q] monotone keys; a row is a candidate iff key(score) > theta
+  uint32_t *counts;            // [Q][n_chunks]
+  uint64_t *entries;           // [Q][n_chunks][cap], ascending by row inside a chunk
+  uint32_t *flags;             // [Q]
+  int32_t cap;
+  int32_t n_chunks;            // chunks in this launch (= gridDim.x)
+  // dense output (every row), indexed by row - chunk_begin*1024
+  float *dense_score32;        // [Q][dense_stride] or null
+  int32_t *dense_qcdist;       // or null
+  double *dense_score64;       // or null
+  int64_t dense_stride;
+};
+
+struct FinalizeArgs {
+  // input: either slots of one sparse launch, or the dense f32 scores of the first segment
+  const uint32_t *counts;      // [Q][n_chunks]
+  const uint64_t *entries;     // [Q][n_chunks][cap]
+  const float *dense_score32;  // [Q][dense_stride]  (dense_rows > 0 selects this input)
+  int64_t dense_stride;
+  int32_t dense_rows;
+  int64_t dense_row_id_base;
+  int32_t n_chunks;
+  int32_t cap;
+  // candidate list being built, ascending by global row
+  uint64_t *lists;             // [Q][list_cap]
+  int32_t *list_counts;        // [Q][2] {count, flags}
+  int64_t list_cap;
+  int32_t emit;                // 0: thresholds only (pilot replica on a shard that does not own those rows)
+  // running top-k keys and the threshold for the next segment
+  uint32_t *topk_keys;         // [Q][k]
+  int32_t *topk_counts;        // [Q]
+  uint32_t *theta;             // [Q]
+  uint32_t *flags;             // [Q]
+  int32_t k;
+  int32_t need_theta;          // 0 on the last segment
+};
+
+constexpr int kFinalizeThreads = 1024;
+constexpr int kFinalizeKeyCap = 12288;   // LDS key buffer of the finalize kernel (new keys + running top-k)
+
+__host__ __device__ inline uint32_t key_of_bits(uint32_t b) { return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+
+}  // namespace bbq

@@ -1,0 +1,427 @@
+// bbq_kernels.hip - hand-written gfx950 (CDNA4) kernels of the binary-quantized scan + top-k path.
+//
+//   bbq_scan_kernel      the hot kernel: streams tile records from HBM with coalesced 16-byte loads
+//                        (lane r owns row r of a 64-row tile: no cross-lane reduction at all), ANDs them
+//                        with the query bit-planes staged once per workgroup in LDS, accumulates popcounts
+//                        per plane, evaluates the reference's float64 score formula in the reference's
+//                        operation order, rounds to f32 and either stores every score (DENSE) or appends
+//                        the rows above the per-query threshold to the chunk's candidate slots.
+//                        Replaces createDirectPackedBuffer + computeBatchFourBitDotProductDirectPacked /
+//                        computeBatchDotProductDirectPacked + computeBatch{FourBit,OneBit}SimilarityScores
+//                        (reference src/batchDotProduct.ts:22-49,420-436,478-617,
+//                        src/utils/computeBatchFourBitDotProductDirectPacked.ts:10-53) and the f32 store of
+//                        src/binaryQuantizationFormat.ts:353,378.
+//   bbq_finalize_kernel  per query: compacts the candidate slots of one launch into the row-ordered
+//                        candidate list, and radix-selects the k-th largest key seen so far = the threshold
+//                        of the next segment (a lower bound of the reference heap's minimum at that point,
+//                        src/binaryQuantizationFormat.ts:387-400).
+//   bbq_retile_kernel    index build: row-major packed rows + corrections -> tile records.
+//
+// HBM-bound integer/byte work: no MFMA.  Compiled with -ffp-contract=off; the pragma below repeats it.
+#include <hip/hip_runtime.h>
+#include "bbq_device.h"
+#include "bbq_launch.h"
+
+#pragma clang fp contract(off)
+
+namespace bbq {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t popc4(u32x4 v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+
+// Math.max(x, 0) of the reference: NaN propagates, -0 -> +0
+__device__ __forceinline__ double js_max0(double x) { return (x != x) ? x : (x > 0.0 ? x : 0.0); }
+
+// src/batchDotProduct.ts:478-541 (one_bit) / :554-617 (every other queryBits); SURVEY App. A.4.
+// Parenthesised exactly as JavaScript evaluates the reference's expressions; no FMA contraction.
+__device__ __forceinline__ double score_f64(double qc, double ax, double ux, double xadd, double x1, const QueryParams &p) {
+  const double lx = ux - ax;
+  const double t1 = (ax * p.ay) * p.dimd;
+  const double t2 = (p.ay * lx) * x1;
+  const double t3 = (ax * p.ly) * p.y1;
+  const double t4 = (lx * p.ly) * qc;
+  const double s = ((t1 + t2) + t3) + t4;
+  if (p.sim == 0) {  // EUCLIDEAN
+    const double e = (p.qadd + xadd) - (2.0 * s);
+    return js_max0(1.0 / (1.0 + e));
+  }
+  const double t = p.one_bit ? (s + ((p.qadd + xadd) - p.cdp)) : (((s + p.qadd) + xadd) - p.cdp);
+  if (p.sim == 1) return js_max0((1.0 + t) / 2.0);  // COSINE
+  if (p.one_bit) return t < 0.0 ? 1.0 / (1.0 - t) : t + 1.0;
+  const double FBS = 1.0 / 15.0;  // FOUR_BIT_SCALE, src/constants.ts:20 - a true division by it, not *15
+  return t < 0.0 ? 1.0 / (1.0 - t / FBS) : t / FBS + 1.0;
+}
+
+// One tile = 64 rows, one row per lane.  W = compile-time number of 16-byte chunks per row (0: runtime).
+template <int QB, int W>
+__device__ __forceinline__ void tile_popcounts(const uint8_t *__restrict__ tp, int lane, int w16,
+                                               const u32x4 *__restrict__ s_planes, uint32_t (&acc)[QB], uint32_t &ones) {
+  const u32x4 *__restrict__ cp = reinterpret_cast<const u32x4 *>(tp) + lane;
+#pragma unroll
+  for (int p = 0; p < QB; ++p) acc[p] = 0;
+  ones = 0;
+  if constexpr (W > 0) {
+    u32x4 c[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) c[j] = __builtin_nontemporal_load(cp + j * kTileRows);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+#pragma unroll
+      for (int p = 0; p < QB; ++p) acc[p] += popc4(c[j] & s_planes[j * QB + p]);
+      ones += popc4(c[j]);
+    }
+  } else {
+    for (int j = 0; j < w16; ++j) {
+      const u32x4 c = __builtin_nontemporal_load(cp + j * kTileRows);
+#pragma unroll
+      for (int p = 0; p < QB; ++p) acc[p] += popc4(c & s_planes[j * QB + p]);
+      ones += popc4(c);
+    }
+  }
+}
+
+// grid = (chunks, queries); block = 16 waves / TPW; wave w handles tiles [w*TPW, (w+1)*TPW) of its chunk
+template <int QB, int W, bool DENSE, int TPW>
+__global__ __launch_bounds__(1024 / TPW) void bbq_scan_kernel(const ScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NT = 1024 / TPW;
+  const int w16 = W > 0 ? W : a.idx.w16;
+  u32x4 *s_planes = reinterpret_cast<u32x4 *>(smem);
+  uint64_t *s_ent = reinterpret_cast<uint64_t *>(smem + (size_t)w16 * QB * 16);
+  uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_ent + (DENSE ? 0 : a.cap));
+
+  const int q = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  {  // stage the query bit-planes once per workgroup
+    const u32x4 *__restrict__ gp = reinterpret_cast<const u32x4 *>(a.qplanes) + (size_t)q * w16 * QB;
+    for (int i = tid; i < w16 * QB; i += NT) s_planes[i] = gp[i];
+    if (!DENSE && tid == 0) *s_cnt = 0;
+  }
+  const QueryParams p = a.qparams[q];
+  const uint32_t theta = DENSE ? 0u : a.theta[q];
+  __syncthreads();
+
+  const int64_t chunk = a.chunk_begin + blockIdx.x;
+  const int64_t n_tiles = (a.idx.n_rows + kTileRows - 1) / kTileRows;
+  bool nan_seen = false;
+
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int64_t tile = chunk * kTilesPerChunk + wave * TPW + t;
+    if (tile < n_tiles) {  // wave-uniform
+      const uint8_t *__restrict__ tp = a.idx.tiles + tile * (int64_t)a.idx.tile_stride;
+      const uint8_t *__restrict__ cr = tp + (size_t)w16 * (kTileRows * 16);
+      const f64x2 lu = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(cr) + lane);
+      const double xadd = __builtin_nontemporal_load(reinterpret_cast<const double *>(cr + 1024) + lane);
+      double x1 = 0.0;
+      if (a.idx.has_x1) x1 = __builtin_nontemporal_load(reinterpret_cast<const double *>(cr + 1536) + lane);
+
+      uint32_t acc[QB], ones;
+      tile_popcounts<QB, W>(tp, lane, w16, s_planes, acc, ones);
+      uint32_t qc = 0;
+#pragma unroll
+      for (int pl = 0; pl < QB; ++pl) qc += acc[pl] << pl;
+      if (!a.idx.has_x1) x1 = (double)ones;  // quantizedComponentSum of a 1-bit row is its popcount
+
+      const double s64 = score_f64((double)qc, lu.x, lu.y, xadd, x1, p);
+      const float s32 = (float)s64;  // Float32Array store, src/binaryQuantizationFormat.ts:353,378
+      const uint32_t bits = __float_as_uint(s32);
+      const int64_t row = tile * kTileRows + lane;
+      const bool valid = row < a.idx.n_rows;
+      if (valid && (s32 != s32)) nan_seen = true;
+      if constexpr (DENSE) {
+        if (valid) {
+          const int64_t o = (int64_t)q * a.dense_stride + (row - a.chunk_begin * kChunkRows);
+          if (a.dense_score32) a.dense_score32[o] = s32;
+          if (a.dense_qcdist) a.dense_qcdist[o] = (int32_t)qc;
+          if (a.dense_score64) a.dense_score64[o] = s64;
+        }
+      } else {
+        if (valid && (s32 == s32) && key_of_bits(bits) > theta) {
+          const uint32_t slot = atomicAdd(s_cnt, 1u);
+          if (slot < (uint32_t)a.cap) s_ent[slot] = ((uint64_t)(uint32_t)(a.row_id_base + row) << 32) | bits;
+        }
+      }
+    }
+  }
+  if (__any(nan_seen) && lane == 0) atomicOr(a.flags + q, kFlagNaN);
+
+  if constexpr (!DENSE) {
+    __syncthreads();
+    uint32_t cnt = *s_cnt;
+    if (cnt > (uint32_t)a.cap) {
+      if (tid == 0) atomicOr(a.flags + q, kFlagOverflow);
+      cnt = (uint32_t)a.cap;
+    }
+    uint64_t *__restrict__ out = a.entries + ((size_t)q * a.n_chunks + blockIdx.x) * (size_t)a.cap;
+    for (uint32_t i = tid; i < cnt; i += NT) {  // rows are distinct: rank by counting puts them in row order
+      const uint64_t e = s_ent[i];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < cnt; ++j) rank += (s_ent[j] < e) ? 1u : 0u;
+      out[rank] = e;
+    }
+    if (tid == 0) a.counts[(size_t)q * a.n_chunks + blockIdx.x] = cnt;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// finalize: one workgroup (1024 threads) per query
+
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t *s_wave, uint32_t &total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t n = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += n;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  uint32_t wave_off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const uint32_t x = s_wave[w];
+    if (w < wave) wave_off += x;
+    tot += x;
+  }
+  total = tot;
+  __syncthreads();
+  return wave_off + incl - v;
+}
+
+__global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const FinalizeArgs a) {
+  __shared__ uint32_t s_keys[kFinalizeKeyCap];
+  __shared__ uint32_t s_hist[256];
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_misc[4];
+  const int q = blockIdx.x;
+  const int tid = threadIdx.x;
+  uint32_t flags = 0;
+  const int64_t base = a.emit ? a.list_counts[2 * q] : 0;
+  __syncthreads();  // every thread has read the running count before thread 0 rewrites it below
+  uint64_t *__restrict__ list = a.lists + (size_t)q * a.list_cap;
+  uint32_t m_new = 0;
+
+  if (a.dense_rows > 0) {
+    m_new = (uint32_t)a.dense_rows;
+    const float *__restrict__ d = a.dense_score32 + (size_t)q * a.dense_stride;
+    for (uint32_t i = tid; i < m_new; i += kFinalizeThreads) {
+      const uint32_t bits = __float_as_uint(d[i]);
+      if (i < (uint32_t)kFinalizeKeyCap) s_keys[i] = key_of_bits(bits);
+      if (a.emit && base + i < a.list_cap) list[base + i] = ((uint64_t)(uint32_t)(a.dense_row_id_base + i) << 32) | bits;
+    }
+  } else {
+    const int cpt = (a.n_chunks + kFinalizeThreads - 1) / kFinalizeThreads;
+    const int c0 = min(tid * cpt, a.n_chunks), c1 = min(c0 + cpt, a.n_chunks);
+    const uint32_t *__restrict__ cnts = a.counts + (size_t)q * a.n_chunks;
+    uint32_t sum = 0;
+    for (int c = c0; c < c1; ++c) sum += cnts[c];
+    uint32_t total;
+    uint32_t off = block_exclusive_scan_1024(sum, s_wave, total);
+    m_new = total;
+    for (int c = c0; c < c1; ++c) {
+      const uint32_t n = cnts[c];
+      const uint64_t *__restrict__ e = a.entries + ((size_t)q * a.n_chunks + c) * (size_t)a.cap;
+      for (uint32_t i = 0; i < n; ++i, ++off) {
+        const uint64_t ent = e[i];
+        if (a.emit && base + off < a.list_cap) list[base + off] = ent;
+        if (off < (uint32_t)kFinalizeKeyCap) s_keys[off] = key_of_bits((uint32_t)ent);
+      }
+    }
+  }
+  if (a.emit) {
+    if (base + m_new > a.list_cap) flags |= kFlagOverflow;
+    if (tid == 0) a.list_counts[2 * q] = (int32_t)min((int64_t)(base + m_new), a.list_cap);
+  }
+
+  if (a.need_theta) {
+    const uint32_t tcount = (uint32_t)a.topk_counts[q];
+    uint32_t *__restrict__ tk = a.topk_keys + (size_t)q * a.k;
+    if (m_new + tcount > (uint32_t)kFinalizeKeyCap) {
+      flags |= kFlagOverflow;  // theta stays as it is: still a valid (weaker) bound
+    } else {
+      for (uint32_t i = tid; i < tcount; i += kFinalizeThreads) s_keys[m_new + i] = tk[i];
+      const uint32_t M = m_new + tcount;
+      __syncthreads();
+      if (M < (uint32_t)a.k) {
+        // fewer than k rows seen so far: the reference heap is still filling, everything stays a candidate
+        for (uint32_t i = tid; i < M; i += kFinalizeThreads) tk[i] = s_keys[i];
+        if (tid == 0) { a.topk_counts[q] = (int32_t)M; a.theta[q] = 0u; }
+      } else {
+        // 4-pass radix select of the k-th largest key
+        uint32_t prefix = 0, mask = 0, kk = (uint32_t)a.k;
+        for (int pass = 3; pass >= 0; --pass) {
+          if (tid < 256) s_hist[tid] = 0;
+          __syncthreads();
+          const int sh = pass * 8;
+          for (uint32_t i = tid; i < M; i += kFinalizeThreads) {
+            const uint32_t key = s_keys[i];
+            if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> sh) & 255u], 1u);
+          }
+          __syncthreads();
+          if (tid == 0) {
+            uint32_t cum = 0;
+            int b = 255;
+            for (; b > 0; --b) {
+              if (cum + s_hist[b] >= kk) break;
+              cum += s_hist[b];
+            }
+            s_misc[0] = (uint32_t)b;
+            s_misc[1] = kk - cum;
+          }
+          __syncthreads();
+          prefix |= s_misc[0] << sh;
+          mask |= 255u << sh;
+          kk = s_misc[1];
+          __syncthreads();
+        }
+        const uint32_t th = prefix;  // exactly the k-th largest key among the M keys
+        if (tid == 0) s_misc[2] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < M; i += kFinalizeThreads) {
+          const uint32_t key = s_keys[i];
+          if (key > th) tk[atomicAdd(&s_misc[2], 1u)] = key;
+        }
+        __syncthreads();
+        const uint32_t gt = s_misc[2];  // < k by construction
+        for (uint32_t i = gt + tid; i < (uint32_t)a.k; i += kFinalizeThreads) tk[i] = th;
+        if (tid == 0) { a.topk_counts[q] = a.k; a.theta[q] = th; }
+      }
+    }
+  }
+  if (tid == 0) {
+    const uint32_t f = a.flags[q] | flags;
+    a.flags[q] = f;
+    a.list_counts[2 * q + 1] = (int32_t)f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// index build: row-major (codes [n][pb], corr [n][4]) -> tile records.  One thread per (row, chunk).
+
+__global__ __launch_bounds__(256) void bbq_retile_kernel(const uint8_t *__restrict__ codes, const double *__restrict__ corr,
+                                                        int64_t n_rows, int32_t pb, uint8_t *__restrict__ tiles, int32_t w16,
+                                                        int32_t tile_stride, int32_t has_x1, int64_t n_rows_padded) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = gid / (w16 + 1);
+  const int j = (int)(gid % (w16 + 1));
+  if (row >= n_rows_padded) return;
+  const int64_t tile = row / kTileRows;
+  const int r = (int)(row % kTileRows);
+  uint8_t *tp = tiles + tile * (int64_t)tile_stride;
+  if (j < w16) {
+    u32x4 v = {0, 0, 0, 0};
+    if (row < n_rows) {
+      uint32_t w[4] = {0, 0, 0, 0};
+      const uint8_t *src = codes + row * (int64_t)pb;
+      for (int b = 0; b < 16; ++b) {
+        const int byte = j * 16 + b;
+        if (byte < pb) w[b >> 2] |= (uint32_t)src[byte] << (8 * (b & 3));
+      }
+      v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+    }
+    reinterpret_cast<u32x4 *>(tp)[j * kTileRows + r] = v;
+  } else {
+    uint8_t *cr = tp + (size_t)w16 * (kTileRows * 16);
+    f64x2 lu = {0.0, 0.0};
+    double add = 0.0, x1 = 0.0;
+    if (row < n_rows) {
+      lu.x = corr[row * 4 + 0]; lu.y = corr[row * 4 + 1]; add = corr[row * 4 + 2]; x1 = corr[row * 4 + 3];
+    }
+    reinterpret_cast<f64x2 *>(cr)[r] = lu;
+    reinterpret_cast<double *>(cr + 1024)[r] = add;
+    if (has_x1) reinterpret_cast<double *>(cr + 1536)[r] = x1;
+  }
+}
+
+// does quantizedComponentSum equal the row's popcount everywhere? (then it need not be stored)
+__global__ __launch_bounds__(256) void bbq_check_x1_kernel(const uint8_t *__restrict__ codes, const double *__restrict__ corr,
+                                                          int64_t n_rows, int32_t pb, uint32_t *__restrict__ mismatch) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n_rows) return;
+  const uint8_t *src = codes + row * (int64_t)pb;
+  uint32_t ones = 0;
+  for (int b = 0; b < pb; ++b) ones += __popc((uint32_t)src[b]);
+  if (!(corr[row * 4 + 3] == (double)ones)) atomicOr(mismatch, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// launch wrappers (declared in bbq_launch.h)
+
+template <int QB, int W, bool DENSE, int TPW>
+static hipError_t launch_scan_t(const ScanArgs &a, int n_queries, int n_chunks, hipStream_t s) {
+  const int w16 = W > 0 ? W : a.idx.w16;
+  const size_t smem = (size_t)w16 * QB * 16 + (DENSE ? 0 : (size_t)a.cap * 8) + 16;
+  dim3 grid((unsigned)n_chunks, (unsigned)n_queries, 1), block(1024 / TPW, 1, 1);
+  hipLaunchKernelGGL((bbq_scan_kernel<QB, W, DENSE, TPW>), grid, block, smem, s, a);
+  return hipGetLastError();
+}
+
+template <int QB, int W, bool DENSE>
+static hipError_t launch_scan_tpw(const ScanArgs &a, int nq, int nc, int tpw, hipStream_t s) {
+  switch (tpw) {
+    case 2: return launch_scan_t<QB, W, DENSE, 2>(a, nq, nc, s);
+    case 4: return launch_scan_t<QB, W, DENSE, 4>(a, nq, nc, s);
+    default: return launch_scan_t<QB, W, DENSE, 1>(a, nq, nc, s);
+  }
+}
+
+template <int QB, bool DENSE>
+static hipError_t launch_scan_w(const ScanArgs &a, int nq, int nc, int tpw, hipStream_t s) {
+  switch (a.idx.w16) {
+    case 1: return launch_scan_tpw<QB, 1, DENSE>(a, nq, nc, tpw, s);    // dim <= 128
+    case 6: return launch_scan_tpw<QB, 6, DENSE>(a, nq, nc, tpw, s);    // dim 768
+    case 8: return launch_scan_tpw<QB, 8, DENSE>(a, nq, nc, tpw, s);    // dim 1024
+    case 12: return launch_scan_tpw<QB, 12, DENSE>(a, nq, nc, tpw, s);  // dim 1536
+    default: return launch_scan_tpw<QB, 0, DENSE>(a, nq, nc, tpw, s);
+  }
+}
+
+hipError_t launch_scan(const ScanArgs &a, int planes, bool dense, int n_queries, int n_chunks, int tiles_per_wave,
+                       hipStream_t s) {
+  if (n_chunks <= 0 || n_queries <= 0) return hipSuccess;
+  if (dense) {
+    switch (planes) {
+      case 1: return launch_scan_w<1, true>(a, n_queries, n_chunks, tiles_per_wave, s);
+      case 2: return launch_scan_w<2, true>(a, n_queries, n_chunks, tiles_per_wave, s);
+      case 4: return launch_scan_w<4, true>(a, n_queries, n_chunks, tiles_per_wave, s);
+      default: return launch_scan_w<8, true>(a, n_queries, n_chunks, tiles_per_wave, s);
+    }
+  }
+  switch (planes) {
+    case 1: return launch_scan_w<1, false>(a, n_queries, n_chunks, tiles_per_wave, s);
+    case 2: return launch_scan_w<2, false>(a, n_queries, n_chunks, tiles_per_wave, s);
+    case 4: return launch_scan_w<4, false>(a, n_queries, n_chunks, tiles_per_wave, s);
+    default: return launch_scan_w<8, false>(a, n_queries, n_chunks, tiles_per_wave, s);
+  }
+}
+
+hipError_t launch_finalize(const FinalizeArgs &a, int n_queries, hipStream_t s) {
+  hipLaunchKernelGGL(bbq_finalize_kernel, dim3((unsigned)n_queries), dim3(kFinalizeThreads), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_retile(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t pb, uint8_t *tiles, int32_t w16,
+                         int32_t tile_stride, int32_t has_x1, hipStream_t s) {
+  const int64_t n_pad = (n_rows + kTileRows - 1) / kTileRows * kTileRows;
+  const int64_t threads = n_pad * (w16 + 1);
+  if (threads == 0) return hipSuccess;
+  const int64_t blocks = (threads + 255) / 256;
+  hipLaunchKernelGGL(bbq_retile_kernel, dim3((unsigned)blocks), dim3(256), 0, s, codes, corr, n_rows, pb, tiles, w16, tile_stride,
+                     has_x1, n_pad);
+  return hipGetLastError();
+}
+
+hipError_t launch_check_x1(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t pb, uint32_t *mismatch, hipStream_t s) {
+  if (n_rows == 0) return hipSuccess;
+  const int64_t blocks = (n_rows + 255) / 256;
+  hipLaunchKernelGGL(bbq_check_x1_kernel, dim3((unsigned)blocks), dim3(256), 0, s, codes, corr, n_rows, pb, mismatch);
+  return hipGetLastError();
+}
+
+}  // namespace bbq

@@ -1,0 +1,17 @@
+// bbq_launch.h - host-callable launch wrappers of the kernels in bbq_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include "bbq_device.h"
+
+namespace bbq {
+
+// planes: number of query bit-planes (1, 2, 4 or 8); tiles_per_wave: 1, 2 or 4
+hipError_t launch_scan(const ScanArgs &a, int planes, bool dense, int n_queries, int n_chunks, int tiles_per_wave,
+                       hipStream_t s);
+hipError_t launch_finalize(const FinalizeArgs &a, int n_queries, hipStream_t s);
+hipError_t launch_retile(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t pb, uint8_t *tiles, int32_t w16,
+                         int32_t tile_stride, int32_t has_x1, hipStream_t s);
+hipError_t launch_check_x1(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t pb, uint32_t *mismatch,
+                           hipStream_t s);
+
+}  // namespace bbq

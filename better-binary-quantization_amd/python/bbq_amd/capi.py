@@ -1,0 +1,227 @@
+"""ctypes binding of libbbq.so (include/bbq.h).  Plumbing only: every numeric operation happens in the
+C++/HIP library.  There is no CPU fallback - device entry points raise BBQError(BBQ_ERR_NO_DEVICE) without a GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))            # better-binary-quantization_amd/
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libbbq.so")
+
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED = 0, 1, 2, 3, 4, 5
+ERR_DIM_MISMATCH, ERR_NEGATIVE_K, ERR_NAN_INPUT, ERR_INF_INPUT, ERR_EMPTY = 6, 7, 8, 9, 10
+EUCLIDEAN, COSINE, MAXIMUM_INNER_PRODUCT = 0, 1, 2
+SIMS = {"EUCLIDEAN": 0, "COSINE": 1, "MAXIMUM_INNER_PRODUCT": 2}
+
+# every symbol include/bbq.h declares (tests/test_capi_symbols.py checks the library exports all of them)
+SYMBOLS = [
+    "bbq_last_error", "bbq_abi_version", "bbq_device_count", "bbq_index_create", "bbq_index_create_shard",
+    "bbq_index_destroy", "bbq_index_size", "bbq_index_dimension", "bbq_index_bytes_per_row", "bbq_search",
+    "bbq_search_batch", "bbq_score_rows", "bbq_shard_scan", "bbq_shard_list_cap", "bbq_replay",
+    "bbq_quantize_vectors", "bbq_quantize_query", "bbq_quantize_query_vector", "bbq_centroid_dp", "bbq_get_stats",
+    "bbq_reset_stats", "bbq_set_option",
+]
+
+
+class BBQError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(message)
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [("last_scan_ms", C.c_double), ("last_scan_rows", C.c_int64), ("last_scan_bytes", C.c_int64),
+                ("candidates", C.c_int64), ("dense_fallbacks", C.c_int64), ("total_scan_ms", C.c_double),
+                ("total_scan_bytes", C.c_int64), ("total_scan_launches", C.c_int64)]
+
+
+_lib = None
+
+
+def lib():
+    """loads libbbq.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')"""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BBQError(ERR_NO_DEVICE, "libbbq.so is not built (%s): run __graft_entry__.build(); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.bbq_last_error.restype = C.c_char_p
+    L.bbq_abi_version.restype = C.c_int
+    L.bbq_device_count.restype = C.c_int
+    L.bbq_index_create.argtypes = [vp, vp, i64, i32, i32, dbl, i32, C.POINTER(vp)]
+    L.bbq_index_create_shard.argtypes = [vp, vp, i64, i32, i32, dbl, i64, vp, vp, i64, i32, C.POINTER(vp)]
+    L.bbq_index_destroy.argtypes = [vp]
+    L.bbq_index_destroy.restype = None
+    L.bbq_index_size.argtypes = [vp]
+    L.bbq_index_size.restype = i64
+    L.bbq_index_dimension.argtypes = [vp]
+    L.bbq_index_dimension.restype = i32
+    L.bbq_index_bytes_per_row.argtypes = [vp]
+    L.bbq_index_bytes_per_row.restype = i32
+    L.bbq_search.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp, vp]
+    L.bbq_search_batch.argtypes = [vp, i32, vp, vp, i32, i32, i64, vp, vp, vp]
+    L.bbq_score_rows.argtypes = [vp, vp, vp, i32, i32, i64, i64, vp, vp, vp]
+    L.bbq_shard_scan.argtypes = [vp, i32, vp, vp, i32, i32, i64, vp, i64, vp]
+    L.bbq_shard_list_cap.argtypes = [vp, i64]
+    L.bbq_shard_list_cap.restype = i64
+    L.bbq_replay.argtypes = [i32, vp, vp, i64, i64, vp, vp, vp]
+    L.bbq_quantize_vectors.argtypes = [vp, i64, i32, i32, i32, dbl, i32, i32, vp, vp, vp, vp, vp]
+    L.bbq_quantize_query.argtypes = [vp, i32, vp, i32, i32, dbl, i32, vp, vp]
+    L.bbq_quantize_query_vector.argtypes = [vp, i32, vp, i32, i32, dbl, i32, vp, vp]
+    L.bbq_centroid_dp.argtypes = [vp, i32]
+    L.bbq_centroid_dp.restype = dbl
+    L.bbq_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.bbq_reset_stats.argtypes = [vp]
+    L.bbq_set_option.argtypes = [vp, C.c_char_p, i64]
+    _lib = L
+    return L
+
+
+def _chk(rc):
+    if rc != OK:
+        raise BBQError(rc, lib().bbq_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def device_count():
+    return lib().bbq_device_count()
+
+
+# ------------------------------------------------------------------------------------------------ host quantizer
+
+def quantize_vectors(vectors, sim, index_bits=1, lam=0.1, iters=5, n_threads=0):
+    v = np.ascontiguousarray(vectors, np.float32)
+    if v.ndim != 2:
+        raise BBQError(ERR_INVALID_ARG, "vectors must be [n, dim]")
+    n, dim = v.shape
+    if n == 0:
+        raise BBQError(ERR_EMPTY, "向量集合不能为空")
+    pb = (dim + 7) // 8 if index_bits == 1 else dim
+    codes = np.zeros((n, pb), np.uint8)
+    corr = np.zeros((n, 4), np.float64)
+    cen = np.zeros(dim, np.float32)
+    _chk(lib().bbq_quantize_vectors(_ptr(v), n, dim, sim, index_bits, lam, iters, n_threads, _ptr(codes), _ptr(corr), _ptr(cen),
+                                   None, None))
+    return codes, corr, cen
+
+
+def quantize_query(query, centroid, sim, query_bits=4, lam=0.1, iters=5, search_path=True):
+    q = np.ascontiguousarray(query, np.float32)
+    cen = np.ascontiguousarray(centroid, np.float32)
+    dim = q.shape[0]
+    qq = np.zeros(dim, np.uint8)
+    qc = np.zeros(4, np.float64)
+    fn = lib().bbq_quantize_query if search_path else lib().bbq_quantize_query_vector
+    _chk(fn(_ptr(q), dim, _ptr(cen), sim, query_bits, lam, iters, _ptr(qq), _ptr(qc)))
+    return qq, qc
+
+
+def centroid_dp(centroid):
+    cen = np.ascontiguousarray(centroid, np.float32)
+    return lib().bbq_centroid_dp(_ptr(cen), cen.shape[0])
+
+
+# ------------------------------------------------------------------------------------------------ device index
+
+class Index:
+    """a device-resident index shard (bbq_index)"""
+
+    def __init__(self, codes, corr, dim, cdp, device=0, index_bits=1, row_base=0, pilot_codes=None, pilot_corr=None):
+        codes = np.ascontiguousarray(codes, np.uint8)
+        corr = np.ascontiguousarray(corr, np.float64)
+        n = codes.shape[0]
+        h = C.c_void_p()
+        if pilot_codes is not None:
+            pilot_codes = np.ascontiguousarray(pilot_codes, np.uint8)
+            pilot_corr = np.ascontiguousarray(pilot_corr, np.float64)
+            npilot = pilot_codes.shape[0]
+        else:
+            npilot = 0
+        _chk(lib().bbq_index_create_shard(_ptr(codes), _ptr(corr), n, dim, index_bits, cdp, row_base, _ptr(pilot_codes),
+                                         _ptr(pilot_corr), npilot, device, C.byref(h)))
+        self._h = h
+        self.dim = dim
+        self.n = n
+
+    def close(self):
+        if self._h:
+            lib().bbq_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def bytes_per_row(self):
+        return lib().bbq_index_bytes_per_row(self._h)
+
+    def set_option(self, name, value):
+        _chk(lib().bbq_set_option(self._h, name.encode(), int(value)))
+
+    def stats(self):
+        s = Stats()
+        _chk(lib().bbq_get_stats(self._h, C.byref(s)))
+        return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
+
+    def reset_stats(self):
+        _chk(lib().bbq_reset_stats(self._h))
+
+    def search(self, qquant, qcorr, query_bits, sim, k):
+        idx, sc, n = self.search_batch(np.asarray(qquant)[None, :], np.asarray(qcorr)[None, :], query_bits, sim, k)
+        return idx[0, :n[0]], sc[0, :n[0]]
+
+    def search_batch(self, qquant, qcorr, query_bits, sim, k):
+        qq = np.ascontiguousarray(qquant, np.uint8)
+        qc = np.ascontiguousarray(qcorr, np.float64)
+        nq = qq.shape[0]
+        if nq and qq.shape[1] != self.dim:
+            raise BBQError(ERR_DIM_MISMATCH, "查询向量维度与目标向量维度不匹配")
+        kk = max(int(k), 0)
+        idx = np.zeros((nq, kk), np.int32)
+        sc = np.zeros((nq, kk), np.float32)
+        cnt = np.zeros(nq, np.int64)
+        _chk(lib().bbq_search_batch(self._h, nq, _ptr(qq), _ptr(qc), query_bits, sim, k, _ptr(idx), _ptr(sc), _ptr(cnt)))
+        return idx, sc, cnt
+
+    def score_rows(self, qquant, qcorr, query_bits, sim, row_begin=0, row_count=None):
+        qq = np.ascontiguousarray(qquant, np.uint8)
+        qc = np.ascontiguousarray(qcorr, np.float64)
+        if row_count is None:
+            row_count = self.n - row_begin
+        d = np.zeros(row_count, np.int32)
+        s64 = np.zeros(row_count, np.float64)
+        s32 = np.zeros(row_count, np.float32)
+        _chk(lib().bbq_score_rows(self._h, _ptr(qq), _ptr(qc), query_bits, sim, row_begin, row_count, _ptr(d), _ptr(s64), _ptr(s32)))
+        return d, s64, s32
+
+    def shard_list_cap(self, k):
+        return lib().bbq_shard_list_cap(self._h, k)
+
+    def shard_scan(self, qquant, qcorr, query_bits, sim, k, dev_lists_ptr, list_cap, dev_counts_ptr):
+        qq = np.ascontiguousarray(qquant, np.uint8)
+        qc = np.ascontiguousarray(qcorr, np.float64)
+        _chk(lib().bbq_shard_scan(self._h, qq.shape[0], _ptr(qq), _ptr(qc), query_bits, sim, k, dev_lists_ptr, list_cap,
+                                 dev_counts_ptr))
+
+
+def replay(lists, n_total, k):
+    """lists: sequence of uint64 numpy arrays (ascending shard order).  Host only - needs no device."""
+    arrs = [np.ascontiguousarray(a, np.uint64) for a in lists]
+    n = len(arrs)
+    ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrs])
+    counts = np.array([a.shape[0] for a in arrs], np.int64)
+    kk = max(int(k), 0)
+    idx = np.zeros(kk, np.int32)
+    sc = np.zeros(kk, np.float32)
+    cnt = C.c_int64(0)
+    _chk(lib().bbq_replay(n, ptrs, _ptr(counts), n_total, k, _ptr(idx), _ptr(sc), C.byref(cnt)))
+    return idx[:cnt.value], sc[:cnt.value]

@@ -1,0 +1,193 @@
+/*
+ * bbq.h - C ABI of libbbq: the MI355X-native (gfx950 HIP) implementation of the
+ * asymmetric binary-quantized scoring + top-k search path of
+ * leolee9086/Better-Binary-Quantization.
+ *
+ * The reference has no FFI seam on this path (it is pure TypeScript); the boundary is the
+ * internal call searchNearestNeighbors -> computeBatchQuantizedScores -> MinHeap.  Each entry
+ * point below names the reference interface it replaces (paths relative to the reference
+ * checkout).  The N-API addon (better-binary-quantization_amd/napi/bbq_napi.c) and the
+ * ctypes binding (better-binary-quantization_amd/python/bbq_amd/capi.py) bind exactly these
+ * symbols; INTEGRATION.md shows the reference-side patch.
+ *
+ * Conventions: plain pointers and sizes, no framework types.  All input arrays are borrowed for
+ * the duration of the call and never retained or written.  Every function returns BBQ_OK (0) or
+ * a BBQ_ERR_* code; bbq_last_error() returns a thread-local, human-readable message for the last
+ * failure on the calling thread.  There is NO CPU fallback: without a usable HIP device every
+ * device entry point fails with BBQ_ERR_NO_DEVICE.
+ *
+ * Corrections layout (src/types.ts:18-27), 4 doubles per vector:
+ *   {lowerInterval, upperInterval, additionalCorrection, quantizedComponentSum}.
+ * Packed 1-bit rows (src/optimizedScalarQuantizer.ts:420-446): dim d -> byte d>>3, bit 7-(d&7),
+ *   ceil(dim/8) bytes per row.
+ */
+#ifndef BBQ_H
+#define BBQ_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BBQ_ABI_VERSION 1
+
+/* status codes */
+enum {
+  BBQ_OK = 0,
+  BBQ_ERR_INVALID_ARG = 1,   /* null pointer, bad size, bits out of 1..8, ... */
+  BBQ_ERR_NO_DEVICE = 2,     /* no HIP device / runtime unusable: the product path refuses to run */
+  BBQ_ERR_HIP = 3,           /* a HIP call failed; message carries hipGetErrorString */
+  BBQ_ERR_OOM = 4,
+  BBQ_ERR_UNSUPPORTED = 5,   /* e.g. indexBits != 1 scoring (reference: SURVEY A.7 / H4) */
+  BBQ_ERR_DIM_MISMATCH = 6,  /* src/binaryQuantizationFormat.ts:327-329 */
+  BBQ_ERR_NEGATIVE_K = 7,    /* src/binaryQuantizationFormat.ts:324-326 */
+  BBQ_ERR_NAN_INPUT = 8,     /* src/binaryQuantizationFormat.ts:202-204 */
+  BBQ_ERR_INF_INPUT = 9,     /* src/binaryQuantizationFormat.ts:205-207 */
+  BBQ_ERR_EMPTY = 10         /* src/binaryQuantizationFormat.ts:169-171 */
+};
+
+/* src/types.ts:9-13 VectorSimilarityFunction (string enum in the reference) */
+enum { BBQ_EUCLIDEAN = 0, BBQ_COSINE = 1, BBQ_MAXIMUM_INNER_PRODUCT = 2 };
+
+typedef struct bbq_index bbq_index; /* opaque: a device-resident index shard */
+
+/* one top-k candidate as the device emits it: (global row << 32) | IEEE-754 bits of the f32 score */
+typedef uint64_t bbq_cand;
+
+const char *bbq_last_error(void);
+int bbq_abi_version(void);
+/* number of usable HIP devices (0 if none); never fails */
+int bbq_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Index: replaces BinarizedByteVectorValuesImpl (src/binaryQuantizationFormat.ts:24-126) as the
+ * scorer sees it, and createDirectPackedBuffer (src/batchDotProduct.ts:420-436): the packed rows
+ * are staged ONCE, re-tiled into the device layout (DESIGN.md "HBM layout"), instead of being
+ * gathered into a contiguous buffer for every batch of 1000.
+ *
+ *   codes        [n_rows * ceil(dim/8)]  packed 1-bit rows (index_bits must be 1 for scoring)
+ *   corr         [n_rows * 4]            corrections as doubles
+ *   centroid_dp  getCentroidDP(undefined) = centroid . centroid  (src/binaryQuantizationFormat.ts:113-121)
+ *   device       HIP device ordinal
+ */
+int bbq_index_create(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim,
+                     int32_t index_bits, double centroid_dp, int32_t device, bbq_index **out);
+
+/* Row-sharded variant for one-process-per-GPU deployments (new; the reference has no distribution).
+ *   row_base     global row id of this shard's row 0 (shards are contiguous, ascending)
+ *   pilot_codes / pilot_corr / n_pilot
+ *                optional replica of GLOBAL rows [0, n_pilot) (n_pilot a multiple of 1024, or the
+ *                whole index): lets every shard derive valid top-k thresholds without waiting for the
+ *                shards before it.  Pass NULL/0 on the shard that owns row 0 (row_base == 0).
+ */
+int bbq_index_create_shard(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim,
+                           int32_t index_bits, double centroid_dp, int64_t row_base,
+                           const uint8_t *pilot_codes, const double *pilot_corr, int64_t n_pilot,
+                           int32_t device, bbq_index **out);
+void bbq_index_destroy(bbq_index *idx);
+int64_t bbq_index_size(const bbq_index *idx);      /* BinarizedByteVectorValues.size()      src/types.ts:46 */
+int32_t bbq_index_dimension(const bbq_index *idx); /* BinarizedByteVectorValues.dimension() src/types.ts:34 */
+/* bytes of HBM one query sweep reads per row: the figure bench.py prices the roofline with */
+int32_t bbq_index_bytes_per_row(const bbq_index *idx);
+
+/* ------------------------------------------------------------------------------------------
+ * Search: replaces steps 2-4 of BinaryQuantizationFormat.searchNearestNeighbors
+ * (src/binaryQuantizationFormat.ts:349-411): score every row
+ * (BinaryQuantizedScorer.computeBatchQuantizedScores, src/binaryQuantizedScorer.ts:315-420;
+ * computeBatchFourBitDotProductDirectPacked / computeBatchDotProductDirectPacked;
+ * computeBatch{FourBit,OneBit}SimilarityScores src/batchDotProduct.ts:478-617), round to f32,
+ * MinHeap top-k (src/minHeap.ts), descending output.  Bit-exact incl. the order among equal scores.
+ *
+ *   qquant   [dim]   quantized query, one value per dimension (Uint8Array from quantizeQueryVector)
+ *   qcorr    [4]     query corrections
+ *   query_bits       1 selects the 1-bit formulas, anything else the "4-bit" formulas
+ *   out_idx/out_score [k]  (only min(k, size) entries are written); *out_n = number written
+ * k == 0 -> *out_n = 0.  k < 0 -> BBQ_ERR_NEGATIVE_K.
+ */
+int bbq_search(bbq_index *idx, const uint8_t *qquant, const double *qcorr, int32_t query_bits, int32_t sim,
+               int64_t k, int32_t *out_idx, float *out_score, int64_t *out_n);
+
+/* The same for n_queries independent queries (each does its own sweep of the index; the calls are
+ * pipelined on the device).  qquant [n_queries*dim], qcorr [n_queries*4], out_idx/out_score
+ * [n_queries*k] (row q at offset q*k), out_n [n_queries]. */
+int bbq_search_batch(bbq_index *idx, int32_t n_queries, const uint8_t *qquant, const double *qcorr,
+                     int32_t query_bits, int32_t sim, int64_t k, int32_t *out_idx, float *out_score,
+                     int64_t *out_n);
+
+/* Per-row results of computeBatchQuantizedScores (src/binaryQuantizedScorer.ts:389-400) for the
+ * contiguous ords [row_begin, row_begin+row_count): bitDotProduct (integer qcDist), the f64 score and
+ * its f32 rounding (src/binaryQuantizationFormat.ts:353,378).  Any output pointer may be NULL. */
+int bbq_score_rows(bbq_index *idx, const uint8_t *qquant, const double *qcorr, int32_t query_bits, int32_t sim,
+                   int64_t row_begin, int64_t row_count, int32_t *out_qcdist, double *out_score64,
+                   float *out_score32);
+
+/* ------------------------------------------------------------------------------------------
+ * Sharded search (one process per GPU).  bbq_shard_scan sweeps THIS shard for n_queries queries and
+ * leaves, per query, the shard's candidate list - a superset of the rows that ever enter the
+ * reference's heap, in ascending global row order - in caller-provided DEVICE memory, so the host
+ * framework can gather the lists over RCCL; bbq_replay then replays the reference heap
+ * (src/binaryQuantizationFormat.ts:383-411) over the concatenation of all shards' lists.
+ *
+ *   dev_lists   device pointer, [n_queries * list_cap] bbq_cand
+ *   dev_counts  device pointer, [n_queries * 2] int32: {count, flags}; flags != 0 means the list is
+ *               unusable (overflow / NaN score) and the query must take bbq_search's dense path
+ *   The call returns after the device work has completed (lists are ready for a collective).
+ */
+int bbq_shard_scan(bbq_index *idx, int32_t n_queries, const uint8_t *qquant, const double *qcorr,
+                   int32_t query_bits, int32_t sim, int64_t k, void *dev_lists, int64_t list_cap,
+                   void *dev_counts);
+/* recommended list capacity for bbq_shard_scan given k */
+int64_t bbq_shard_list_cap(const bbq_index *idx, int64_t k);
+
+/* Host-only (no device needed): exact replay of the reference heap over candidate lists.
+ *   lists[i] / counts[i]  i = 0..n_lists-1, in ascending shard order; entries ascending by row
+ *   n_total               global number of rows (k2 = min(k, n_total))
+ */
+int bbq_replay(int32_t n_lists, const bbq_cand *const *lists, const int64_t *counts, int64_t n_total, int64_t k,
+               int32_t *out_idx, float *out_score, int64_t *out_n);
+
+/* ------------------------------------------------------------------------------------------
+ * Host-side quantizer (multithreaded C++): what the JS host calls for quantizeVectors /
+ * quantizeQueryVector so that the drop-in API needs no TypeScript arithmetic.
+ */
+/* BinaryQuantizationFormat.quantizeVectors, src/binaryQuantizationFormat.ts:165-263 (+ normalizeVector,
+ * computeCentroid, OptimizedScalarQuantizer.scalarQuantize :108-227, packAsBinary :420-446).
+ * vectors [n*dim] row-major.  index_bits == 1: codes [n*ceil(dim/8)] packed; otherwise codes [n*dim] unpacked.
+ * Fails with BBQ_ERR_EMPTY / BBQ_ERR_NAN_INPUT / BBQ_ERR_INF_INPUT like the reference throws; for the
+ * NaN/Inf cases *bad_row / *bad_col (may be NULL) receive the offending position. */
+int bbq_quantize_vectors(const float *vectors, int64_t n, int32_t dim, int32_t sim, int32_t index_bits,
+                         double lambda, int32_t iters, int32_t n_threads, uint8_t *codes, double *corr,
+                         float *centroid, int64_t *bad_row, int32_t *bad_col);
+/* searchNearestNeighbors' query preparation, src/binaryQuantizationFormat.ts:337-347 + :271-299
+ * (COSINE: the query is normalised twice) */
+int bbq_quantize_query(const float *query, int32_t dim, const float *centroid, int32_t sim, int32_t query_bits,
+                       double lambda, int32_t iters, uint8_t *qquant, double *qcorr);
+/* quantizeQueryVector alone, src/binaryQuantizationFormat.ts:271-299 (normalises once for COSINE) */
+int bbq_quantize_query_vector(const float *query, int32_t dim, const float *centroid, int32_t sim,
+                              int32_t query_bits, double lambda, int32_t iters, uint8_t *qquant, double *qcorr);
+/* computeDotProduct(centroid, centroid), src/vectorOperations.ts:171-185 */
+double bbq_centroid_dp(const float *centroid, int32_t dim);
+
+/* ------------------------------------------------------------------------------------------
+ * Introspection for bench.py / profiling (not part of the drop-in surface)
+ */
+typedef struct {
+  double last_scan_ms;        /* hipEvent time of the dominant (largest) scan launch of the last batch call */
+  int64_t last_scan_rows;     /* rows x queries that launch covered */
+  int64_t last_scan_bytes;    /* algorithmic HBM bytes of that launch */
+  int64_t candidates;         /* candidates replayed on the host in the last call (all queries) */
+  int64_t dense_fallbacks;    /* queries of the last call that took the dense path */
+  double total_scan_ms;       /* sum of hipEvent times of every dominant-scan launch since the last reset */
+  int64_t total_scan_bytes;   /* and their algorithmic bytes */
+  int64_t total_scan_launches;
+} bbq_stats;
+int bbq_get_stats(bbq_index *idx, bbq_stats *out);
+int bbq_reset_stats(bbq_index *idx);
+/* tuning knobs; returns BBQ_ERR_INVALID_ARG for unknown names.  See DESIGN.md "Knobs". */
+int bbq_set_option(bbq_index *idx, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,229 @@
+"""GPU parity: the HIP path, called through the C ABI, against the pinned oracle and the golden vectors.
+Bit-exact: integer qcDist, f64 score, f32 score, top-k indices AND their order (ties included)."""
+import numpy as np
+import pytest
+
+import orclib as O
+from bbqlib import bbq_amd as B
+
+pytestmark = pytest.mark.gpu
+
+CASES = [n for n in O.golden_names() if not n.startswith(("intdot_", "api_"))]
+FULL = [n for n in CASES if O.load_golden(n)["full"]]
+HASHED = [n for n in CASES if not O.load_golden(n)["full"]]
+
+
+def canon64(a):
+    a = np.array(a, np.float64)
+    a[np.isnan(a)] = np.nan
+    return a.view(np.uint64)
+
+
+def canon32(a):
+    a = np.array(a, np.float32)
+    a[np.isnan(a)] = np.nan
+    return a.view(np.uint32)
+
+
+def _index_from_case(g):
+    sim = O.SIMS[g["sim"]]
+    base, queries = O.golden_inputs(g)
+    # the product's own host quantizer builds the index; it must reproduce the reference's bytes
+    codes, corr, cen = B.quantize_vectors(base, sim, 1, g["lambda"], g["iters"])
+    assert O.sha(codes) == g["codes_sha256"]
+    if not np.isnan(corr).any():
+        assert O.sha(corr) == g["corr_sha256"]
+    assert O.sha(cen) == O.sha(O.dec(g["centroid_f32"], "<f4"))
+    cdp = B.centroid_dp(cen)
+    assert np.float64(cdp).view(np.uint64) == O.dec(g["centroid_dp_f64"], "<f8").view(np.uint64)[0]
+    return sim, base, queries, codes, corr, cen, cdp
+
+
+def _check(name, options=None):
+    g = O.load_golden(name)
+    sim, base, queries, codes, corr, cen, cdp = _index_from_case(g)
+    ix = B.Index(codes, corr, g["dim"], cdp)
+    for k_, v_ in (options or {}).items():
+        ix.set_option(k_, v_)
+    try:
+        for qi, rec in enumerate(g["queries"]):
+            qq, qc = B.quantize_query(queries[qi], cen, sim, g["qb"], g["lambda"], g["iters"])
+            np.testing.assert_array_equal(qq, O.dec(rec["qquant_u8"], "u1"))
+            np.testing.assert_array_equal(canon64(qc), canon64(O.dec(rec["qcorr_f64"], "<f8")))
+            d, s64, s32 = ix.score_rows(qq, qc, g["qb"], sim)
+            assert O.sha(d) == rec["qcdist_sha256"], "integer qcDist"
+            if g["full"]:
+                np.testing.assert_array_equal(d, O.dec(rec["qcdist_i32"], "<i4"))
+                np.testing.assert_array_equal(canon64(s64), canon64(O.dec(rec["score_f64"], "<f8")))
+            if not np.isnan(s64).any():
+                assert O.sha(s64) == rec["score_sha256"], "f64 score"
+                assert O.sha(s32) == rec["score_f32_sha256"], "f32 score"
+            for tk in rec["topk"]:
+                idx, sc = ix.search(qq, qc, g["qb"], sim, tk["k"])
+                np.testing.assert_array_equal(idx, O.dec(tk["idx_i32"], "<i4"), err_msg="%s q%d k=%d" % (name, qi, tk["k"]))
+                np.testing.assert_array_equal(canon32(sc), canon32(O.dec(tk["score_f32"], "<f4")))
+    finally:
+        ix.close()
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_golden_full(name):
+    _check(name)
+
+
+@pytest.mark.parametrize("name", HASHED)
+def test_golden_ties_and_big(name):
+    _check(name)
+
+
+@pytest.mark.parametrize("name", ["ties_cos_qb4", "ties_16d_qb1", "big_20000x128_cos", "ties_max_qb4"])
+def test_golden_many_small_segments(name):
+    """force the multi-segment sparse path on small indexes: 1024-row first segment, x2 growth"""
+    _check(name, {"first_segment_rows": 1024, "segment_growth": 2})
+
+
+@pytest.mark.parametrize("name", ["ties_euc_qb4", "c1_1000x128_cos_qb4", "big_20000x128_cos"])
+def test_golden_dense_path(name):
+    _check(name, {"force_dense": 1})
+
+
+@pytest.mark.parametrize("tpw", [2, 4])
+def test_golden_tiles_per_wave(tpw):
+    _check("big_20000x128_cos", {"tiles_per_wave": tpw})
+    _check("m_768d_cos_qb4", {"tiles_per_wave": tpw})
+
+
+def _oracle_topk(codes, corr, dim, qq, qc, qb, sim, cdp, k):
+    _, _, s32 = O.score_all(codes, corr, dim, qq, qc, qb, sim, cdp)
+    return O.heap_topk(s32, k)
+
+
+def test_batch_pipeline_matches_oracle():
+    """more queries than one sub-batch, several pipeline slots; every query equals the oracle's replayed heap"""
+    rng = np.random.default_rng(5)
+    n, dim, nq, k = 30000, 256, 41, 100
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    sim = 1
+    codes, corr, cen = B.quantize_vectors(base, sim)
+    cdp = B.centroid_dp(cen)
+    qs = [B.quantize_query(q, cen, sim, 4) for q in queries]
+    qq = np.stack([a for a, _ in qs])
+    qc = np.stack([b for _, b in qs])
+    ix = B.Index(codes, corr, dim, cdp)
+    try:
+        for opts in ({"batch_queries": 8, "pipeline_slots": 3, "first_segment_rows": 2048, "segment_growth": 4},
+                     {"batch_queries": 16, "pipeline_slots": 2, "replay_threads": 4}):
+            for o, v in opts.items():
+                ix.set_option(o, v)
+            idx, sc, cnt = ix.search_batch(qq, qc, 4, sim, k)
+            assert (cnt == k).all()
+            for i in range(nq):
+                oi, os_ = _oracle_topk(codes, corr, dim, qq[i], qc[i], 4, sim, cdp, k)
+                np.testing.assert_array_equal(idx[i], oi)
+                np.testing.assert_array_equal(sc[i].view(np.uint32), os_.view(np.uint32))
+        st = ix.stats()
+        assert st["dense_fallbacks"] == 0 and st["candidates"] > 0
+    finally:
+        ix.close()
+
+
+@pytest.mark.parametrize("k", [1, 3000, 25000, 70000])
+def test_k_edge_cases(k):
+    """k beyond the fast path (dense replay), k > N (clamped like src/binaryQuantizationFormat.ts:385)"""
+    rng = np.random.default_rng(6)
+    n, dim = 50000, 64
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    sim = 0
+    codes, corr, cen = B.quantize_vectors(base, sim)
+    cdp = B.centroid_dp(cen)
+    qq, qc = B.quantize_query(rng.standard_normal(dim).astype(np.float32), cen, sim, 4)
+    ix = B.Index(codes, corr, dim, cdp)
+    try:
+        idx, sc = ix.search(qq, qc, 4, sim, k)
+        oi, os_ = _oracle_topk(codes, corr, dim, qq, qc, 4, sim, cdp, k)
+        assert len(idx) == min(k, n)
+        np.testing.assert_array_equal(idx, oi)
+        np.testing.assert_array_equal(sc.view(np.uint32), os_.view(np.uint32))
+    finally:
+        ix.close()
+
+
+def test_adversarial_increasing_scores_falls_back_and_stays_exact():
+    """rows sorted by ascending score: every row enters the reference heap, candidate lists overflow, the
+    dense path takes over - result must still be exact"""
+    rng = np.random.default_rng(7)
+    n, dim, k = 40000, 64, 50
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    sim = 1
+    codes, corr, cen = B.quantize_vectors(base, sim)
+    cdp = B.centroid_dp(cen)
+    qq, qc = B.quantize_query(rng.standard_normal(dim).astype(np.float32), cen, sim, 4)
+    _, _, s32 = O.score_all(codes, corr, dim, qq, qc, 4, sim, cdp)
+    order = np.argsort(s32, kind="stable")
+    codes, corr = codes[order].copy(), corr[order].copy()
+    ix = B.Index(codes, corr, dim, cdp)
+    try:
+        idx, sc = ix.search(qq, qc, 4, sim, k)
+        oi, os_ = _oracle_topk(codes, corr, dim, qq, qc, 4, sim, cdp, k)
+        np.testing.assert_array_equal(idx, oi)
+        np.testing.assert_array_equal(sc.view(np.uint32), os_.view(np.uint32))
+        assert ix.stats()["dense_fallbacks"] == 1
+    finally:
+        ix.close()
+
+
+def test_explicit_component_sum_layout():
+    """quantizedComponentSum that is NOT the row popcount (hand-edited corrections) must be honoured (4-double layout)"""
+    g = O.load_golden("m_64d_cos_qb4")
+    sim, base, queries, codes, corr, cen, cdp = _index_from_case(g)
+    corr = corr.copy()
+    corr[::3, 3] += 2.0
+    ix = B.Index(codes, corr, g["dim"], cdp)
+    try:
+        assert ix.bytes_per_row == 16 + 32
+        qq, qc = B.quantize_query(queries[0], cen, sim, 4)
+        d, s64, s32 = ix.score_rows(qq, qc, 4, sim)
+        od, os64, os32 = O.score_all(codes, corr, g["dim"], qq, qc, 4, sim, cdp)
+        np.testing.assert_array_equal(d, od)
+        np.testing.assert_array_equal(s64.view(np.uint64), os64.view(np.uint64))
+        idx, sc = ix.search(qq, qc, 4, sim, 10)
+        oi, _ = O.heap_topk(os32, 10)
+        np.testing.assert_array_equal(idx, oi)
+    finally:
+        ix.close()
+
+
+def test_empty_and_argument_errors():
+    g = O.load_golden("edge_n1")
+    sim, base, queries, codes, corr, cen, cdp = _index_from_case(g)
+    ix = B.Index(codes, corr, g["dim"], cdp)
+    try:
+        qq, qc = B.quantize_query(queries[0], cen, sim, 4)
+        idx, sc = ix.search(qq, qc, 4, sim, 0)
+        assert len(idx) == 0
+        with pytest.raises(B.BBQError) as e:
+            ix.search(qq, qc, 4, sim, -1)
+        assert e.value.code == 7 and "k值不能为负数" in str(e.value)
+        with pytest.raises(B.BBQError):
+            ix.search(qq[:4], qc, 4, sim, 1)
+        with pytest.raises(B.BBQError):
+            ix.score_rows(qq, qc, 4, sim, 0, 5)
+    finally:
+        ix.close()
+    with pytest.raises(B.BBQError) as e:
+        B.Index(np.zeros((4, 8), np.uint8), np.zeros((4, 4)), 8, 0.0, index_bits=2)
+    assert e.value.code == 5
+    empty = B.Index(np.zeros((0, 1), np.uint8), np.zeros((0, 4)), 8, 0.0)
+    idx, sc = empty.search(np.zeros(8, np.uint8), np.zeros(4), 4, 0, 5)
+    assert len(idx) == 0
+    empty.close()
+
+
+def test_python_api_mirror_quicksearch_c1():
+    """BASELINE config 1 through the mirrored public API (src/index.ts:95-111): SURVEY App. C known answer"""
+    g = O.load_golden("c1_1000x128_cos_qb4")
+    base, queries = O.golden_inputs(g)
+    res = B.quickSearch(queries[0], list(base), 10)
+    assert [r["index"] for r in res] == [438, 839, 190, 656, 637, 545, 630, 174, 862, 42]
+    assert res[0]["score"] == 0.6655263304710388
