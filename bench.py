@@ -114,12 +114,15 @@ def cpu_baseline(dim, k, codes, corr, qq, qc, cdp, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=16, help="queries per step (each sweeps the index on its own)")
+    ap.add_argument("--batch", type=int, default=64, help="queries per step (each sweeps the index on its own)")
+    ap.add_argument("--sub-batch", type=int, default=16, help="queries per device launch sequence (pipelined inside a step)")
+    ap.add_argument("--slots", type=int, default=3, help="pipeline slots (streams) inside the library")
+    ap.add_argument("--replay-threads", type=int, default=8, help="host threads replaying the reference heap")
     ap.add_argument("--pilot", type=int, default=65536, help="replicated pilot rows per non-root shard (multi-GPU)")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -158,7 +161,9 @@ def main():
             pilot = synth_rows(1, 0, P, pb)
     ix = B.Index(codes, corr, dim, cdp, device=device, row_base=r0,
                  pilot_codes=None if pilot is None else pilot[0], pilot_corr=None if pilot is None else pilot[1])
-    ix.set_option("batch_queries", Q)
+    ix.set_option("batch_queries", min(args.sub_batch, Q))
+    ix.set_option("pipeline_slots", args.slots)
+    ix.set_option("replay_threads", args.replay_threads)
     for o in args.opt:
         name, val = o.split("=")
         ix.set_option(name, int(val))
@@ -237,7 +242,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64 popcount + f64 score epilogue", "data": "synthetic",
             "config": {"workload": "%dx%d-dim 1-bit index, queryBits=4, k=%d, COSINE, row-sharded over %d GPU(s)" % (N, dim, k, world),
-                       "queries_per_step": Q, "sweeps_per_query": 1, "bytes_per_row": bytes_per_row,
+                       "queries_per_step": Q, "queries_per_launch": min(args.sub_batch, Q), "sweeps_per_query": 1,
+                       "pipeline_slots": args.slots, "replay_threads": args.replay_threads, "bytes_per_row": bytes_per_row,
                        "parallelism": "row-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "bbq_scan_kernel (largest segment launch)",
@@ -256,7 +262,7 @@ def main():
                 import orclib as O
                 _, _, s32 = O.score_all(codes, corr, dim, qq_all[args.warmup * Q], qc_all[args.warmup * Q], 4, 1, cdp)
                 oi, osc = O.heap_topk(s32, k)
-                gi, gs, _ = results[0]
+                gi, gs, _ = results[args.warmup]
                 out["parity_full_size"] = bool((gi[0] == oi).all() and (gs[0].view(np.uint32) == osc.view(np.uint32)).all())
         if not args.no_recall:
             rec, desc = recall_probe(B, device)

@@ -45,6 +45,7 @@ struct Segment {
   int64_t chunk_begin, n_chunks, rows;
   bool dense, emit, need_theta, dominant;
   int cap;
+  bool big = false;  // large sweeps of different sub-batches are serialised through an event chain
 };
 
 struct Plan {
@@ -58,7 +59,7 @@ struct Plan {
 
 struct Slot {
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr, ev_big = nullptr;
   // capacities the buffers below were allocated for
   int q_cap = 0;
   int64_t qbuf_bytes = 0, chunks_cap = 0, slots_cap = 0, dense_cap = 0, list_cap = 0, k_cap = 0, hprefix = 0;
@@ -96,6 +97,7 @@ struct bbq_index {
   int opt_batch = 16, opt_slots = 2, opt_growth = 8, opt_tpw = 1, opt_replay_threads = 1, opt_force_dense = 0;
   int64_t opt_s0 = 4096;
   bbq_stats stats{};
+  int last_big_slot = -1;  // slot whose ev_big marks the end of the most recently enqueued big sweep
 };
 
 namespace {
@@ -210,6 +212,7 @@ void build_plan(bbq_index *ix, int64_t k) {
     if (best < 0 || s.rows > p.segs[best].rows) best = (int64_t)i;
   }
   if (best >= 0) p.segs[best].dominant = true;
+  for (Segment &sg : p.segs) sg.big = best >= 0 && sg.rows * 32 >= p.segs[best].rows && sg.rows >= 65536;
   // list capacity: everything dense + 4x the expected sparse candidates + slack
   double sparse = 0;
   int64_t dense_rows = 0;
@@ -227,11 +230,8 @@ void free_slot_buffers(Slot &s) {
   if (s.d_qbuf) (void)hipFree(s.d_qbuf);
   if (s.h_qbuf) (void)hipHostFree(s.h_qbuf);
   if (s.d_theta) (void)hipFree(s.d_theta);
-  if (s.d_flags) (void)hipFree(s.d_flags);
   if (s.d_counts) (void)hipFree(s.d_counts);
   if (s.d_topk) (void)hipFree(s.d_topk);
-  if (s.d_topk_counts) (void)hipFree(s.d_topk_counts);
-  if (s.d_list_counts) (void)hipFree(s.d_list_counts);
   if (s.h_list_counts) (void)hipHostFree(s.h_list_counts);
   if (s.d_entries) (void)hipFree(s.d_entries);
   if (s.d_lists) (void)hipFree(s.d_lists);
@@ -256,7 +256,7 @@ int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
                   (!own_lists || s.d_lists != nullptr);
   if (ok) return BBQ_OK;
   free_slot_buffers(s);
-  const int Q = std::max(nq, ix->opt_batch);
+  const int Q = (std::max(nq, ix->opt_batch) + 1) / 2 * 2;
   s.qbuf_bytes = qb;
   s.chunks_cap = std::max<int64_t>(p.max_chunks, 1);
   s.slots_cap = std::max<int64_t>(p.max_slots, 1);
@@ -266,12 +266,13 @@ int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
   s.hprefix = hprefix;
   HIPCHK(hipMalloc((void **)&s.d_qbuf, (size_t)(Q * qb)));
   HIPCHK(hipHostMalloc((void **)&s.h_qbuf, (size_t)(Q * qb), hipHostMallocDefault));
-  HIPCHK(hipMalloc((void **)&s.d_theta, (size_t)Q * 4));
-  HIPCHK(hipMalloc((void **)&s.d_flags, (size_t)Q * 4));
+  // theta | flags | topk_counts | list_counts live in one control block so that one memset resets a sub-batch
+  HIPCHK(hipMalloc((void **)&s.d_theta, (size_t)Q * 20));
+  s.d_flags = s.d_theta + Q;
+  s.d_topk_counts = reinterpret_cast<int32_t *>(s.d_theta + 2 * (size_t)Q);
+  s.d_list_counts = reinterpret_cast<int32_t *>(s.d_theta + 3 * (size_t)Q);
   HIPCHK(hipMalloc((void **)&s.d_counts, (size_t)(Q * s.chunks_cap) * 4));
   HIPCHK(hipMalloc((void **)&s.d_topk, (size_t)(Q * s.k_cap) * 4));
-  HIPCHK(hipMalloc((void **)&s.d_topk_counts, (size_t)Q * 4));
-  HIPCHK(hipMalloc((void **)&s.d_list_counts, (size_t)Q * 8));
   HIPCHK(hipHostMalloc((void **)&s.h_list_counts, (size_t)Q * 8, hipHostMallocDefault));
   HIPCHK(hipMalloc((void **)&s.d_entries, (size_t)(Q * s.slots_cap) * 8));
   HIPCHK(hipMalloc((void **)&s.d_dense0, (size_t)(Q * s.dense_cap) * 4));
@@ -364,10 +365,8 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
   uint64_t *d_lists = d_lists_ext ? d_lists_ext : s.d_lists;
   const int64_t list_cap = d_lists_ext ? list_cap_ext : s.list_cap;
   int32_t *d_list_counts = d_counts_ext ? d_counts_ext : s.d_list_counts;
-  HIPCHK(hipMemsetAsync(s.d_theta, 0, (size_t)nq * 4, st));
-  HIPCHK(hipMemsetAsync(s.d_flags, 0, (size_t)nq * 4, st));
-  HIPCHK(hipMemsetAsync(s.d_topk_counts, 0, (size_t)nq * 4, st));
-  HIPCHK(hipMemsetAsync(d_list_counts, 0, (size_t)nq * 8, st));
+  HIPCHK(hipMemsetAsync(s.d_theta, 0, (size_t)s.q_cap * 20, st));
+  if (d_counts_ext) HIPCHK(hipMemsetAsync(d_counts_ext, 0, (size_t)nq * 8, st));
 
   s.timed = false;
   for (const Segment &g : p.segs) {
@@ -386,8 +385,15 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
     a.n_chunks = (int32_t)g.n_chunks;
     a.dense_score32 = g.dense ? s.d_dense0 : nullptr;
     a.dense_stride = s.dense_cap;
+    const int my_slot = (int)(&s - ix->slots);
+    if (g.big && ix->last_big_slot >= 0 && ix->last_big_slot != my_slot)
+      HIPCHK(hipStreamWaitEvent(st, ix->slots[ix->last_big_slot].ev_big, 0));  // one big sweep at a time on the device
     if (g.dominant) HIPCHK(hipEventRecord(s.ev0, st));
     HIPCHK(launch_scan(a, c.planes, g.dense, nq, (int)g.n_chunks, ix->opt_tpw, st));
+    if (g.big) {
+      HIPCHK(hipEventRecord(s.ev_big, st));
+      ix->last_big_slot = my_slot;
+    }
     if (g.dominant) {
       HIPCHK(hipEventRecord(s.ev1, st));
       s.timed = true;
@@ -596,6 +602,7 @@ int bbq_index_create_shard(const uint8_t *codes, const double *corr, int64_t n_r
     HIPCHK(hipEventCreate(&ix->slots[i].ev0));
     HIPCHK(hipEventCreate(&ix->slots[i].ev1));
     HIPCHK(hipEventCreateWithFlags(&ix->slots[i].ev_done, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ix->slots[i].ev_big, hipEventDisableTiming));
   }
   HIPCHK(hipStreamCreateWithFlags(&ix->aux_stream, hipStreamNonBlocking));
   HIPCHK(hipMalloc((void **)&ix->d_aux_qbuf, (size_t)qbuf_bytes_per_query(ix.get())));
@@ -637,6 +644,7 @@ void bbq_index_destroy(bbq_index *ix) {
     if (s.ev0) (void)hipEventDestroy(s.ev0);
     if (s.ev1) (void)hipEventDestroy(s.ev1);
     if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+    if (s.ev_big) (void)hipEventDestroy(s.ev_big);
     if (s.stream) (void)hipStreamDestroy(s.stream);
   }
   if (ix->pilot.d_tiles) (void)hipFree(ix->pilot.d_tiles);

@@ -264,15 +264,25 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
             if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> sh) & 255u], 1u);
           }
           __syncthreads();
-          if (tid == 0) {
-            uint32_t cum = 0;
-            int b = 255;
-            for (; b > 0; --b) {
-              if (cum + s_hist[b] >= kk) break;
-              cum += s_hist[b];
+          if (tid < 64) {
+            // wave 0 finds the bin: lane l owns bins 4l..4l+3; suffix sums over lanes by shuffles (no LDS round trips)
+            const uint32_t h0 = s_hist[4 * tid], h1 = s_hist[4 * tid + 1], h2 = s_hist[4 * tid + 2], h3 = s_hist[4 * tid + 3];
+            uint32_t suf = h0 + h1 + h2 + h3;  // becomes the sum over bins >= 4*tid
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+              const uint32_t n = __shfl_down(suf, d, 64);
+              if (tid + d < 64) suf += n;
             }
-            s_misc[0] = (uint32_t)b;
-            s_misc[1] = kk - cum;
+            const uint32_t above = suf - (h0 + h1 + h2 + h3);  // bins > 4*tid+3
+            if (suf >= kk && above < kk) {                     // exactly one lane: the k-th largest lies in its 4 bins
+              uint32_t cum = above;
+              int b = 4 * tid + 3;
+              if (cum + h3 < kk) { cum += h3; b = 4 * tid + 2;
+                if (cum + h2 < kk) { cum += h2; b = 4 * tid + 1;
+                  if (cum + h1 < kk) { cum += h1; b = 4 * tid; } } }
+              s_misc[0] = (uint32_t)b;
+              s_misc[1] = kk - cum;
+            }
           }
           __syncthreads();
           prefix |= s_misc[0] << sh;
