@@ -1,0 +1,48 @@
+// TypeScript surface of the MI355X drop-in (mirrors the reference's src/index.ts exports used on the search path).
+export declare enum VectorSimilarityFunction { EUCLIDEAN = 'EUCLIDEAN', COSINE = 'COSINE', MAXIMUM_INNER_PRODUCT = 'MAXIMUM_INNER_PRODUCT' }
+export interface QuantizationResult { lowerInterval: number; upperInterval: number; additionalCorrection: number; quantizedComponentSum: number; }
+export interface QuantizerConfig { similarityFunction: VectorSimilarityFunction; lambda?: number; iters?: number; }
+export interface BinaryQuantizationConfig { queryBits?: number; indexBits?: number; quantizer: QuantizerConfig; }
+export interface BinarizedByteVectorValues {
+  dimension(): number;
+  vectorValue(ord: number): Uint8Array;
+  getUnpackedVector(ord: number): Uint8Array;
+  getCorrectiveTerms(ord: number): QuantizationResult;
+  getCentroidDP(queryVector?: Float32Array): number;
+  getCentroid(): Float32Array;
+  size(): number;
+  clearUnpackedVectorCache?(): void;
+  /** releases the device-resident copy (extension) */
+  dispose(): void;
+}
+export interface QuantizedScoreResult { score: number; bitDotProduct: number; corrections: { query: QuantizationResult; index: QuantizationResult }; }
+export declare class OptimizedScalarQuantizer {
+  constructor(config: QuantizerConfig);
+  scalarQuantize(vector: Float32Array, destination: Uint8Array, bits: number, centroid: Float32Array): QuantizationResult;
+  static packAsBinary(vector: Uint8Array, packed: Uint8Array): void;
+}
+export declare class BinaryQuantizedScorer {
+  constructor(similarityFunction: VectorSimilarityFunction);
+  computeBatchQuantizedScores(quantizedQuery: Uint8Array, queryCorrections: QuantizationResult, targetVectors: BinarizedByteVectorValues,
+    targetOrds: number[], queryBits: number): QuantizedScoreResult[];
+}
+export declare class BinaryQuantizationFormat {
+  constructor(config: BinaryQuantizationConfig);
+  quantizeVectors(vectors: Float32Array[]): { quantizedVectors: BinarizedByteVectorValues; queryQuantizer: OptimizedScalarQuantizer };
+  quantizeQueryVector(queryVector: Float32Array, centroid: Float32Array): { quantizedQuery: Uint8Array; queryCorrections: QuantizationResult };
+  searchNearestNeighbors(queryVector: Float32Array, targetVectors: BinarizedByteVectorValues, k: number): Array<{ index: number; score: number }>;
+  /** extension: many independent queries per call, pipelined on the device */
+  searchNearestNeighborsBatch(queryVectors: Float32Array[], targetVectors: BinarizedByteVectorValues, k: number): Array<Array<{ index: number; score: number }>>;
+  getConfig(): BinaryQuantizationConfig;
+  getQuantizer(): OptimizedScalarQuantizer;
+  getScorer(): BinaryQuantizedScorer;
+}
+export interface TopKCandidate { index: number; quantizedScore: number; trueScore: number; }
+export declare function getOversampledTopKWithHeap(query: Float32Array, quantizedVectors: any, vectors: Float32Array[], k: number, oversampleFactor: number, format: BinaryQuantizationFormat): TopKCandidate[];
+export declare function getOversampledTopKWithSort(query: Float32Array, quantizedVectors: any, vectors: Float32Array[], k: number, oversampleFactor: number, format: BinaryQuantizationFormat): TopKCandidate[];
+export declare const DEFAULT_CONFIG: { readonly queryBits: 4; readonly indexBits: 1; readonly quantizer: { readonly similarityFunction: VectorSimilarityFunction.COSINE; readonly lambda: 0.1; readonly iters: 5 } };
+export declare function createBinaryQuantizationFormat(config?: BinaryQuantizationConfig): BinaryQuantizationFormat;
+export declare function quickQuantize(vectors: Float32Array[], similarityFunction?: VectorSimilarityFunction): { quantizedVectors: BinarizedByteVectorValues; queryQuantizer: OptimizedScalarQuantizer };
+export declare function quickSearch(queryVector: Float32Array, targetVectors: Float32Array[], k: number, similarityFunction?: VectorSimilarityFunction): Array<{ index: number; score: number }>;
+export declare const VERSION: string;
+export declare function deviceCount(): number;

@@ -1,0 +1,350 @@
+'use strict';
+/*
+ * Host-side drop-in for the search path of leolee9086/Better-Binary-Quantization on MI355X.
+ *
+ * Same public surface as the reference's src/index.ts (createBinaryQuantizationFormat, quickQuantize, quickSearch,
+ * BinaryQuantizationFormat, VectorSimilarityFunction, DEFAULT_CONFIG, VERSION) with the same argument meaning,
+ * defaults and error messages; every numeric operation runs in libbbq (C++ host quantizer + gfx950 HIP kernels)
+ * through the N-API addon ../lib/bbq_napi.node.  There is no JavaScript/CPU fallback for the scan: without a HIP
+ * device searchNearestNeighbors throws.
+ *
+ * Plain ES2019 CommonJS (runs on Node >= 12 without a build step); index.d.ts carries the TypeScript surface.
+ */
+const path = require('path');
+const native = require(path.join(__dirname, '..', 'lib', 'bbq_napi.node'));
+
+// src/types.ts:9-13 (string enum)
+const VectorSimilarityFunction = Object.freeze({
+  EUCLIDEAN: 'EUCLIDEAN', COSINE: 'COSINE', MAXIMUM_INNER_PRODUCT: 'MAXIMUM_INNER_PRODUCT',
+});
+const SIM_ORDINAL = { EUCLIDEAN: 0, COSINE: 1, MAXIMUM_INNER_PRODUCT: 2 };
+
+// src/constants.ts:9-30
+const QUERY_BITS = 4;
+const INDEX_BITS = 1;
+const FOUR_BIT_SCALE = 1.0 / ((1 << 4) - 1);
+const DEFAULT_LAMBDA = 0.1;
+const DEFAULT_ITERS = 5;
+
+// src/index.ts:47-55
+const DEFAULT_CONFIG = Object.freeze({
+  queryBits: 4, indexBits: 1,
+  quantizer: Object.freeze({ similarityFunction: VectorSimilarityFunction.COSINE, lambda: 0.1, iters: 5 }),
+});
+
+function simOrdinal(sim) {
+  const o = SIM_ORDINAL[sim];
+  if (o === undefined) throw new Error('不支持的相似性函数: ' + sim);
+  return o;
+}
+
+function corrObject(f64, off) {
+  return {
+    lowerInterval: f64[off], upperInterval: f64[off + 1], additionalCorrection: f64[off + 2],
+    quantizedComponentSum: f64[off + 3],
+  };
+}
+
+/**
+ * BinarizedByteVectorValues (src/types.ts:32-49; BinarizedByteVectorValuesImpl, src/binaryQuantizationFormat.ts:24-126).
+ * One flat Uint8Array / Float64Array instead of per-row objects; vectorValue(ord) is a subarray view, which is
+ * API-compatible with the reference's per-row Uint8Array.  The device copy is created on first search and cached.
+ */
+class BinarizedByteVectorValuesImpl {
+  constructor(codes, corr, centroid, indexBits, size) {
+    this._codes = codes; this._corr = corr; this._centroid = centroid; this._indexBits = indexBits;
+    this._size = size; this._rowBytes = size > 0 ? codes.length / size : 0;
+    this._device = null;
+  }
+  dimension() { return this._centroid.length; }
+  size() { return this._size; }
+  vectorValue(ord) {
+    if (!(ord >= 0 && ord < this._size)) throw new Error('向量索引 ' + ord + ' 不存在');
+    return this._codes.subarray(ord * this._rowBytes, (ord + 1) * this._rowBytes);
+  }
+  getUnpackedVector(ord) {
+    if (!(ord >= 0 && ord < this._size)) throw new Error('未打包向量索引 ' + ord + ' 不存在');
+    const dim = this.dimension();
+    if (this._indexBits !== 1) return new Uint8Array(this.vectorValue(ord));
+    const row = this.vectorValue(ord), out = new Uint8Array(dim);
+    for (let d = 0; d < dim; d++) out[d] = (row[d >> 3] >> (7 - (d & 7))) & 1;
+    return out;
+  }
+  clearUnpackedVectorCache() {}
+  getCorrectiveTerms(ord) {
+    if (!(ord >= 0 && ord < this._size)) throw new Error('修正项索引 ' + ord + ' 不存在');
+    return corrObject(this._corr, 4 * ord);
+  }
+  getCentroidDP(queryVector) {
+    if (queryVector) {  // computeDotProduct(queryVector, centroid), src/vectorOperations.ts:171-185
+      if (queryVector.length !== this._centroid.length) throw new Error('向量维度不匹配');
+      let s = 0;
+      for (let i = 0; i < queryVector.length; i++) s += queryVector[i] * this._centroid[i];
+      return s;
+    }
+    return native.centroidDP(this._centroid);
+  }
+  getCentroid() { return this._centroid; }
+  /** device-resident copy (libbbq bbq_index); created lazily, released by dispose() or GC */
+  _deviceIndex() {
+    if (!this._device) {
+      this._device = native.indexCreate(this._codes, this._corr, this._size, this.dimension(), this._indexBits,
+        this.getCentroidDP(), Number(process.env.BBQ_DEVICE || 0));
+    }
+    return this._device;
+  }
+  dispose() { if (this._device) { native.indexDestroy(this._device); this._device = null; } }
+}
+
+function flatten(vectors, dim) {
+  const flat = new Float32Array(vectors.length * dim);
+  for (let i = 0; i < vectors.length; i++) flat.set(vectors[i], i * dim);
+  return flat;
+}
+
+/** the quantizer handle the reference returns as `queryQuantizer` (OptimizedScalarQuantizer) */
+class OptimizedScalarQuantizer {
+  constructor(config) {
+    this.lambda = (config.lambda !== undefined && config.lambda !== null) ? config.lambda : DEFAULT_LAMBDA;
+    this.iters = (config.iters !== undefined && config.iters !== null) ? config.iters : DEFAULT_ITERS;
+    this.similarityFunction = (config.similarityFunction !== undefined && config.similarityFunction !== null)
+      ? config.similarityFunction : VectorSimilarityFunction.EUCLIDEAN;
+  }
+  /** scalarQuantize(vector, destination, bits, centroid), src/optimizedScalarQuantizer.ts:108-227 */
+  scalarQuantize(vector, destination, bits, centroid) {
+    if (!vector) throw new Error('输入向量不能为空');
+    if (!destination) throw new Error('目标数组不能为空');
+    if (!centroid) throw new Error('质心向量不能为空');
+    if (vector.length !== centroid.length) throw new Error('向量和质心维度不匹配');
+    if (destination.length !== vector.length) throw new Error('目标数组长度与向量长度不匹配');
+    if (bits < 1 || bits > 8) throw new Error('位数必须在1-8之间');
+    // a sim that never normalises gives the bare scalarQuantize; EUCLIDEAN/MIP ordinals keep their correction rule
+    const sim = this.similarityFunction === VectorSimilarityFunction.EUCLIDEAN ? 0 : 2;
+    const r = native.quantizeQuery(Float32Array.from(vector), centroid, sim, bits, this.lambda, this.iters, false);
+    destination.set(r.quantizedQuery);
+    return corrObject(r.corrections, 0);
+  }
+  /** packAsBinary, src/optimizedScalarQuantizer.ts:420-446 */
+  static packAsBinary(vector, packed) {
+    for (let i = 0; i < vector.length;) {
+      let result = 0;
+      for (let j = 7; j >= 0 && i < vector.length; j--) {
+        const v = vector[i];
+        if (v !== 0 && v !== 1) throw new Error('1位量化值必须为0或1');
+        result |= (v & 1) << j;
+        i++;
+      }
+      const index = Math.floor((i - 1) / 8);
+      if (index >= packed.length) throw new Error('打包数组长度不足');
+      packed[index] = result;
+    }
+  }
+}
+
+/** BinaryQuantizedScorer as far as the search path uses it (src/binaryQuantizedScorer.ts:315-420) */
+class BinaryQuantizedScorer {
+  constructor(similarityFunction) { this.similarityFunction = similarityFunction; }
+  /** computeBatchQuantizedScores(quantizedQuery, queryCorrections, targetVectors, targetOrds, queryBits) */
+  computeBatchQuantizedScores(quantizedQuery, queryCorrections, targetVectors, targetOrds, queryBits) {
+    if (targetOrds.length === 0) return [];
+    const qc = new Float64Array([queryCorrections.lowerInterval, queryCorrections.upperInterval,
+      queryCorrections.additionalCorrection, queryCorrections.quantizedComponentSum]);
+    let lo = targetOrds[0], hi = targetOrds[0];
+    for (let i = 1; i < targetOrds.length; i++) { if (targetOrds[i] < lo) lo = targetOrds[i]; if (targetOrds[i] > hi) hi = targetOrds[i]; }
+    const r = native.scoreRows(targetVectors._deviceIndex(), quantizedQuery, qc, queryBits, simOrdinal(this.similarityFunction), lo, hi - lo + 1);
+    return targetOrds.map(function (ord) {
+      return {
+        score: r.score64[ord - lo], bitDotProduct: r.qcDist[ord - lo],
+        corrections: { query: queryCorrections, index: targetVectors.getCorrectiveTerms(ord) },
+      };
+    });
+  }
+}
+
+/** BinaryQuantizationFormat, src/binaryQuantizationFormat.ts:132-412 */
+class BinaryQuantizationFormat {
+  constructor(config) {
+    if (config.queryBits !== undefined && (config.queryBits < 1 || config.queryBits > 8)) throw new Error('queryBits必须在1-8之间');
+    if (config.indexBits !== undefined && (config.indexBits < 1 || config.indexBits > 8)) throw new Error('indexBits必须在1-8之间');
+    this.config = Object.assign({ queryBits: QUERY_BITS, indexBits: INDEX_BITS }, config);
+    this.quantizer = new OptimizedScalarQuantizer(config.quantizer);
+    this.scorer = new BinaryQuantizedScorer(config.quantizer.similarityFunction);
+  }
+
+  /** quantizeVectors(vectors: Float32Array[]) -> {quantizedVectors, queryQuantizer}  (:165-263) */
+  quantizeVectors(vectors) {
+    if (vectors.length === 0) throw new Error('向量集合不能为空');
+    const first = vectors[0];
+    if (!first) throw new Error('第一个向量不能为空');
+    const dim = first.length;
+    for (let i = 1; i < vectors.length; i++) {
+      const v = vectors[i];
+      if (!v) throw new Error('向量 ' + i + ' 不能为空');
+      if (v.length !== dim) throw new Error('向量 ' + i + ' 维度 ' + v.length + ' 与第一个向量维度 ' + dim + ' 不匹配');
+    }
+    const q = this.quantizer;
+    const r = native.quantizeVectors(flatten(vectors, dim), vectors.length, dim, simOrdinal(q.similarityFunction),
+      this.config.indexBits, q.lambda, q.iters, Number(process.env.BBQ_THREADS || 0));
+    return {
+      quantizedVectors: new BinarizedByteVectorValuesImpl(r.codes, r.corr, r.centroid, this.config.indexBits, vectors.length),
+      queryQuantizer: this.quantizer,
+    };
+  }
+
+  /** quantizeQueryVector(queryVector, centroid) -> {quantizedQuery, queryCorrections}  (:271-299) */
+  quantizeQueryVector(queryVector, centroid) {
+    const q = this.quantizer;
+    const r = native.quantizeQuery(Float32Array.from(queryVector), centroid, simOrdinal(q.similarityFunction), this.config.queryBits,
+      q.lambda, q.iters, false);
+    return { quantizedQuery: r.quantizedQuery, queryCorrections: corrObject(r.corrections, 0) };
+  }
+
+  /** searchNearestNeighbors(queryVector, targetVectors, k) -> Array<{index, score}>  (:308-412) */
+  searchNearestNeighbors(queryVector, targetVectors, k) {
+    if (!queryVector) throw new Error('查询向量不能为空');
+    if (!targetVectors) throw new Error('目标向量集合不能为空');
+    if (k < 0) throw new Error('k值不能为负数');
+    if (queryVector.length !== targetVectors.dimension()) throw new Error('查询向量维度与目标向量维度不匹配');
+    if (k === 0) return [];
+    return this.searchNearestNeighborsBatch([queryVector], targetVectors, k)[0];
+  }
+
+  /** extension (not in the reference): many queries per call, pipelined on the device; each query sweeps the index itself */
+  searchNearestNeighborsBatch(queryVectors, targetVectors, k) {
+    if (!queryVectors) throw new Error('查询向量不能为空');
+    if (!targetVectors) throw new Error('目标向量集合不能为空');
+    if (k < 0) throw new Error('k值不能为负数');
+    const dim = targetVectors.dimension(), nq = queryVectors.length;
+    if (k === 0) return queryVectors.map(function () { return []; });
+    const q = this.quantizer, sim = simOrdinal(q.similarityFunction);
+    const qq = new Uint8Array(nq * dim), qc = new Float64Array(nq * 4);
+    for (let i = 0; i < nq; i++) {
+      const v = queryVectors[i];
+      if (!v) throw new Error('查询向量不能为空');
+      if (v.length !== dim) throw new Error('查询向量维度与目标向量维度不匹配');
+      // searchNearestNeighbors normalises for COSINE and quantizeQueryVector normalises again (:337-347, :279-281)
+      const r = native.quantizeQuery(Float32Array.from(v), targetVectors.getCentroid(), sim, this.config.queryBits, q.lambda, q.iters, true);
+      qq.set(r.quantizedQuery, i * dim);
+      qc.set(r.corrections, i * 4);
+    }
+    const r = native.searchBatch(targetVectors._deviceIndex(), nq, qq, qc, this.config.queryBits, sim, k);
+    const out = [];
+    for (let i = 0; i < nq; i++) {
+      const res = [], n = r.counts[i], base = i * r.stride;
+      for (let j = 0; j < n; j++) res.push({ index: r.indices[base + j], score: r.scores[base + j] });
+      out.push(res);
+    }
+    return out;
+  }
+
+  getConfig() { return this.config; }
+  getQuantizer() { return this.quantizer; }
+  getScorer() { return this.scorer; }
+}
+
+// ------------------------------------------------------------------ src/topKSelector.ts (host-side caller of the path)
+
+/** MinHeap with the reference's tie behaviour (src/minHeap.ts:9-130) */
+class MinHeap {
+  constructor(compareFn) { this.heap = []; this.compareFn = compareFn || function (a, b) { return a - b; }; }
+  size() { return this.heap.length; }
+  isEmpty() { return this.heap.length === 0; }
+  peek() { return this.heap[0]; }
+  push(item) {
+    const h = this.heap; h.push(item);
+    let i = h.length - 1;
+    while (i > 0) {
+      const p = Math.floor((i - 1) / 2);
+      if (this.compareFn(h[i], h[p]) >= 0) break;
+      const t = h[i]; h[i] = h[p]; h[p] = t; i = p;
+    }
+  }
+  pop() {
+    const h = this.heap;
+    if (h.length === 0) return null;
+    const min = h[0], last = h.pop();
+    if (h.length > 0) {
+      h[0] = last;
+      let i = 0;
+      for (;;) {
+        let s = i; const l = 2 * i + 1, r = 2 * i + 2;
+        if (l < h.length && this.compareFn(h[l], h[s]) < 0) s = l;
+        if (r < h.length && this.compareFn(h[r], h[s]) < 0) s = r;
+        if (s === i) break;
+        const t = h[i]; h[i] = h[s]; h[s] = t; i = s;
+      }
+    }
+    return min;
+  }
+  toArray() { return this.heap.slice().sort(this.compareFn); }
+  clear() { this.heap = []; }
+}
+
+// src/vectorSimilarity.ts:73-101
+function computeCosineSimilarity(a, b) {
+  if (!a || !b) throw new Error('向量不能为空');
+  if (a.length !== b.length) throw new Error('向量维度不匹配');
+  let dp = 0, na = 0, nb = 0;
+  for (let i = 0; i < a.length; i++) { dp += a[i] * b[i]; na += a[i] * a[i]; nb += b[i] * b[i]; }
+  if (na === 0 || nb === 0) return 0;
+  return dp / (Math.sqrt(na) * Math.sqrt(nb));
+}
+
+/** getOversampledTopKWithHeap, src/topKSelector.ts:29-79 */
+function getOversampledTopKWithHeap(query, quantizedVectors, vectors, k, oversampleFactor, format) {
+  const results = format.searchNearestNeighbors(query, quantizedVectors, k * oversampleFactor);
+  const heap = new MinHeap(function (a, b) { return a.trueScore - b.trueScore; });
+  for (const result of results) {
+    const vector = vectors[result.index];
+    if (!vector) continue;
+    const trueScore = computeCosineSimilarity(query, vector);
+    const cand = { index: result.index, quantizedScore: result.score, trueScore: trueScore };
+    if (heap.size() < k) heap.push(cand);
+    else { const p = heap.peek(); if (p && trueScore > p.trueScore) { heap.pop(); heap.push(cand); } }
+  }
+  const topK = [];
+  while (!heap.isEmpty()) { const it = heap.pop(); if (it) topK.push(it); }
+  topK.sort(function (a, b) { return b.trueScore - a.trueScore; });
+  return topK;
+}
+
+/** getOversampledTopKWithSort, src/topKSelector.ts:92-115 */
+function getOversampledTopKWithSort(query, quantizedVectors, vectors, k, oversampleFactor, format) {
+  const results = format.searchNearestNeighbors(query, quantizedVectors, k * oversampleFactor);
+  const cands = results.map(function (r) {
+    const v = vectors[r.index];
+    return v ? { index: r.index, quantizedScore: r.score, trueScore: computeCosineSimilarity(query, v) } : null;
+  }).filter(function (c) { return c !== null; });
+  cands.sort(function (a, b) { return b.trueScore - a.trueScore; });
+  return cands.slice(0, k);
+}
+
+// ------------------------------------------------------------------ src/index.ts:62-111
+
+function createBinaryQuantizationFormat(config) {
+  return new BinaryQuantizationFormat(config === undefined ? DEFAULT_CONFIG : config);
+}
+function quickQuantize(vectors, similarityFunction) {
+  const sim = similarityFunction === undefined ? VectorSimilarityFunction.COSINE : similarityFunction;
+  return new BinaryQuantizationFormat({ quantizer: { similarityFunction: sim, lambda: 0.1, iters: 5 } }).quantizeVectors(vectors);
+}
+function quickSearch(queryVector, targetVectors, k, similarityFunction) {
+  const sim = similarityFunction === undefined ? VectorSimilarityFunction.COSINE : similarityFunction;
+  const format = new BinaryQuantizationFormat({ quantizer: { similarityFunction: sim, lambda: 0.1, iters: 5 } });
+  const built = format.quantizeVectors(targetVectors);
+  try {
+    return format.searchNearestNeighbors(queryVector, built.quantizedVectors, k);
+  } finally {
+    built.quantizedVectors.dispose();  // quickSearch rebuilds the index on every call (src/index.ts:109): free the device copy now
+  }
+}
+
+module.exports = {
+  VectorSimilarityFunction, DEFAULT_CONFIG, VERSION: '1.0.0',
+  QUERY_BITS, INDEX_BITS, FOUR_BIT_SCALE, DEFAULT_LAMBDA, DEFAULT_ITERS,
+  BinaryQuantizationFormat, OptimizedScalarQuantizer, BinaryQuantizedScorer, MinHeap,
+  createBinaryQuantizationFormat, quickQuantize, quickSearch,
+  getOversampledTopKWithHeap, getOversampledTopKWithSort, computeCosineSimilarity,
+  deviceCount: native.deviceCount,
+  _native: native,
+};

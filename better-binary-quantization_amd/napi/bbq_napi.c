@@ -1,0 +1,301 @@
+/*
+ * bbq_napi.c - thin Node N-API (v8, plain C, no node-addon-api) binding of libbbq's C ABI (include/bbq.h).
+ * The JavaScript host (../js/index.js) keeps the reference's public API and calls these functions; typed arrays
+ * are passed zero-copy (napi_get_typedarray_info) and are only valid for the duration of the call, exactly as
+ * the C ABI borrows them.  Errors become JS `Error`s carrying bbq_last_error() (the reference's own messages).
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/bbq.h"
+
+#define NAPI_CALL(env, call)                                              \
+  do {                                                                    \
+    if ((call) != napi_ok) {                                              \
+      napi_throw_error((env), NULL, "bbq_napi: N-API call failed: " #call); \
+      return NULL;                                                        \
+    }                                                                     \
+  } while (0)
+
+static napi_value throw_bbq(napi_env env, int rc) {
+  char code[16];
+  snprintf(code, sizeof code, "BBQ%d", rc);
+  const char *m = bbq_last_error();
+  napi_throw_error(env, code, (m && *m) ? m : "libbbq error");
+  return NULL;
+}
+
+static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv) {
+  size_t argc = want;
+  if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < want) {
+    napi_throw_type_error(env, NULL, "bbq_napi: wrong number of arguments");
+    return 0;
+  }
+  return 1;
+}
+
+static int get_typed(napi_env env, napi_value v, napi_typedarray_type want, void **data, size_t *len) {
+  bool is = false;
+  napi_typedarray_type t;
+  napi_value ab;
+  size_t off;
+  if (napi_is_typedarray(env, v, &is) != napi_ok || !is ||
+      napi_get_typedarray_info(env, v, &t, len, data, &ab, &off) != napi_ok || t != want) {
+    napi_throw_type_error(env, NULL, "bbq_napi: typed array of the wrong kind");
+    return 0;
+  }
+  return 1;
+}
+
+static int get_i64(napi_env env, napi_value v, int64_t *out) {
+  double d;
+  if (napi_get_value_double(env, v, &d) != napi_ok) {
+    napi_throw_type_error(env, NULL, "bbq_napi: number expected");
+    return 0;
+  }
+  *out = (int64_t)d;
+  return 1;
+}
+static int get_f64(napi_env env, napi_value v, double *out) {
+  if (napi_get_value_double(env, v, out) != napi_ok) {
+    napi_throw_type_error(env, NULL, "bbq_napi: number expected");
+    return 0;
+  }
+  return 1;
+}
+
+static napi_value new_typed(napi_env env, napi_typedarray_type t, size_t count, size_t elem, void **data) {
+  napi_value ab, ta;
+  if (napi_create_arraybuffer(env, count * elem, data, &ab) != napi_ok) return NULL;
+  if (napi_create_typedarray(env, t, count, ab, 0, &ta) != napi_ok) return NULL;
+  return ta;
+}
+
+static void set_prop(napi_env env, napi_value obj, const char *name, napi_value v) { napi_set_named_property(env, obj, name, v); }
+
+/* deviceCount() */
+static napi_value DeviceCount(napi_env env, napi_callback_info info) {
+  (void)info;
+  napi_value r;
+  NAPI_CALL(env, napi_create_int32(env, bbq_device_count(), &r));
+  return r;
+}
+
+/* quantizeVectors(flat Float32Array, n, dim, sim, indexBits, lambda, iters, threads) -> {codes, corr, centroid} */
+static napi_value QuantizeVectors(napi_env env, napi_callback_info info) {
+  napi_value a[8];
+  if (!get_args(env, info, 8, a)) return NULL;
+  void *vec; size_t vlen;
+  int64_t n, dim, sim, ib, iters, threads; double lambda;
+  if (!get_typed(env, a[0], napi_float32_array, &vec, &vlen) || !get_i64(env, a[1], &n) || !get_i64(env, a[2], &dim) ||
+      !get_i64(env, a[3], &sim) || !get_i64(env, a[4], &ib) || !get_f64(env, a[5], &lambda) || !get_i64(env, a[6], &iters) ||
+      !get_i64(env, a[7], &threads)) return NULL;
+  if (n < 0 || dim <= 0 || (size_t)(n * dim) != vlen) { napi_throw_range_error(env, NULL, "bbq_napi: n*dim does not match the array"); return NULL; }
+  const size_t rb = ib == 1 ? (size_t)((dim + 7) / 8) : (size_t)dim;
+  void *codes, *corr, *cen;
+  napi_value tcodes = new_typed(env, napi_uint8_array, (size_t)n * rb, 1, &codes);
+  napi_value tcorr = new_typed(env, napi_float64_array, (size_t)n * 4, 8, &corr);
+  napi_value tcen = new_typed(env, napi_float32_array, (size_t)dim, 4, &cen);
+  if (!tcodes || !tcorr || !tcen) { napi_throw_error(env, NULL, "bbq_napi: allocation failed"); return NULL; }
+  int rc = bbq_quantize_vectors((const float *)vec, n, (int32_t)dim, (int32_t)sim, (int32_t)ib, lambda, (int32_t)iters, (int32_t)threads,
+                                (uint8_t *)codes, (double *)corr, (float *)cen, NULL, NULL);
+  if (rc != BBQ_OK) return throw_bbq(env, rc);
+  napi_value o;
+  NAPI_CALL(env, napi_create_object(env, &o));
+  set_prop(env, o, "codes", tcodes); set_prop(env, o, "corr", tcorr); set_prop(env, o, "centroid", tcen);
+  return o;
+}
+
+/* quantizeQuery(query Float32Array, centroid Float32Array, sim, queryBits, lambda, iters, searchPath) -> {quantizedQuery, corrections} */
+static napi_value QuantizeQuery(napi_env env, napi_callback_info info) {
+  napi_value a[7];
+  if (!get_args(env, info, 7, a)) return NULL;
+  void *q, *c; size_t ql, cl;
+  int64_t sim, qb, iters; double lambda; bool sp;
+  if (!get_typed(env, a[0], napi_float32_array, &q, &ql) || !get_typed(env, a[1], napi_float32_array, &c, &cl) ||
+      !get_i64(env, a[2], &sim) || !get_i64(env, a[3], &qb) || !get_f64(env, a[4], &lambda) || !get_i64(env, a[5], &iters)) return NULL;
+  NAPI_CALL(env, napi_get_value_bool(env, a[6], &sp));
+  if (ql != cl) { napi_throw_error(env, "BBQ6", "向量和质心维度不匹配"); return NULL; }
+  void *qq, *qc;
+  napi_value tqq = new_typed(env, napi_uint8_array, ql, 1, &qq);
+  napi_value tqc = new_typed(env, napi_float64_array, 4, 8, &qc);
+  if (!tqq || !tqc) { napi_throw_error(env, NULL, "bbq_napi: allocation failed"); return NULL; }
+  int rc = sp ? bbq_quantize_query((const float *)q, (int32_t)ql, (const float *)c, (int32_t)sim, (int32_t)qb, lambda, (int32_t)iters, (uint8_t *)qq, (double *)qc)
+              : bbq_quantize_query_vector((const float *)q, (int32_t)ql, (const float *)c, (int32_t)sim, (int32_t)qb, lambda, (int32_t)iters, (uint8_t *)qq, (double *)qc);
+  if (rc != BBQ_OK) return throw_bbq(env, rc);
+  napi_value o;
+  NAPI_CALL(env, napi_create_object(env, &o));
+  set_prop(env, o, "quantizedQuery", tqq); set_prop(env, o, "corrections", tqc);
+  return o;
+}
+
+/* centroidDP(centroid Float32Array) */
+static napi_value CentroidDP(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  void *c; size_t cl;
+  if (!get_typed(env, a[0], napi_float32_array, &c, &cl)) return NULL;
+  napi_value r;
+  NAPI_CALL(env, napi_create_double(env, bbq_centroid_dp((const float *)c, (int32_t)cl), &r));
+  return r;
+}
+
+static void finalize_index(napi_env env, void *data, void *hint) {
+  (void)env; (void)hint;
+  bbq_index **box = (bbq_index **)data;
+  if (*box) bbq_index_destroy(*box);
+  free(box);
+}
+
+static bbq_index *unbox(napi_env env, napi_value v) {
+  void *p = NULL;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p || !*(bbq_index **)p) {
+    napi_throw_error(env, NULL, "目标向量集合不能为空");
+    return NULL;
+  }
+  return *(bbq_index **)p;
+}
+
+/* indexCreate(codes Uint8Array, corr Float64Array, n, dim, indexBits, centroidDP, device) -> external */
+static napi_value IndexCreate(napi_env env, napi_callback_info info) {
+  napi_value a[7];
+  if (!get_args(env, info, 7, a)) return NULL;
+  void *codes, *corr; size_t cl, rl;
+  int64_t n, dim, ib, dev; double cdp;
+  if (!get_typed(env, a[0], napi_uint8_array, &codes, &cl) || !get_typed(env, a[1], napi_float64_array, &corr, &rl) ||
+      !get_i64(env, a[2], &n) || !get_i64(env, a[3], &dim) || !get_i64(env, a[4], &ib) || !get_f64(env, a[5], &cdp) ||
+      !get_i64(env, a[6], &dev)) return NULL;
+  if (n < 0 || dim <= 0 || rl != (size_t)n * 4 || cl < (size_t)n * (size_t)((dim + 7) / 8)) {
+    napi_throw_range_error(env, NULL, "bbq_napi: array sizes do not match n/dim"); return NULL;
+  }
+  bbq_index **box = (bbq_index **)calloc(1, sizeof *box);
+  int rc = bbq_index_create((const uint8_t *)codes, (const double *)corr, n, (int32_t)dim, (int32_t)ib, cdp, (int32_t)dev, box);
+  if (rc != BBQ_OK) { free(box); return throw_bbq(env, rc); }
+  napi_value ext;
+  if (napi_create_external(env, box, finalize_index, NULL, &ext) != napi_ok) { bbq_index_destroy(*box); free(box); napi_throw_error(env, NULL, "bbq_napi: external"); return NULL; }
+  return ext;
+}
+
+/* indexDestroy(handle) */
+static napi_value IndexDestroy(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  void *p = NULL;
+  if (napi_get_value_external(env, a[0], &p) == napi_ok && p) {
+    bbq_index **box = (bbq_index **)p;
+    if (*box) { bbq_index_destroy(*box); *box = NULL; }
+  }
+  napi_value u; napi_get_undefined(env, &u); return u;
+}
+
+/* searchBatch(handle, nq, qquant Uint8Array[nq*dim], qcorr Float64Array[nq*4], queryBits, sim, k) -> {indices Int32Array[nq*k], scores Float32Array[nq*k], counts Float64Array[nq]} */
+static napi_value SearchBatch(napi_env env, napi_callback_info info) {
+  napi_value a[7];
+  if (!get_args(env, info, 7, a)) return NULL;
+  bbq_index *ix = unbox(env, a[0]);
+  if (!ix) return NULL;
+  void *qq, *qc; size_t ql, cl;
+  int64_t nq, qb, sim, k;
+  if (!get_i64(env, a[1], &nq) || !get_typed(env, a[2], napi_uint8_array, &qq, &ql) || !get_typed(env, a[3], napi_float64_array, &qc, &cl) ||
+      !get_i64(env, a[4], &qb) || !get_i64(env, a[5], &sim) || !get_i64(env, a[6], &k)) return NULL;
+  if (nq < 0 || ql != (size_t)nq * (size_t)bbq_index_dimension(ix) || cl != (size_t)nq * 4) {
+    napi_throw_error(env, "BBQ6", "查询向量维度与目标向量维度不匹配"); return NULL;
+  }
+  if (k < 0) { napi_throw_error(env, "BBQ7", "k值不能为负数"); return NULL; }
+  int64_t keff = k < bbq_index_size(ix) ? k : bbq_index_size(ix);
+  void *oi, *os, *on;
+  napi_value ti = new_typed(env, napi_int32_array, (size_t)(nq * keff), 4, &oi);
+  napi_value ts = new_typed(env, napi_float32_array, (size_t)(nq * keff), 4, &os);
+  napi_value tn = new_typed(env, napi_float64_array, (size_t)nq, 8, &on);
+  if (!ti || !ts || !tn) { napi_throw_error(env, NULL, "bbq_napi: allocation failed"); return NULL; }
+  int64_t *cnt = (int64_t *)calloc((size_t)nq + 1, sizeof(int64_t));
+  /* outputs are strided by the k passed to the library: pass keff so rows are packed */
+  int rc = bbq_search_batch(ix, (int32_t)nq, (const uint8_t *)qq, (const double *)qc, (int32_t)qb, (int32_t)sim, keff, (int32_t *)oi, (float *)os, cnt);
+  if (rc != BBQ_OK) { free(cnt); return throw_bbq(env, rc); }
+  for (int64_t i = 0; i < nq; ++i) ((double *)on)[i] = (double)cnt[i];
+  free(cnt);
+  napi_value o;
+  NAPI_CALL(env, napi_create_object(env, &o));
+  set_prop(env, o, "indices", ti); set_prop(env, o, "scores", ts); set_prop(env, o, "counts", tn);
+  napi_value kv; napi_create_double(env, (double)keff, &kv); set_prop(env, o, "stride", kv);
+  return o;
+}
+
+/* scoreRows(handle, qquant, qcorr, queryBits, sim, rowBegin, rowCount) -> {qcDist Int32Array, score64 Float64Array, score32 Float32Array} */
+static napi_value ScoreRows(napi_env env, napi_callback_info info) {
+  napi_value a[7];
+  if (!get_args(env, info, 7, a)) return NULL;
+  bbq_index *ix = unbox(env, a[0]);
+  if (!ix) return NULL;
+  void *qq, *qc; size_t ql, cl;
+  int64_t qb, sim, rb, rc_;
+  if (!get_typed(env, a[1], napi_uint8_array, &qq, &ql) || !get_typed(env, a[2], napi_float64_array, &qc, &cl) ||
+      !get_i64(env, a[3], &qb) || !get_i64(env, a[4], &sim) || !get_i64(env, a[5], &rb) || !get_i64(env, a[6], &rc_)) return NULL;
+  if (ql != (size_t)bbq_index_dimension(ix) || cl != 4) { napi_throw_error(env, "BBQ6", "查询向量维度与目标向量维度不匹配"); return NULL; }
+  if (rc_ < 0) rc_ = 0;
+  void *od, *o64, *o32;
+  napi_value td = new_typed(env, napi_int32_array, (size_t)rc_, 4, &od);
+  napi_value t64 = new_typed(env, napi_float64_array, (size_t)rc_, 8, &o64);
+  napi_value t32 = new_typed(env, napi_float32_array, (size_t)rc_, 4, &o32);
+  if (!td || !t64 || !t32) { napi_throw_error(env, NULL, "bbq_napi: allocation failed"); return NULL; }
+  int rc = bbq_score_rows(ix, (const uint8_t *)qq, (const double *)qc, (int32_t)qb, (int32_t)sim, rb, rc_, (int32_t *)od, (double *)o64, (float *)o32);
+  if (rc != BBQ_OK) return throw_bbq(env, rc);
+  napi_value o;
+  NAPI_CALL(env, napi_create_object(env, &o));
+  set_prop(env, o, "qcDist", td); set_prop(env, o, "score64", t64); set_prop(env, o, "score32", t32);
+  return o;
+}
+
+/* setOption(handle, name, value) */
+static napi_value SetOption(napi_env env, napi_callback_info info) {
+  napi_value a[3];
+  if (!get_args(env, info, 3, a)) return NULL;
+  bbq_index *ix = unbox(env, a[0]);
+  if (!ix) return NULL;
+  char name[64]; size_t nl; int64_t v;
+  NAPI_CALL(env, napi_get_value_string_utf8(env, a[1], name, sizeof name, &nl));
+  if (!get_i64(env, a[2], &v)) return NULL;
+  int rc = bbq_set_option(ix, name, v);
+  if (rc != BBQ_OK) return throw_bbq(env, rc);
+  napi_value u; napi_get_undefined(env, &u); return u;
+}
+
+/* stats(handle) -> {lastScanMs, lastScanBytes, candidates, denseFallbacks} */
+static napi_value Stats(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  bbq_index *ix = unbox(env, a[0]);
+  if (!ix) return NULL;
+  bbq_stats st;
+  int rc = bbq_get_stats(ix, &st);
+  if (rc != BBQ_OK) return throw_bbq(env, rc);
+  napi_value o, v;
+  NAPI_CALL(env, napi_create_object(env, &o));
+  napi_create_double(env, st.last_scan_ms, &v); set_prop(env, o, "lastScanMs", v);
+  napi_create_double(env, (double)st.last_scan_bytes, &v); set_prop(env, o, "lastScanBytes", v);
+  napi_create_double(env, (double)st.candidates, &v); set_prop(env, o, "candidates", v);
+  napi_create_double(env, (double)st.dense_fallbacks, &v); set_prop(env, o, "denseFallbacks", v);
+  napi_create_double(env, (double)bbq_index_bytes_per_row(ix), &v); set_prop(env, o, "bytesPerRow", v);
+  return o;
+}
+
+static napi_value Init(napi_env env, napi_value exports) {
+  napi_property_descriptor d[] = {
+      {"deviceCount", NULL, DeviceCount, NULL, NULL, NULL, napi_default, NULL},
+      {"quantizeVectors", NULL, QuantizeVectors, NULL, NULL, NULL, napi_default, NULL},
+      {"quantizeQuery", NULL, QuantizeQuery, NULL, NULL, NULL, napi_default, NULL},
+      {"centroidDP", NULL, CentroidDP, NULL, NULL, NULL, napi_default, NULL},
+      {"indexCreate", NULL, IndexCreate, NULL, NULL, NULL, napi_default, NULL},
+      {"indexDestroy", NULL, IndexDestroy, NULL, NULL, NULL, napi_default, NULL},
+      {"searchBatch", NULL, SearchBatch, NULL, NULL, NULL, napi_default, NULL},
+      {"scoreRows", NULL, ScoreRows, NULL, NULL, NULL, napi_default, NULL},
+      {"setOption", NULL, SetOption, NULL, NULL, NULL, napi_default, NULL},
+      {"stats", NULL, Stats, NULL, NULL, NULL, napi_default, NULL},
+  };
+  if (napi_define_properties(env, exports, sizeof d / sizeof d[0], d) != napi_ok) return NULL;
+  return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

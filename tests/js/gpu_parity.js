@@ -1,0 +1,68 @@
+'use strict';
+// GPU parity through the JavaScript drop-in API: top-k lists, per-row scores and quickSearch against the golden vectors.
+const T = require('./common');
+const bbq = T.bbq;
+if (bbq.deviceCount() < 1) { console.error('no HIP device'); process.exit(2); }
+
+T.goldenNames().filter(function (n) { return !/^(intdot_|api_)/.test(n); }).forEach(function (name) {
+  if (/^big_(50000|30000)/.test(name)) return;  // covered by pytest; keeps the node run short
+  const g = T.loadGolden(name), io = T.inputs(g);
+  const fmt = new bbq.BinaryQuantizationFormat({ queryBits: g.qb, indexBits: g.ib, quantizer: { similarityFunction: g.sim, lambda: g.lambda, iters: g.iters } });
+  const index = fmt.quantizeVectors(io.base).quantizedVectors;
+  for (let qi = 0; qi < g.nq; qi++) {
+    const rec = g.queries[qi];
+    rec.topk.forEach(function (tk) {
+      const res = fmt.searchNearestNeighbors(io.queries[qi], index, tk.k);
+      const wi = T.dec(tk.idx_i32, Int32Array), ws = T.dec(tk.score_f32, Float32Array);
+      let ok = res.length === wi.length;
+      for (let i = 0; ok && i < res.length; i++) ok = res[i].index === wi[i] && (res[i].score === ws[i] || (res[i].score !== res[i].score && ws[i] !== ws[i]));
+      T.check(ok, name + ' q' + qi + ' k=' + tk.k + ': top-k list');
+    });
+    if (g.full && g.n <= 1000) {  // computeBatchQuantizedScores with scattered ords
+      const q = fmt.quantizeQueryVector(g.sim === 'COSINE' ? normalise(io.queries[qi]) : io.queries[qi], index.getCentroid());
+      const ords = []; for (let i = g.n - 1; i >= 0; i -= 3) ords.push(i);
+      const out = fmt.getScorer().computeBatchQuantizedScores(q.quantizedQuery, q.queryCorrections, index, ords, g.qb);
+      const wd = T.dec(rec.qcdist_i32, Int32Array), w64 = T.dec(rec.score_f64, Float64Array);
+      let ok = out.length === ords.length;
+      for (let i = 0; ok && i < ords.length; i++) ok = out[i].bitDotProduct === wd[ords[i]] && (out[i].score === w64[ords[i]] || (out[i].score !== out[i].score && w64[ords[i]] !== w64[ords[i]]));
+      T.check(ok, name + ' q' + qi + ': computeBatchQuantizedScores');
+    }
+  }
+  index.dispose();
+});
+function normalise(v) {
+  let n2 = 0; for (let i = 0; i < v.length; i++) n2 += v[i] * v[i];
+  const nm = Math.sqrt(n2), out = new Float32Array(v.length);
+  if (nm !== 0) for (let i = 0; i < v.length; i++) out[i] = v[i] / nm;
+  return out;
+}
+// BASELINE config 1 through quickSearch (SURVEY App. C)
+(function () {
+  const base = T.randMatrix(3, 1000, 128), query = T.randMatrix(4, 1, 128)[0];
+  const t0 = Date.now();
+  const res = bbq.quickSearch(query, base, 10);
+  const ms = Date.now() - t0;
+  T.check(JSON.stringify(res.map(function (r) { return r.index; })) === JSON.stringify([438, 839, 190, 656, 637, 545, 630, 174, 862, 42]), 'quickSearch C1 indices');
+  T.check(res[0].score === 0.6655263304710388, 'quickSearch C1 top score');
+  console.log('quickSearch 1000x128 k=10 (quantize + upload + search): ' + ms + ' ms');
+  // oversample + rerank (tests/recall.test.ts:515-636) on the reference's closed-form dataset
+  const g = T.loadGolden('closed_100x128_qb4'), io = T.inputs(g);
+  const fmt = new bbq.BinaryQuantizationFormat({ queryBits: 4, indexBits: 1, quantizer: { similarityFunction: 'COSINE', lambda: 0.001, iters: 20 } });
+  const index = fmt.quantizeVectors(io.base).quantizedVectors;
+  for (let qi = 0; qi < g.nq; qi++) {
+    const got = bbq.getOversampledTopKWithHeap(io.queries[qi], index, io.base, g.k, 3, fmt).map(function (c) { return c.index; });
+    T.check(JSON.stringify(got) === JSON.stringify(g.queries[qi].oversample.idx), 'oversampled top-k q' + qi);
+    const got2 = bbq.getOversampledTopKWithSort(io.queries[qi], index, io.base, g.k, 3, fmt).map(function (c) { return c.index; });
+    T.check(got2.length === g.k, 'oversample with sort length');
+  }
+  const k50 = fmt.searchNearestNeighbors(io.queries[0], index, 500);
+  T.check(k50.length === 100, 'k > N clamps to N');
+  const batch = fmt.searchNearestNeighborsBatch(io.queries, index, 10);
+  let ok = batch.length === g.nq;
+  for (let qi = 0; ok && qi < g.nq; qi++) {
+    const wi = T.dec(g.queries[qi].topk[0].idx_i32, Int32Array);
+    for (let i = 0; ok && i < 10; i++) ok = batch[qi][i].index === wi[i];
+  }
+  T.check(ok, 'searchNearestNeighborsBatch equals per-query results');
+})();
+T.finish('js gpu_parity');

@@ -1,0 +1,125 @@
+"""CPU: the product's host-side code (C++ quantizer, heap replay) against the golden vectors and the oracle."""
+import numpy as np
+import pytest
+
+import orclib as O
+from bbqlib import bbq_amd as B, capi
+
+CASES = [n for n in O.golden_names() if not n.startswith(("intdot_", "api_", "big_5", "big_3"))]
+
+
+def canon64(a):
+    a = np.array(a, np.float64)
+    a[np.isnan(a)] = np.nan
+    return a.view(np.uint64)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_product_quantizer_matches_reference(name):
+    g = O.load_golden(name)
+    sim = O.SIMS[g["sim"]]
+    base, queries = O.golden_inputs(g)
+    codes, corr, cen = B.quantize_vectors(base, sim, 1, g["lambda"], g["iters"], n_threads=3)
+    assert O.sha(codes) == g["codes_sha256"]
+    ocodes, ocorr, ocen = O.build_index(base, sim, g["lambda"], g["iters"])
+    np.testing.assert_array_equal(canon64(corr), canon64(ocorr))
+    assert O.sha(cen) == O.sha(O.dec(g["centroid_f32"], "<f4"))
+    for qi, rec in enumerate(g["queries"]):
+        qq, qc = B.quantize_query(queries[qi], cen, sim, g["qb"], g["lambda"], g["iters"])
+        np.testing.assert_array_equal(qq, O.dec(rec["qquant_u8"], "u1"))
+        np.testing.assert_array_equal(canon64(qc), canon64(O.dec(rec["qcorr_f64"], "<f8")))
+
+
+@pytest.mark.parametrize("name", O.golden_names("intdot_*"))
+def test_product_quantizer_multibit_index(name):
+    g = O.load_golden(name)
+    n, dim = g["n"], g["dim"]
+    base = O.mulberry32(g["gen"]["base_seed"], n * dim).reshape(n, dim)
+    codes, corr, cen = B.quantize_vectors(base, O.SIMS[g["sim"]], g["ib"], g["lambda"], g["iters"])
+    np.testing.assert_array_equal(codes.ravel(), O.dec(g["codes_unpacked_u8"], "u1"))
+    np.testing.assert_array_equal(corr.ravel().view(np.uint64), O.dec(g["corr_f64"], "<f8").view(np.uint64))
+
+
+def test_quantizer_errors_like_the_reference():
+    with pytest.raises(B.BBQError) as e:
+        B.quantize_vectors(np.zeros((0, 4), np.float32), 0)
+    assert e.value.code == capi.ERR_EMPTY and "向量集合不能为空" in str(e.value)
+    v = np.ones((3, 4), np.float32)
+    v[2, 1] = np.nan
+    with pytest.raises(B.BBQError) as e:
+        B.quantize_vectors(v, 0)
+    assert e.value.code == capi.ERR_NAN_INPUT and "向量 2 位置 1 包含NaN值" in str(e.value)
+    v[2, 1] = np.inf
+    v[1, 3] = -np.inf
+    with pytest.raises(B.BBQError) as e:
+        B.quantize_vectors(v, 2)
+    assert e.value.code == capi.ERR_INF_INPUT and "向量 1 位置 3 包含Infinity值" in str(e.value)
+
+
+def _entries(rows, s32):
+    return (rows.astype(np.uint64) << np.uint64(32)) | s32[rows].view(np.uint32).astype(np.uint64)
+
+
+def _superset(s32, k, seg_bounds):
+    """rows the device would emit: everything in the first segment, then rows above the k-th largest of the prefix
+    that ends where their segment starts (keys compared as the kernels do)"""
+    b = s32.view(np.uint32).astype(np.int64)
+    key = np.where(b & 0x80000000, (~b) & 0xFFFFFFFF, b | 0x80000000)
+    keep = np.zeros(len(s32), bool)
+    keep[:seg_bounds[0]] = True
+    for a, e in zip(seg_bounds[:-1], seg_bounds[1:]):
+        if a >= k:
+            th = np.sort(key[:a])[-k]
+            keep[a:e] = key[a:e] > th
+        else:
+            keep[a:e] = True
+    return np.nonzero(keep)[0]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_replay_over_candidate_superset_equals_reference_heap(seed):
+    """size-independent property: replaying the heap over ANY superset (in row order) of the rows above the
+    prefix thresholds reproduces the reference's top-k exactly, ties included"""
+    rng = np.random.default_rng(seed)
+    n, k = 20000, [1, 7, 50, 100, 300, 1000][seed]
+    levels = [40, 300, 5000, 20000, 8, 100][seed]  # few distinct values => heavy ties
+    s32 = (rng.integers(0, levels, n).astype(np.float32) / np.float32(levels)).astype(np.float32)
+    oi, osc = O.heap_topk(s32, k)
+    bounds = [min(max(1024, 4 * k), n)]
+    while bounds[-1] < n:
+        bounds.append(min(bounds[-1] * 4, n))
+    rows = _superset(s32, k, bounds)
+    assert len(rows) < n
+    idx, sc = B.replay([_entries(rows, s32)], n, k)
+    np.testing.assert_array_equal(idx, oi)
+    np.testing.assert_array_equal(sc.view(np.uint32), osc.view(np.uint32))
+    # a looser superset (extra random rows) changes nothing
+    extra = np.union1d(rows, rng.integers(0, n, 500))
+    idx2, _ = B.replay([_entries(extra, s32)], n, k)
+    np.testing.assert_array_equal(idx2, oi)
+    # split over several shard lists
+    cut = [0, len(rows) // 3, 2 * len(rows) // 3, len(rows)]
+    idx3, _ = B.replay([_entries(rows[a:b], s32) for a, b in zip(cut[:-1], cut[1:])], n, k)
+    np.testing.assert_array_equal(idx3, oi)
+
+
+def test_replay_edge_cases():
+    s32 = np.array([0.5, 0.25, 0.5, 0.75], np.float32)
+    rows = np.arange(4)
+    idx, sc = B.replay([_entries(rows, s32)], 4, 10)          # k > N
+    oi, osc = O.heap_topk(s32, 10)
+    np.testing.assert_array_equal(idx, oi)
+    idx, sc = B.replay([_entries(rows, s32)], 4, 0)           # k == 0
+    assert len(idx) == 0
+    idx, sc = B.replay([], 0, 5)                              # nothing
+    assert len(idx) == 0
+    with pytest.raises(B.BBQError):
+        B.replay([_entries(rows[::-1].copy(), s32)], 4, 2)    # not ascending
+    with pytest.raises(B.BBQError) as e:
+        B.replay([_entries(rows, s32)], 4, -1)
+    assert e.value.code == capi.ERR_NEGATIVE_K
+    # NaN scores follow the reference's comparator (a - b >= 0 is false for NaN)
+    s = np.array([0.1, np.nan, 0.3, 0.2, np.nan, 0.9], np.float32)
+    idx, sc = B.replay([_entries(np.arange(6), s)], 6, 3)
+    oi, osc = O.heap_topk(s, 3)
+    np.testing.assert_array_equal(idx, oi)

@@ -1,0 +1,18 @@
+"""GPU: the JavaScript drop-in API (N-API addon over libbbq) against the golden vectors, under node."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from bbqlib import ROOT
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_js_host_gpu_parity():
+    r = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "gpu_parity.js")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    print(r.stdout[-2000:])
+    assert r.returncode == 0, r.stdout[-4000:]
+    assert "0 failures" in r.stdout
