@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1: nccl (= RCCL) or gloo (rehearsal)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -138,8 +140,13 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        if args.same_device:
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
     if world != args.gpus:
         log("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     device = local if world > 1 else 0
@@ -179,46 +186,28 @@ def main():
         torch.cuda.synchronize()
 
     results = []
+    batches = [(qq_all[i * Q:(i + 1) * Q], qc_all[i * Q:(i + 1) * Q]) for i in range(n_steps)]
     if world == 1:
-        def step(i):
-            s = slice(i * Q, (i + 1) * Q)
-            results.append(ix.search_batch(qq_all[s], qc_all[s], 4, 1, k))
+        def run(bs):
+            for qq, qc in bs:
+                results.append(ix.search_batch(qq, qc, 4, 1, k))
     else:
-        cap = int(ix.shard_list_cap(k))
-        caps = torch.tensor([cap], device="cuda")
-        dist.all_reduce(caps, op=dist.ReduceOp.MAX)
-        cap = int(caps.item())
-        lists = torch.zeros((Q, cap), dtype=torch.int64, device="cuda")
-        counts = torch.zeros((Q, 2), dtype=torch.int32, device="cuda")
-        g_lists = torch.zeros((world, Q, cap), dtype=torch.int64, device="cuda")
-        g_counts = torch.zeros((world, Q, 2), dtype=torch.int32, device="cuda")
+        from bbq_amd.distributed import ShardedSearcher
+        searcher = ShardedSearcher(ix, N, k, Q, query_bits=4, sim=1, replay_threads=max(args.replay_threads, 16), device="cuda",
+                                   collective_device="cuda" if args.backend == "nccl" else "cpu")
 
-        def step(i):
-            s = slice(i * Q, (i + 1) * Q)
-            ix.shard_scan(qq_all[s], qc_all[s], 4, 1, k, lists.data_ptr(), cap, counts.data_ptr())
-            dist.all_gather_into_tensor(g_counts, counts)
-            dist.all_gather_into_tensor(g_lists, lists)
-            if rank == 0:
-                hc = g_counts.cpu().numpy()
-                if (hc[:, :, 1] != 0).any():
-                    raise SystemExit("bench.py: a shard flagged overflow/NaN; dense multi-shard path not exercised by the bench")
-                hl = g_lists.cpu().numpy().view(np.uint64)
-                out = []
-                for q in range(Q):
-                    out.append(B.replay([hl[r, q, :hc[r, q, 0]] for r in range(world)], N, k))
-                results.append(out)
+        def run(bs):
+            results.extend(searcher.search_stream(bs))
 
-    for i in range(args.warmup):
-        step(i)
+    run(batches[:args.warmup])
     ix.reset_stats()
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.warmup, n_steps):
-        step(i)
+    run(batches[args.warmup:])
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = ix.stats()
@@ -257,13 +246,16 @@ def main():
             out["cpu_baseline"] = {"value": 1e6 / (us_row * N), "unit": "queries/s", "cores": 1, "kind": "port",
                                    "sample": "%d queries x %d rows of the same synthetic index in %.1fs (%.3f us/row), linearly extrapolated to %d rows"
                                              % (done, rows, secs, us_row, N)}
-            # the sample doubles as a parity check of the timed configuration
+            # the sample doubles as a parity check of the timed configuration: one full-size query against the oracle
+            import orclib as O
             if world == 1:
-                import orclib as O
-                _, _, s32 = O.score_all(codes, corr, dim, qq_all[args.warmup * Q], qc_all[args.warmup * Q], 4, 1, cdp)
-                oi, osc = O.heap_topk(s32, k)
-                gi, gs, _ = results[args.warmup]
-                out["parity_full_size"] = bool((gi[0] == oi).all() and (gs[0].view(np.uint32) == osc.view(np.uint32)).all())
+                fc, fr = codes, corr
+            else:
+                fc, fr = synth_rows(1, 0, N, pb)  # rank 0 rebuilds the whole index for the checker only
+            _, _, s32 = O.score_all(fc, fr, dim, qq_all[args.warmup * Q], qc_all[args.warmup * Q], 4, 1, cdp)
+            oi, osc = O.heap_topk(s32, k)
+            gi, gs, _ = results[args.warmup]
+            out["parity_full_size"] = bool((gi[0] == oi).all() and (gs[0].view(np.uint32) == osc.view(np.uint32)).all())
         if not args.no_recall:
             rec, desc = recall_probe(B, device)
             out["recall_at_100"] = rec

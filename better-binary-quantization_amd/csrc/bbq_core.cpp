@@ -93,6 +93,10 @@ struct bbq_index {
   uint32_t *d_aux_flags = nullptr;
   float *d_dense_all = nullptr;
   int64_t dense_all_cap = 0;
+  // bbq_shard_scan: per-query lists before packing
+  uint64_t *d_shard_lists = nullptr;
+  int32_t *d_shard_counts = nullptr;
+  int64_t shard_q_cap = 0, shard_list_cap = 0;
   // options
   int opt_batch = 16, opt_slots = 2, opt_growth = 8, opt_tpw = 1, opt_replay_threads = 1, opt_force_dense = 0;
   int64_t opt_s0 = 4096;
@@ -650,6 +654,8 @@ void bbq_index_destroy(bbq_index *ix) {
   if (ix->pilot.d_tiles) (void)hipFree(ix->pilot.d_tiles);
   if (ix->main.d_tiles) (void)hipFree(ix->main.d_tiles);
   if (ix->d_dense_all) (void)hipFree(ix->d_dense_all);
+  if (ix->d_shard_lists) (void)hipFree(ix->d_shard_lists);
+  if (ix->d_shard_counts) (void)hipFree(ix->d_shard_counts);
   if (ix->d_aux_qbuf) (void)hipFree(ix->d_aux_qbuf);
   if (ix->d_aux_flags) (void)hipFree(ix->d_aux_flags);
   if (ix->aux_stream) (void)hipStreamDestroy(ix->aux_stream);
@@ -795,42 +801,61 @@ int64_t bbq_shard_list_cap(const bbq_index *cix, int64_t k) {
 }
 
 int bbq_shard_scan(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, const double *qcorr, int32_t query_bits,
-                   int32_t sim, int64_t k, void *dev_lists, int64_t list_cap, void *dev_counts) {
+                   int32_t sim, int64_t k, void *dev_packed, int64_t packed_cap, void *dev_offsets, void *dev_flags,
+                   int64_t *out_total) {
   clear_error();
   int rc = validate_query_args(ix, n_queries, qquant, qcorr, query_bits, sim, k);
   if (rc != BBQ_OK) return rc;
+  if (out_total) *out_total = 0;
   if (n_queries == 0) return BBQ_OK;
-  if (!dev_lists || !dev_counts || list_cap <= 0) return fail(BBQ_ERR_INVALID_ARG, "bbq_shard_scan: null list buffers");
+  if (!dev_packed || !dev_offsets || !dev_flags || !out_total || packed_cap <= 0)
+    return fail(BBQ_ERR_INVALID_ARG, "bbq_shard_scan: null output buffers");
   if (k == 0 || k > kMaxFastK) return fail(BBQ_ERR_UNSUPPORTED, "bbq_shard_scan: k must be in 1..%lld", (long long)kMaxFastK);
   HIPCHK(hipSetDevice(ix->device));
   BatchCtx c{ix, qquant, qcorr, planes_for(qquant, (int64_t)n_queries * ix->dim), query_bits == 1 ? 1 : 0, sim, k};
   if (c.one_bit) c.planes = 1;
   build_plan(ix, k);
+  const int64_t list_cap = ix->plan.list_cap;
+  if (ix->shard_q_cap < n_queries || ix->shard_list_cap < list_cap) {  // per-query lists the finalize kernels build
+    if (ix->d_shard_lists) HIPCHK(hipFree(ix->d_shard_lists));
+    if (ix->d_shard_counts) HIPCHK(hipFree(ix->d_shard_counts));
+    ix->d_shard_lists = nullptr;
+    ix->d_shard_counts = nullptr;
+    HIPCHK(hipMalloc((void **)&ix->d_shard_lists, (size_t)n_queries * (size_t)list_cap * 8));
+    HIPCHK(hipMalloc((void **)&ix->d_shard_counts, (size_t)n_queries * 8 + 16));
+    ix->shard_q_cap = n_queries;
+    ix->shard_list_cap = list_cap;
+  }
   const int Q = std::max(1, ix->opt_batch);
   const int nslots = std::min(std::max(1, ix->opt_slots), kMaxSlots);
   const int64_t nsub = ((int64_t)n_queries + Q - 1) / Q;
+  auto retire = [&](Slot &s) -> int {
+    HIPCHK(hipEventSynchronize(s.ev_done));
+    s.busy = false;
+    account_timing(ix, s);
+    return BBQ_OK;
+  };
   for (int64_t i = 0; i < nsub; ++i) {
     Slot &s = ix->slots[i % nslots];
-    if (s.busy) {
-      HIPCHK(hipEventSynchronize(s.ev_done));
-      s.busy = false;
-      account_timing(ix, s);
-    }
+    if (s.busy && (rc = retire(s)) != BBQ_OK) { drain(ix); return rc; }
     const int nq = (int)std::min<int64_t>(Q, n_queries - i * Q);
     rc = ensure_slot(ix, s, nq, false);
     if (rc != BBQ_OK) { drain(ix); return rc; }
-    rc = enqueue_subbatch(c, s, i * Q, nq, reinterpret_cast<uint64_t *>(dev_lists) + (size_t)(i * Q) * list_cap, list_cap,
-                          reinterpret_cast<int32_t *>(dev_counts) + (size_t)(i * Q) * 2);
+    rc = enqueue_subbatch(c, s, i * Q, nq, ix->d_shard_lists + (size_t)(i * Q) * list_cap, list_cap, ix->d_shard_counts + (size_t)(i * Q) * 2);
     if (rc != BBQ_OK) { drain(ix); return rc; }
   }
-  for (int i = 0; i < nslots; ++i) {
-    Slot &s = ix->slots[i];
-    if (s.busy) {
-      HIPCHK(hipEventSynchronize(s.ev_done));
-      s.busy = false;
-      account_timing(ix, s);
-    }
-  }
+  for (int i = 0; i < nslots; ++i)
+    if (ix->slots[i].busy && (rc = retire(ix->slots[i])) != BBQ_OK) { drain(ix); return rc; }
+  // pack: [nq][list_cap] -> contiguous entries + offsets, what the host framework sends over RCCL
+  int64_t *d_total = reinterpret_cast<int64_t *>(ix->d_shard_counts + (size_t)n_queries * 2);
+  d_total = reinterpret_cast<int64_t *>(((uintptr_t)d_total + 7) & ~(uintptr_t)7);
+  HIPCHK(launch_pack(ix->d_shard_counts, ix->d_shard_lists, list_cap, n_queries, reinterpret_cast<int64_t *>(dev_offsets),
+                     reinterpret_cast<int32_t *>(dev_flags), d_total, reinterpret_cast<uint64_t *>(dev_packed), packed_cap, ix->aux_stream));
+  int64_t total = 0;
+  HIPCHK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, ix->aux_stream));
+  HIPCHK(hipStreamSynchronize(ix->aux_stream));
+  *out_total = total;
+  if (total > packed_cap) return fail(BBQ_ERR_OOM, "bbq_shard_scan: %lld candidates do not fit packed_cap %lld", (long long)total, (long long)packed_cap);
   return BBQ_OK;
 }
 

@@ -361,6 +361,45 @@ __global__ __launch_bounds__(256) void bbq_check_x1_kernel(const uint8_t *__rest
 }
 
 // ---------------------------------------------------------------------------------------------------
+// shard transport: per-query lists [nq][list_cap] -> one packed buffer + offsets (what goes over RCCL)
+
+__global__ __launch_bounds__(1024) void bbq_pack_offsets_kernel(const int32_t *__restrict__ counts /*[nq][2]*/, int32_t nq,
+                                                               int64_t *__restrict__ offsets /*[nq+1]*/, int32_t *__restrict__ flags_out,
+                                                               int64_t *__restrict__ total_out) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint64_t s_base;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (int32_t q0 = 0; q0 < nq; q0 += 1024) {
+    const int32_t q = q0 + (int32_t)threadIdx.x;
+    uint32_t c = 0;
+    if (q < nq) {
+      const int32_t f = counts[2 * q + 1];
+      flags_out[q] = f;
+      c = f ? 0u : (uint32_t)counts[2 * q];  // a flagged query carries no list: it takes the dense path
+    }
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan_1024(c, s_wave, total);
+    const uint64_t base = s_base;
+    if (q < nq) offsets[q] = (int64_t)(base + ex);
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = base + total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { offsets[nq] = (int64_t)s_base; *total_out = (int64_t)s_base; }
+}
+
+__global__ __launch_bounds__(256) void bbq_pack_copy_kernel(const uint64_t *__restrict__ lists, int64_t list_cap,
+                                                           const int64_t *__restrict__ offsets, uint64_t *__restrict__ packed,
+                                                           int64_t packed_cap) {
+  const int q = blockIdx.x;
+  const int64_t b = offsets[q], e = offsets[q + 1];
+  if (e > packed_cap) return;  // the host sees total > packed_cap and reports it
+  const uint64_t *__restrict__ src = lists + (size_t)q * list_cap;
+  for (int64_t i = threadIdx.x; i < e - b; i += 256) packed[b + i] = src[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // launch wrappers (declared in bbq_launch.h)
 
 template <int QB, int W, bool DENSE, int TPW>
@@ -413,6 +452,14 @@ hipError_t launch_scan(const ScanArgs &a, int planes, bool dense, int n_queries,
 
 hipError_t launch_finalize(const FinalizeArgs &a, int n_queries, hipStream_t s) {
   hipLaunchKernelGGL(bbq_finalize_kernel, dim3((unsigned)n_queries), dim3(kFinalizeThreads), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack(const int32_t *counts, const uint64_t *lists, int64_t list_cap, int32_t nq, int64_t *offsets, int32_t *flags_out,
+                       int64_t *total_out, uint64_t *packed, int64_t packed_cap, hipStream_t s) {
+  if (nq <= 0) return hipSuccess;
+  hipLaunchKernelGGL(bbq_pack_offsets_kernel, dim3(1), dim3(1024), 0, s, counts, nq, offsets, flags_out, total_out);
+  hipLaunchKernelGGL(bbq_pack_copy_kernel, dim3((unsigned)nq), dim3(256), 0, s, lists, list_cap, (const int64_t *)offsets, packed, packed_cap);
   return hipGetLastError();
 }
 

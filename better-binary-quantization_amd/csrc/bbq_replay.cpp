@@ -11,6 +11,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <thread>
+#include <vector>
 #include "bbq_internal.h"
 
 namespace bbq {
@@ -116,6 +118,53 @@ int bbq_replay(int32_t n_lists, const bbq_cand *const *lists, const int64_t *cou
     }
   }
   *out_n = h.finish(out_idx, out_score);
+  return BBQ_OK;
+}
+
+
+int bbq_replay_batch(int32_t n_sources, const bbq_cand *const *packed, const int64_t *const *offsets, int32_t n_queries,
+                     int64_t n_total, int64_t k, int32_t n_threads, int32_t *out_idx, float *out_score, int64_t *out_n) {
+  bbq::clear_error();
+  if (n_sources < 0 || n_queries < 0 || (n_sources > 0 && (!packed || !offsets)) || (n_queries > 0 && !out_n))
+    return bbq::fail(BBQ_ERR_INVALID_ARG, "bbq_replay_batch: null argument");
+  if (k < 0) return bbq::fail(BBQ_ERR_NEGATIVE_K, "k值不能为负数");
+  for (int32_t q = 0; q < n_queries; ++q) out_n[q] = 0;
+  if (k == 0 || n_queries == 0) return BBQ_OK;
+  if (!out_idx || !out_score) return bbq::fail(BBQ_ERR_INVALID_ARG, "bbq_replay_batch: null output");
+  std::vector<int> bad((size_t)n_queries, 0);
+  auto work = [&](int32_t lo, int32_t hi) {
+    for (int32_t q = lo; q < hi; ++q) {
+      bbq::HeapReplay h(k, n_total);
+      uint32_t prev = 0;
+      bool first = true;
+      for (int32_t s = 0; s < n_sources && !bad[(size_t)q]; ++s) {
+        const bbq_cand *l = packed[s] + offsets[s][q];
+        const int64_t cnt = offsets[s][q + 1] - offsets[s][q];
+        for (int64_t j = 0; j < cnt; ++j) {
+          const uint32_t row = (uint32_t)(l[j] >> 32);
+          if (!first && row <= prev) { bad[(size_t)q] = 1; break; }
+          prev = row;
+          first = false;
+          const uint32_t bits = (uint32_t)l[j];
+          float sc;
+          memcpy(&sc, &bits, 4);
+          h.offer(sc, (int32_t)row);
+        }
+      }
+      out_n[q] = h.finish(out_idx + (int64_t)q * k, out_score + (int64_t)q * k);
+    }
+  };
+  int T = n_threads > 0 ? n_threads : 1;
+  if (T > n_queries) T = n_queries;
+  if (T <= 1) {
+    work(0, n_queries);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(work, (int32_t)((int64_t)n_queries * t / T), (int32_t)((int64_t)n_queries * (t + 1) / T));
+    for (auto &x : th) x.join();
+  }
+  for (int32_t q = 0; q < n_queries; ++q)
+    if (bad[(size_t)q]) return bbq::fail(BBQ_ERR_INVALID_ARG, "bbq_replay_batch: candidates of query %d not in ascending row order", q);
   return BBQ_OK;
 }
 

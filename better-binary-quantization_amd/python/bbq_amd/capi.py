@@ -18,7 +18,7 @@ SIMS = {"EUCLIDEAN": 0, "COSINE": 1, "MAXIMUM_INNER_PRODUCT": 2}
 SYMBOLS = [
     "bbq_last_error", "bbq_abi_version", "bbq_device_count", "bbq_index_create", "bbq_index_create_shard",
     "bbq_index_destroy", "bbq_index_size", "bbq_index_dimension", "bbq_index_bytes_per_row", "bbq_search",
-    "bbq_search_batch", "bbq_score_rows", "bbq_shard_scan", "bbq_shard_list_cap", "bbq_replay",
+    "bbq_search_batch", "bbq_score_rows", "bbq_shard_scan", "bbq_shard_list_cap", "bbq_replay", "bbq_replay_batch",
     "bbq_quantize_vectors", "bbq_quantize_query", "bbq_quantize_query_vector", "bbq_centroid_dp", "bbq_get_stats",
     "bbq_reset_stats", "bbq_set_option",
 ]
@@ -64,10 +64,11 @@ def lib():
     L.bbq_search.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp, vp]
     L.bbq_search_batch.argtypes = [vp, i32, vp, vp, i32, i32, i64, vp, vp, vp]
     L.bbq_score_rows.argtypes = [vp, vp, vp, i32, i32, i64, i64, vp, vp, vp]
-    L.bbq_shard_scan.argtypes = [vp, i32, vp, vp, i32, i32, i64, vp, i64, vp]
+    L.bbq_shard_scan.argtypes = [vp, i32, vp, vp, i32, i32, i64, vp, i64, vp, vp, C.POINTER(i64)]
     L.bbq_shard_list_cap.argtypes = [vp, i64]
     L.bbq_shard_list_cap.restype = i64
     L.bbq_replay.argtypes = [i32, vp, vp, i64, i64, vp, vp, vp]
+    L.bbq_replay_batch.argtypes = [i32, vp, vp, i32, i64, i64, i32, vp, vp, vp]
     L.bbq_quantize_vectors.argtypes = [vp, i64, i32, i32, i32, dbl, i32, i32, vp, vp, vp, vp, vp]
     L.bbq_quantize_query.argtypes = [vp, i32, vp, i32, i32, dbl, i32, vp, vp]
     L.bbq_quantize_query_vector.argtypes = [vp, i32, vp, i32, i32, dbl, i32, vp, vp]
@@ -206,11 +207,14 @@ class Index:
     def shard_list_cap(self, k):
         return lib().bbq_shard_list_cap(self._h, k)
 
-    def shard_scan(self, qquant, qcorr, query_bits, sim, k, dev_lists_ptr, list_cap, dev_counts_ptr):
+    def shard_scan(self, qquant, qcorr, query_bits, sim, k, dev_packed_ptr, packed_cap, dev_offsets_ptr, dev_flags_ptr):
+        """device pointers in (e.g. torch tensors' data_ptr()); returns the number of packed entries"""
         qq = np.ascontiguousarray(qquant, np.uint8)
         qc = np.ascontiguousarray(qcorr, np.float64)
-        _chk(lib().bbq_shard_scan(self._h, qq.shape[0], _ptr(qq), _ptr(qc), query_bits, sim, k, dev_lists_ptr, list_cap,
-                                 dev_counts_ptr))
+        total = C.c_int64(0)
+        _chk(lib().bbq_shard_scan(self._h, qq.shape[0], _ptr(qq), _ptr(qc), query_bits, sim, k, dev_packed_ptr, packed_cap,
+                                 dev_offsets_ptr, dev_flags_ptr, C.byref(total)))
+        return total.value
 
 
 def replay(lists, n_total, k):
@@ -225,3 +229,18 @@ def replay(lists, n_total, k):
     cnt = C.c_int64(0)
     _chk(lib().bbq_replay(n, ptrs, _ptr(counts), n_total, k, _ptr(idx), _ptr(sc), C.byref(cnt)))
     return idx[:cnt.value], sc[:cnt.value]
+
+
+def replay_batch(packed, offsets, n_queries, n_total, k, n_threads=1):
+    """packed[s]: uint64 array of source s (ascending shard order), offsets[s]: int64 [n_queries+1].  Host only."""
+    pk = [np.ascontiguousarray(a, np.uint64) for a in packed]
+    of = [np.ascontiguousarray(a, np.int64) for a in offsets]
+    n = len(pk)
+    pp = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in pk])
+    po = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in of])
+    kk = max(int(k), 0)
+    idx = np.zeros((n_queries, kk), np.int32)
+    sc = np.zeros((n_queries, kk), np.float32)
+    cnt = np.zeros(n_queries, np.int64)
+    _chk(lib().bbq_replay_batch(n, pp, po, n_queries, n_total, k, n_threads, _ptr(idx), _ptr(sc), _ptr(cnt)))
+    return idx, sc, cnt

@@ -124,20 +124,23 @@ int bbq_score_rows(bbq_index *idx, const uint8_t *qquant, const double *qcorr, i
 
 /* ------------------------------------------------------------------------------------------
  * Sharded search (one process per GPU).  bbq_shard_scan sweeps THIS shard for n_queries queries and
- * leaves, per query, the shard's candidate list - a superset of the rows that ever enter the
- * reference's heap, in ascending global row order - in caller-provided DEVICE memory, so the host
- * framework can gather the lists over RCCL; bbq_replay then replays the reference heap
- * (src/binaryQuantizationFormat.ts:383-411) over the concatenation of all shards' lists.
+ * leaves the shard's candidates - per query a superset of the rows that ever enter the reference's heap,
+ * ascending by global row - PACKED in caller-provided DEVICE memory, so the host framework can move them
+ * over RCCL; bbq_replay_batch then replays the reference heap
+ * (src/binaryQuantizationFormat.ts:383-411) over all shards' lists in shard order.
  *
- *   dev_lists   device pointer, [n_queries * list_cap] bbq_cand
- *   dev_counts  device pointer, [n_queries * 2] int32: {count, flags}; flags != 0 means the list is
- *               unusable (overflow / NaN score) and the query must take bbq_search's dense path
- *   The call returns after the device work has completed (lists are ready for a collective).
+ *   dev_packed   device pointer, [packed_cap] bbq_cand; query q's entries at [offsets[q], offsets[q+1])
+ *   dev_offsets  device pointer, [n_queries + 1] int64
+ *   dev_flags    device pointer, [n_queries] int32; non-zero: this shard could not bound the query
+ *                (candidate overflow / NaN score) - it carries no entries and the query must be scored densely
+ *   *out_total   (host) number of entries written = offsets[n_queries]
+ * The call returns after the device work has completed (buffers are ready for a collective).
+ * BBQ_ERR_OOM if the entries do not fit packed_cap.
  */
 int bbq_shard_scan(bbq_index *idx, int32_t n_queries, const uint8_t *qquant, const double *qcorr,
-                   int32_t query_bits, int32_t sim, int64_t k, void *dev_lists, int64_t list_cap,
-                   void *dev_counts);
-/* recommended list capacity for bbq_shard_scan given k */
+                   int32_t query_bits, int32_t sim, int64_t k, void *dev_packed, int64_t packed_cap,
+                   void *dev_offsets, void *dev_flags, int64_t *out_total);
+/* upper estimate of the entries ONE query leaves on this shard (use n_queries x this for packed_cap) */
 int64_t bbq_shard_list_cap(const bbq_index *idx, int64_t k);
 
 /* Host-only (no device needed): exact replay of the reference heap over candidate lists.
@@ -146,6 +149,11 @@ int64_t bbq_shard_list_cap(const bbq_index *idx, int64_t k);
  */
 int bbq_replay(int32_t n_lists, const bbq_cand *const *lists, const int64_t *counts, int64_t n_total, int64_t k,
                int32_t *out_idx, float *out_score, int64_t *out_n);
+/* The same for n_queries queries at once, n_threads host threads: source s (shard s, ascending shard order)
+ * contributes packed[s][offsets[s][q] .. offsets[s][q+1]) to query q.  out_idx/out_score [n_queries*k]. */
+int bbq_replay_batch(int32_t n_sources, const bbq_cand *const *packed, const int64_t *const *offsets,
+                     int32_t n_queries, int64_t n_total, int64_t k, int32_t n_threads, int32_t *out_idx,
+                     float *out_score, int64_t *out_n);
 
 /* ------------------------------------------------------------------------------------------
  * Host-side quantizer (multithreaded C++): what the JS host calls for quantizeVectors /
