@@ -58,9 +58,9 @@ def synth_rows(seed, row0, row1, pb):
     return codes, corr
 
 
-def synth_queries(seed, nq, dim):
+def synth_queries(seed, nq, dim, qb=4):
     rng = np.random.default_rng([seed, 777])
-    qq = rng.integers(0, 16, size=(nq, dim), dtype=np.uint8)
+    qq = rng.integers(0, 1 << qb, size=(nq, dim), dtype=np.uint8)
     qc = np.empty((nq, 4), np.float64)
     qc[:, 0] = -0.15 * (0.9 + 0.2 * rng.random(nq))
     qc[:, 1] = 0.148 * (0.9 + 0.2 * rng.random(nq))
@@ -92,7 +92,7 @@ def recall_probe(B, device, n=200000, dim=768, nq=32, k=100):
     return float(rec), {"n": n, "dim": dim, "queries": nq, "data": "2000 gaussian clusters, sigma 0.7"}
 
 
-def cpu_baseline(dim, k, codes, corr, qq, qc, cdp, budget_s=20.0):
+def cpu_baseline(dim, k, codes, corr, qq, qc, cdp, qb, sim, budget_s=20.0):
     """the oracle (CPU restatement of the reference loops, 1 thread) on a bounded sample of the same workload"""
     import orclib as O
     n = codes.shape[0]
@@ -101,7 +101,7 @@ def cpu_baseline(dim, k, codes, corr, qq, qc, cdp, budget_s=20.0):
     t0 = time.perf_counter()
     done = 0
     while True:
-        _, _, s32 = O.score_all(c, r, dim, qq[done % len(qq)], qc[done % len(qq)], 4, 1, cdp)
+        _, _, s32 = O.score_all(c, r, dim, qq[done % len(qq)], qc[done % len(qq)], qb, sim, cdp)
         O.heap_topk(s32, k)
         done += 1
         if time.perf_counter() - t0 > budget_s / 2 or done >= 8:
@@ -114,13 +114,15 @@ def cpu_baseline(dim, k, codes, corr, qq, qc, cdp, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=64, help="queries per step (each sweeps the index on its own)")
-    ap.add_argument("--sub-batch", type=int, default=16, help="queries per device launch sequence (pipelined inside a step)")
+    ap.add_argument("--batch", type=int, default=256, help="queries per step (each sweeps the index on its own)")
+    ap.add_argument("--sim", default="COSINE", choices=["EUCLIDEAN", "COSINE", "MAXIMUM_INNER_PRODUCT"])
+    ap.add_argument("--query-bits", type=int, default=4)
+    ap.add_argument("--sub-batch", type=int, default=32, help="queries per device launch sequence (pipelined inside a step)")
     ap.add_argument("--slots", type=int, default=3, help="pipeline slots (streams) inside the library")
     ap.add_argument("--replay-threads", type=int, default=8, help="host threads replaying the reference heap")
     ap.add_argument("--pilot", type=int, default=65536, help="replicated pilot rows per non-root shard (multi-GPU)")
@@ -155,6 +157,8 @@ def main():
     torch.cuda.set_device(device)
 
     N, dim, k, Q = args.rows, args.dim, args.k, args.batch
+    SIM = {"EUCLIDEAN": 0, "COSINE": 1, "MAXIMUM_INNER_PRODUCT": 2}[args.sim]
+    QB = args.query_bits
     pb = (dim + 7) // 8
     cdp = 0.0009110655808639536
     shard = (N + world - 1) // world
@@ -177,7 +181,7 @@ def main():
     bytes_per_row = ix.bytes_per_row
     log("rank %d: shard rows [%d,%d) built in %.1fs, %d B/row" % (rank, r0, r1, time.perf_counter() - t0, bytes_per_row))
     n_steps = args.warmup + args.steps
-    qq_all, qc_all = synth_queries(2, n_steps * Q, dim)
+    qq_all, qc_all = synth_queries(2, n_steps * Q, dim, QB)
 
     def barrier():
         torch.cuda.synchronize()
@@ -190,10 +194,10 @@ def main():
     if world == 1:
         def run(bs):
             for qq, qc in bs:
-                results.append(ix.search_batch(qq, qc, 4, 1, k))
+                results.append(ix.search_batch(qq, qc, QB, SIM, k))
     else:
         from bbq_amd.distributed import ShardedSearcher
-        searcher = ShardedSearcher(ix, N, k, Q, query_bits=4, sim=1, replay_threads=max(args.replay_threads, 16), device="cuda",
+        searcher = ShardedSearcher(ix, N, k, Q, query_bits=QB, sim=SIM, replay_threads=max(args.replay_threads, 16), device="cuda",
                                    collective_device="cuda" if args.backend == "nccl" else "cpu")
 
         def run(bs):
@@ -226,11 +230,11 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "queries/sec, 10Mx768 1-bit index, queryBits=4, k=100, exact top-k (bit-exact vs reference TS path)",
+            "metric": "queries/sec, %dx%d 1-bit index, queryBits=%d, k=%d, exact top-k (bit-exact vs reference TS path)" % (N, dim, QB, k),
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64 popcount + f64 score epilogue", "data": "synthetic",
-            "config": {"workload": "%dx%d-dim 1-bit index, queryBits=4, k=%d, COSINE, row-sharded over %d GPU(s)" % (N, dim, k, world),
+            "config": {"workload": "%dx%d-dim 1-bit index, queryBits=%d, k=%d, %s, row-sharded over %d GPU(s)" % (N, dim, QB, k, args.sim, world),
                        "queries_per_step": Q, "queries_per_launch": min(args.sub_batch, Q), "sweeps_per_query": 1,
                        "pipeline_slots": args.slots, "replay_threads": args.replay_threads, "bytes_per_row": bytes_per_row,
                        "parallelism": "row-shard x%d" % world},
@@ -242,7 +246,7 @@ def main():
             "dense_fallbacks": st["dense_fallbacks"],
         }
         if not args.no_cpu_baseline:
-            us_row, done, rows, secs = cpu_baseline(dim, k, codes, corr, qq_all, qc_all, cdp)
+            us_row, done, rows, secs = cpu_baseline(dim, k, codes, corr, qq_all, qc_all, cdp, QB, SIM)
             out["cpu_baseline"] = {"value": 1e6 / (us_row * N), "unit": "queries/s", "cores": 1, "kind": "port",
                                    "sample": "%d queries x %d rows of the same synthetic index in %.1fs (%.3f us/row), linearly extrapolated to %d rows"
                                              % (done, rows, secs, us_row, N)}
@@ -252,7 +256,7 @@ def main():
                 fc, fr = codes, corr
             else:
                 fc, fr = synth_rows(1, 0, N, pb)  # rank 0 rebuilds the whole index for the checker only
-            _, _, s32 = O.score_all(fc, fr, dim, qq_all[args.warmup * Q], qc_all[args.warmup * Q], 4, 1, cdp)
+            _, _, s32 = O.score_all(fc, fr, dim, qq_all[args.warmup * Q], qc_all[args.warmup * Q], QB, SIM, cdp)
             oi, osc = O.heap_topk(s32, k)
             gi, gs, _ = results[args.warmup]
             out["parity_full_size"] = bool((gi[0] == oi).all() and (gs[0].view(np.uint32) == osc.view(np.uint32)).all())

@@ -98,7 +98,7 @@ struct bbq_index {
   int32_t *d_shard_counts = nullptr;
   int64_t shard_q_cap = 0, shard_list_cap = 0;
   // options
-  int opt_batch = 16, opt_slots = 2, opt_growth = 8, opt_tpw = 1, opt_replay_threads = 1, opt_force_dense = 0;
+  int opt_batch = 32, opt_slots = 2, opt_growth = 8, opt_tpw = 1, opt_replay_threads = 1, opt_force_dense = 0;
   int64_t opt_s0 = 4096;
   bbq_stats stats{};
   int last_big_slot = -1;  // slot whose ev_big marks the end of the most recently enqueued big sweep
