@@ -260,6 +260,20 @@ def main():
             oi, osc = O.heap_topk(s32, k)
             gi, gs, _ = results[args.warmup]
             out["parity_full_size"] = bool((gi[0] == oi).all() and (gs[0].view(np.uint32) == osc.view(np.uint32)).all())
+            # the same loops restated in JS, under node on this box's host, 1 core
+            import shutil
+            import subprocess
+            if shutil.which("node"):
+                try:
+                    r = subprocess.run(["node", os.path.join(ROOT, "oracle", "bbq_oracle_js_baseline.js"), "300000", str(dim), str(k), "3"],
+                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
+                    js = json.loads(r.stdout.strip().splitlines()[-1])
+                    out["cpu_baseline_js"] = {"value": 1e6 / (js["us_per_row"] * N), "unit": "queries/s", "cores": 1,
+                                              "kind": "port (JavaScript restatement of the reference loops, node %s)" % js["node"],
+                                              "sample": "%d queries x %d rows in %.1fs (%.3f us/row), linearly extrapolated to %d rows"
+                                                        % (js["queries"], js["rows"], js["seconds"], js["us_per_row"], N)}
+                except Exception as e:  # the baseline is informational: never fail the bench for it
+                    out["cpu_baseline_js"] = {"error": str(e)[:200]}
         if not args.no_recall:
             rec, desc = recall_probe(B, device)
             out["recall_at_100"] = rec

@@ -15,6 +15,7 @@
 #include <string.h>
 #include <algorithm>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "bbq_internal.h"
@@ -78,18 +79,33 @@ struct Slot {
 
 }  // namespace
 
+// Per-device context shared by every index on that device: streams, events and the per-slot workspace are expensive
+// to create (~10 ms per index with hipStreamCreate/Destroy) and quickSearch builds a fresh index on every call
+// (src/index.ts:109), so they live for the process.  One API call at a time per device (mutex).
+struct DeviceCtx {
+  int device = 0;
+  std::mutex mu;
+  bool ready = false;
+  Slot slots[kMaxSlots];
+  hipStream_t aux_stream = nullptr;   // dense path / bbq_score_rows / index build: never touches an in-flight slot
+  uint8_t *d_aux_qbuf = nullptr;
+  int64_t aux_qbuf_bytes = 0;
+  uint32_t *d_aux_flags = nullptr;
+  int last_big_slot = -1;             // slot whose ev_big marks the end of the most recently enqueued big sweep
+};
+
 struct bbq_index {
   int device = 0;
+  DeviceCtx *ctx = nullptr;
+  Slot *slots = nullptr;  // = ctx->slots
   int32_t dim = 0, pb = 0, w16 = 0, tile_stride = 0, has_x1 = 0, bytes_per_row = 0;
   int64_t n_rows = 0, row_base = 0;
   double centroid_dp = 0;
   bool has_pilot = false;
   Storage pilot, main;
   Plan plan;
-  Slot slots[kMaxSlots];
-  // dense path / bbq_score_rows: own stream and staging so that it never touches an in-flight slot
-  hipStream_t aux_stream = nullptr;
-  uint8_t *d_aux_qbuf = nullptr;
+  hipStream_t aux_stream = nullptr;  // = ctx->aux_stream
+  uint8_t *d_aux_qbuf = nullptr;     // = ctx->d_aux_qbuf
   uint32_t *d_aux_flags = nullptr;
   float *d_dense_all = nullptr;
   int64_t dense_all_cap = 0;
@@ -101,10 +117,47 @@ struct bbq_index {
   int opt_batch = 32, opt_slots = 2, opt_growth = 8, opt_tpw = 1, opt_replay_threads = 1, opt_force_dense = 0;
   int64_t opt_s0 = 4096;
   bbq_stats stats{};
-  int last_big_slot = -1;  // slot whose ev_big marks the end of the most recently enqueued big sweep
 };
 
 namespace {
+
+int64_t qbuf_bytes_per_query_w(int w16) { return (int64_t)w16 * 8 * 16 + (int64_t)sizeof(QueryParams); }
+
+std::mutex g_ctx_mu;
+DeviceCtx *g_ctx[64] = {nullptr};
+
+// returns the (lazily created, never destroyed) context of a device; call with hipSetDevice(device) done
+int get_ctx(int device, DeviceCtx **out) {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  if (device < 0 || device >= 64) return fail(BBQ_ERR_INVALID_ARG, "device %d out of range", device);
+  if (!g_ctx[device]) {
+    DeviceCtx *c = new DeviceCtx();
+    c->device = device;
+    for (int i = 0; i < kMaxSlots; ++i) {
+      HIPCHK(hipStreamCreateWithFlags(&c->slots[i].stream, hipStreamNonBlocking));
+      HIPCHK(hipEventCreate(&c->slots[i].ev0));
+      HIPCHK(hipEventCreate(&c->slots[i].ev1));
+      HIPCHK(hipEventCreateWithFlags(&c->slots[i].ev_done, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&c->slots[i].ev_big, hipEventDisableTiming));
+    }
+    HIPCHK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc((void **)&c->d_aux_flags, 4));
+    HIPCHK(hipMemset(c->d_aux_flags, 0, 4));
+    c->ready = true;
+    g_ctx[device] = c;
+  }
+  *out = g_ctx[device];
+  return BBQ_OK;
+}
+
+int ensure_aux_qbuf(DeviceCtx *c, int64_t bytes) {
+  if (c->aux_qbuf_bytes >= bytes) return BBQ_OK;
+  if (c->d_aux_qbuf) HIPCHK(hipFree(c->d_aux_qbuf));
+  c->d_aux_qbuf = nullptr;
+  HIPCHK(hipMalloc((void **)&c->d_aux_qbuf, (size_t)bytes));
+  c->aux_qbuf_bytes = bytes;
+  return BBQ_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ storage
 
@@ -115,7 +168,7 @@ int make_storage(bbq_index *ix, Storage &st, const uint8_t *codes, const double 
   uint8_t *d_codes = nullptr;
   double *d_corr = nullptr;
   uint32_t *d_mis = nullptr;
-  hipStream_t s = ix->slots[0].stream;
+  hipStream_t s = ix->aux_stream;
   if (n_rows > 0) {
     HIPCHK(hipMalloc((void **)&d_codes, (size_t)(n_rows * pb)));
     HIPCHK(hipMalloc((void **)&d_corr, (size_t)n_rows * 32));
@@ -390,13 +443,13 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
     a.dense_score32 = g.dense ? s.d_dense0 : nullptr;
     a.dense_stride = s.dense_cap;
     const int my_slot = (int)(&s - ix->slots);
-    if (g.big && ix->last_big_slot >= 0 && ix->last_big_slot != my_slot)
-      HIPCHK(hipStreamWaitEvent(st, ix->slots[ix->last_big_slot].ev_big, 0));  // one big sweep at a time on the device
+    if (g.big && ix->ctx->last_big_slot >= 0 && ix->ctx->last_big_slot != my_slot)
+      HIPCHK(hipStreamWaitEvent(st, ix->slots[ix->ctx->last_big_slot].ev_big, 0));  // one big sweep at a time on the device
     if (g.dominant) HIPCHK(hipEventRecord(s.ev0, st));
     HIPCHK(launch_scan(a, c.planes, g.dense, nq, (int)g.n_chunks, ix->opt_tpw, st));
     if (g.big) {
       HIPCHK(hipEventRecord(s.ev_big, st));
-      ix->last_big_slot = my_slot;
+      ix->ctx->last_big_slot = my_slot;
     }
     if (g.dominant) {
       HIPCHK(hipEventRecord(s.ev1, st));
@@ -461,17 +514,19 @@ int dense_search_one(const BatchCtx &c, int64_t qi, int32_t *out_idx, float *out
     HIPCHK(hipMalloc((void **)&ix->d_dense_all, (size_t)std::max<int64_t>(n, 1) * 4));
     ix->dense_all_cap = n;
   }
+  int rc_aux = ensure_aux_qbuf(ix->ctx, qbuf_bytes_per_query_w(ix->w16));
+  if (rc_aux != BBQ_OK) return rc_aux;
   const int64_t qb = (int64_t)ix->w16 * c.planes * 16;
   std::vector<uint8_t> hb((size_t)qb + sizeof(QueryParams));
   fill_query(ix, hb.data(), reinterpret_cast<QueryParams *>(hb.data() + qb), c.qquant + (size_t)qi * ix->dim, c.qcorr + (size_t)qi * 4,
              c.planes, c.one_bit, c.sim);
   hipStream_t st = ix->aux_stream;
-  HIPCHK(hipMemcpyAsync(ix->d_aux_qbuf, hb.data(), hb.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ix->ctx->d_aux_qbuf, hb.data(), hb.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
   ScanArgs a{};
   a.idx = ix->main.view;
-  a.qplanes = reinterpret_cast<const uint4 *>(ix->d_aux_qbuf);
-  a.qparams = reinterpret_cast<const QueryParams *>(ix->d_aux_qbuf + qb);
+  a.qplanes = reinterpret_cast<const uint4 *>(ix->ctx->d_aux_qbuf);
+  a.qparams = reinterpret_cast<const QueryParams *>(ix->ctx->d_aux_qbuf + qb);
   a.chunk_begin = 0;
   a.row_id_base = ix->main.row_id_base;
   a.flags = ix->d_aux_flags;
@@ -555,6 +610,18 @@ int drain(bbq_index *ix) {
   return BBQ_OK;
 }
 
+// frees what the index owns; the device context (streams, workspace) stays
+void destroy_unlocked(bbq_index *ix) {
+  if (!ix) return;
+  (void)hipSetDevice(ix->device);
+  if (ix->pilot.d_tiles) (void)hipFree(ix->pilot.d_tiles);
+  if (ix->main.d_tiles) (void)hipFree(ix->main.d_tiles);
+  if (ix->d_dense_all) (void)hipFree(ix->d_dense_all);
+  if (ix->d_shard_lists) (void)hipFree(ix->d_shard_lists);
+  if (ix->d_shard_counts) (void)hipFree(ix->d_shard_counts);
+  delete ix;
+}
+
 }  // namespace
 
 // ================================================================================================ C ABI
@@ -601,33 +668,32 @@ int bbq_index_create_shard(const uint8_t *codes, const double *corr, int64_t n_r
   ix->row_base = row_base;
   ix->centroid_dp = centroid_dp;
   ix->has_pilot = n_pilot > 0;
-  for (int i = 0; i < kMaxSlots; ++i) {
-    HIPCHK(hipStreamCreateWithFlags(&ix->slots[i].stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreate(&ix->slots[i].ev0));
-    HIPCHK(hipEventCreate(&ix->slots[i].ev1));
-    HIPCHK(hipEventCreateWithFlags(&ix->slots[i].ev_done, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ix->slots[i].ev_big, hipEventDisableTiming));
-  }
-  HIPCHK(hipStreamCreateWithFlags(&ix->aux_stream, hipStreamNonBlocking));
-  HIPCHK(hipMalloc((void **)&ix->d_aux_qbuf, (size_t)qbuf_bytes_per_query(ix.get())));
-  HIPCHK(hipMalloc((void **)&ix->d_aux_flags, 4));
-  HIPCHK(hipMemset(ix->d_aux_flags, 0, 4));
+  DeviceCtx *ctx = nullptr;
+  int rc0 = get_ctx(device, &ctx);
+  if (rc0 != BBQ_OK) return rc0;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ix->ctx = ctx;
+  ix->slots = ctx->slots;
+  ix->aux_stream = ctx->aux_stream;
+  ix->d_aux_flags = ctx->d_aux_flags;
+  rc0 = ensure_aux_qbuf(ctx, qbuf_bytes_per_query_w(ix->w16));
+  if (rc0 != BBQ_OK) return rc0;
   int rc;
   if (ix->has_pilot) {
     rc = make_storage(ix.get(), ix->pilot, pilot_codes, pilot_corr, n_pilot, 0, true);
-    if (rc != BBQ_OK) { bbq_index_destroy(ix.release()); return rc; }
+    if (rc != BBQ_OK) { destroy_unlocked(ix.release()); return rc; }
     const int had = ix->has_x1;
     rc = make_storage(ix.get(), ix->main, codes, corr, n_rows, row_base, true);
-    if (rc != BBQ_OK) { bbq_index_destroy(ix.release()); return rc; }
+    if (rc != BBQ_OK) { destroy_unlocked(ix.release()); return rc; }
     if (ix->has_x1 != had) {  // main needs explicit sums but pilot was built without: rebuild the pilot
       if (ix->pilot.d_tiles) (void)hipFree(ix->pilot.d_tiles);
       ix->pilot.d_tiles = nullptr;
       rc = make_storage(ix.get(), ix->pilot, pilot_codes, pilot_corr, n_pilot, 0, false);
-      if (rc != BBQ_OK) { bbq_index_destroy(ix.release()); return rc; }
+      if (rc != BBQ_OK) { destroy_unlocked(ix.release()); return rc; }
     }
   } else {
     rc = make_storage(ix.get(), ix->main, codes, corr, n_rows, row_base, true);
-    if (rc != BBQ_OK) { bbq_index_destroy(ix.release()); return rc; }
+    if (rc != BBQ_OK) { destroy_unlocked(ix.release()); return rc; }
   }
   *out = ix.release();
   return BBQ_OK;
@@ -640,26 +706,12 @@ int bbq_index_create(const uint8_t *codes, const double *corr, int64_t n_rows, i
 
 void bbq_index_destroy(bbq_index *ix) {
   if (!ix) return;
-  (void)hipSetDevice(ix->device);
-  for (int i = 0; i < kMaxSlots; ++i) {
-    Slot &s = ix->slots[i];
-    if (s.stream) (void)hipStreamSynchronize(s.stream);
-    free_slot_buffers(s);
-    if (s.ev0) (void)hipEventDestroy(s.ev0);
-    if (s.ev1) (void)hipEventDestroy(s.ev1);
-    if (s.ev_done) (void)hipEventDestroy(s.ev_done);
-    if (s.ev_big) (void)hipEventDestroy(s.ev_big);
-    if (s.stream) (void)hipStreamDestroy(s.stream);
+  if (ix->ctx) {
+    std::lock_guard<std::mutex> lk(ix->ctx->mu);
+    destroy_unlocked(ix);
+  } else {
+    destroy_unlocked(ix);
   }
-  if (ix->pilot.d_tiles) (void)hipFree(ix->pilot.d_tiles);
-  if (ix->main.d_tiles) (void)hipFree(ix->main.d_tiles);
-  if (ix->d_dense_all) (void)hipFree(ix->d_dense_all);
-  if (ix->d_shard_lists) (void)hipFree(ix->d_shard_lists);
-  if (ix->d_shard_counts) (void)hipFree(ix->d_shard_counts);
-  if (ix->d_aux_qbuf) (void)hipFree(ix->d_aux_qbuf);
-  if (ix->d_aux_flags) (void)hipFree(ix->d_aux_flags);
-  if (ix->aux_stream) (void)hipStreamDestroy(ix->aux_stream);
-  delete ix;
 }
 
 int64_t bbq_index_size(const bbq_index *ix) { return ix ? ix->n_rows : 0; }
@@ -677,6 +729,7 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
   if (!out_idx || !out_score) return fail(BBQ_ERR_INVALID_ARG, "output arrays are null");
   if (ix->has_pilot || ix->row_base != 0)
     return fail(BBQ_ERR_INVALID_ARG, "bbq_search on a non-root shard: use bbq_shard_scan + bbq_replay");
+  std::lock_guard<std::mutex> lk(ix->ctx->mu);
   HIPCHK(hipSetDevice(ix->device));
   ix->stats.candidates = 0;
   ix->stats.dense_fallbacks = 0;
@@ -737,14 +790,17 @@ int bbq_score_rows(bbq_index *ix, const uint8_t *qquant, const double *qcorr, in
   if (row_begin < 0 || row_count < 0 || row_begin + row_count > ix->n_rows)
     return fail(BBQ_ERR_INVALID_ARG, "向量索引 %lld 不存在", (long long)(row_begin + row_count - 1));
   if (row_count == 0) return BBQ_OK;
+  std::lock_guard<std::mutex> lk(ix->ctx->mu);
   HIPCHK(hipSetDevice(ix->device));
   BatchCtx c{ix, qquant, qcorr, planes_for(qquant, ix->dim), query_bits == 1 ? 1 : 0, sim, 0};
   if (c.one_bit) c.planes = 1;
+  rc = ensure_aux_qbuf(ix->ctx, qbuf_bytes_per_query_w(ix->w16));
+  if (rc != BBQ_OK) return rc;
   const int64_t qb = (int64_t)ix->w16 * c.planes * 16;
   std::vector<uint8_t> hb((size_t)qb + sizeof(QueryParams));
   fill_query(ix, hb.data(), reinterpret_cast<QueryParams *>(hb.data() + qb), qquant, qcorr, c.planes, c.one_bit, sim);
   hipStream_t st = ix->aux_stream;
-  HIPCHK(hipMemcpyAsync(ix->d_aux_qbuf, hb.data(), hb.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ix->ctx->d_aux_qbuf, hb.data(), hb.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
   const int64_t piece_chunks = 1024;  // 1M rows per piece
   const int64_t c_first = row_begin / kChunkRows, c_last = (row_begin + row_count + kChunkRows - 1) / kChunkRows;
@@ -763,8 +819,8 @@ int bbq_score_rows(bbq_index *ix, const uint8_t *qquant, const double *qcorr, in
     const int64_t nc = std::min(piece_chunks, c_last - cb);
     ScanArgs a{};
     a.idx = ix->main.view;
-    a.qplanes = reinterpret_cast<const uint4 *>(ix->d_aux_qbuf);
-    a.qparams = reinterpret_cast<const QueryParams *>(ix->d_aux_qbuf + qb);
+    a.qplanes = reinterpret_cast<const uint4 *>(ix->ctx->d_aux_qbuf);
+    a.qparams = reinterpret_cast<const QueryParams *>(ix->ctx->d_aux_qbuf + qb);
     a.chunk_begin = cb;
     a.row_id_base = ix->main.row_id_base;
     a.flags = ix->d_aux_flags;
@@ -811,6 +867,7 @@ int bbq_shard_scan(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, cons
   if (!dev_packed || !dev_offsets || !dev_flags || !out_total || packed_cap <= 0)
     return fail(BBQ_ERR_INVALID_ARG, "bbq_shard_scan: null output buffers");
   if (k == 0 || k > kMaxFastK) return fail(BBQ_ERR_UNSUPPORTED, "bbq_shard_scan: k must be in 1..%lld", (long long)kMaxFastK);
+  std::lock_guard<std::mutex> lk(ix->ctx->mu);
   HIPCHK(hipSetDevice(ix->device));
   BatchCtx c{ix, qquant, qcorr, planes_for(qquant, (int64_t)n_queries * ix->dim), query_bits == 1 ? 1 : 0, sim, k};
   if (c.one_bit) c.planes = 1;
@@ -881,12 +938,7 @@ int bbq_set_option(bbq_index *ix, const char *name, int64_t v) {
   else if (n == "replay_threads" && v >= 1 && v <= 256) ix->opt_replay_threads = (int)v;
   else if (n == "force_dense" && (v == 0 || v == 1)) ix->opt_force_dense = (int)v;
   else return fail(BBQ_ERR_INVALID_ARG, "bbq_set_option: unknown option or value out of range: %s=%lld", name, (long long)v);
-  // buffers are sized per plan/batch: drop them so the next call reallocates
-  (void)hipSetDevice(ix->device);
-  for (int i = 0; i < kMaxSlots; ++i) {
-    if (ix->slots[i].stream) (void)hipStreamSynchronize(ix->slots[i].stream);
-    free_slot_buffers(ix->slots[i]);
-  }
+  ix->plan.k = -1;  // workspace is grow-only and re-checked by ensure_slot on the next call
   return BBQ_OK;
 }
 
