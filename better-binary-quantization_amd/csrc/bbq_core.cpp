@@ -12,6 +12,7 @@
 // sub-batches are pipelined over NSLOT streams so the host replay of one overlaps the scan of the next.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <memory>
@@ -36,6 +37,7 @@ constexpr int64_t kMaxFastK = 2048;  // beyond this the dense path is used (fina
 
 struct Storage {
   uint8_t *d_tiles = nullptr;
+  double *d_exact = nullptr;  // kLayoutCompact: exact corrections, gathered for the rows whose bound passes
   IndexView view{};
   int64_t row_id_base = 0;
   int64_t n_chunks() const { return (view.n_rows + kChunkRows - 1) / kChunkRows; }
@@ -98,7 +100,7 @@ struct bbq_index {
   int device = 0;
   DeviceCtx *ctx = nullptr;
   Slot *slots = nullptr;  // = ctx->slots
-  int32_t dim = 0, pb = 0, w16 = 0, tile_stride = 0, has_x1 = 0, bytes_per_row = 0;
+  int32_t dim = 0, pb = 0, w16 = 0, tile_stride = 0, has_x1 = 0, bytes_per_row = 0, layout = 0, want_compact = 1;
   int64_t n_rows = 0, row_base = 0;
   double centroid_dp = 0;
   bool has_pilot = false;
@@ -114,7 +116,7 @@ struct bbq_index {
   int32_t *d_shard_counts = nullptr;
   int64_t shard_q_cap = 0, shard_list_cap = 0;
   // options
-  int opt_batch = 32, opt_slots = 2, opt_growth = 8, opt_tpw = 1, opt_replay_threads = 1, opt_force_dense = 0;
+  int opt_batch = 32, opt_slots = 2, opt_growth = 8, opt_replay_threads = 1, opt_force_dense = 0;
   int64_t opt_s0 = 4096;
   bbq_stats stats{};
 };
@@ -187,7 +189,9 @@ int make_storage(bbq_index *ix, Storage &st, const uint8_t *codes, const double 
     HIPCHK(hipFree(d_mis));
     if (mis) ix->has_x1 = 1;
   }
-  ix->tile_stride = ix->w16 * 1024 + 1536 + (ix->has_x1 ? 512 : 0);
+  // compact corrections (8 B/row streamed + exact side array) need the implicit component sum; otherwise inline
+  ix->layout = (ix->want_compact && !ix->has_x1) ? kLayoutCompact : kLayoutInline;
+  ix->tile_stride = ix->w16 * 1024 + (ix->layout == kLayoutCompact ? 512 : 1536 + (ix->has_x1 ? 512 : 0));
   ix->bytes_per_row = ix->tile_stride / kTileRows;
   st.row_id_base = row_id_base;
   st.view.n_rows = n_rows;
@@ -195,11 +199,14 @@ int make_storage(bbq_index *ix, Storage &st, const uint8_t *codes, const double 
   st.view.tile_stride = ix->tile_stride;
   st.view.has_x1 = ix->has_x1;
   st.view.dim = ix->dim;
+  st.view.layout = ix->layout;
   if (n_tiles > 0) {
     HIPCHK(hipMalloc((void **)&st.d_tiles, (size_t)(n_tiles * ix->tile_stride)));
-    HIPCHK(launch_retile(d_codes, d_corr, n_rows, (int32_t)pb, st.d_tiles, ix->w16, ix->tile_stride, ix->has_x1, s));
+    if (ix->layout == kLayoutCompact) HIPCHK(hipMalloc((void **)&st.d_exact, (size_t)(n_tiles * kTileRows) * 32));
+    HIPCHK(launch_retile(d_codes, d_corr, n_rows, (int32_t)pb, st.d_tiles, ix->w16, ix->tile_stride, ix->has_x1, ix->layout, st.d_exact, s));
     HIPCHK(hipStreamSynchronize(s));
   }
+  st.view.exact = st.d_exact;
   st.view.tiles = st.d_tiles;
   if (d_codes) HIPCHK(hipFree(d_codes));
   if (d_corr) HIPCHK(hipFree(d_corr));
@@ -446,7 +453,7 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
     if (g.big && ix->ctx->last_big_slot >= 0 && ix->ctx->last_big_slot != my_slot)
       HIPCHK(hipStreamWaitEvent(st, ix->slots[ix->ctx->last_big_slot].ev_big, 0));  // one big sweep at a time on the device
     if (g.dominant) HIPCHK(hipEventRecord(s.ev0, st));
-    HIPCHK(launch_scan(a, c.planes, g.dense, nq, (int)g.n_chunks, ix->opt_tpw, st));
+    HIPCHK(launch_scan(a, c.planes, g.dense, nq, (int)g.n_chunks, st));
     if (g.big) {
       HIPCHK(hipEventRecord(s.ev_big, st));
       ix->ctx->last_big_slot = my_slot;
@@ -533,7 +540,7 @@ int dense_search_one(const BatchCtx &c, int64_t qi, int32_t *out_idx, float *out
   a.dense_score32 = ix->d_dense_all;
   a.dense_stride = n;
   // gridDim.x is limited to 2^31-1: fine for any index that fits in HBM
-  HIPCHK(launch_scan(a, c.planes, true, 1, (int)chunks, ix->opt_tpw, st));
+  HIPCHK(launch_scan(a, c.planes, true, 1, (int)chunks, st));
   std::vector<float> h((size_t)std::max<int64_t>(n, 1));
   HIPCHK(hipMemcpyAsync(h.data(), ix->d_dense_all, (size_t)n * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -616,6 +623,8 @@ void destroy_unlocked(bbq_index *ix) {
   (void)hipSetDevice(ix->device);
   if (ix->pilot.d_tiles) (void)hipFree(ix->pilot.d_tiles);
   if (ix->main.d_tiles) (void)hipFree(ix->main.d_tiles);
+  if (ix->pilot.d_exact) (void)hipFree(ix->pilot.d_exact);
+  if (ix->main.d_exact) (void)hipFree(ix->main.d_exact);
   if (ix->d_dense_all) (void)hipFree(ix->d_dense_all);
   if (ix->d_shard_lists) (void)hipFree(ix->d_shard_lists);
   if (ix->d_shard_counts) (void)hipFree(ix->d_shard_counts);
@@ -668,6 +677,10 @@ int bbq_index_create_shard(const uint8_t *codes, const double *corr, int64_t n_r
   ix->row_base = row_base;
   ix->centroid_dp = centroid_dp;
   ix->has_pilot = n_pilot > 0;
+  {
+    const char *e = getenv("BBQ_COMPACT_CORRECTIONS");  // 0: stream the exact f64 corrections (120 B/row at 768-d) instead
+    ix->want_compact = (e && e[0] == '0') ? 0 : 1;
+  }
   DeviceCtx *ctx = nullptr;
   int rc0 = get_ctx(device, &ctx);
   if (rc0 != BBQ_OK) return rc0;
@@ -687,7 +700,9 @@ int bbq_index_create_shard(const uint8_t *codes, const double *corr, int64_t n_r
     if (rc != BBQ_OK) { destroy_unlocked(ix.release()); return rc; }
     if (ix->has_x1 != had) {  // main needs explicit sums but pilot was built without: rebuild the pilot
       if (ix->pilot.d_tiles) (void)hipFree(ix->pilot.d_tiles);
+      if (ix->pilot.d_exact) (void)hipFree(ix->pilot.d_exact);
       ix->pilot.d_tiles = nullptr;
+      ix->pilot.d_exact = nullptr;
       rc = make_storage(ix.get(), ix->pilot, pilot_codes, pilot_corr, n_pilot, 0, false);
       if (rc != BBQ_OK) { destroy_unlocked(ix.release()); return rc; }
     }
@@ -828,7 +843,7 @@ int bbq_score_rows(bbq_index *ix, const uint8_t *qquant, const double *qcorr, in
     a.dense_qcdist = dqc;
     a.dense_score64 = d64;
     a.dense_stride = piece_rows;
-    hipError_t e = launch_scan(a, c.planes, true, 1, (int)nc, ix->opt_tpw, st);
+    hipError_t e = launch_scan(a, c.planes, true, 1, (int)nc, st);
     const int64_t r0 = cb * kChunkRows, r1 = std::min((cb + nc) * kChunkRows, ix->main.view.n_rows);
     if (e == hipSuccess) e = hipMemcpyAsync(h32.data(), d32, (size_t)(r1 - r0) * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(hqc.data(), dqc, (size_t)(r1 - r0) * 4, hipMemcpyDeviceToHost, st);
@@ -934,7 +949,6 @@ int bbq_set_option(bbq_index *ix, const char *name, int64_t v) {
   else if (n == "pipeline_slots" && v >= 1 && v <= kMaxSlots) ix->opt_slots = (int)v;
   else if (n == "segment_growth" && v >= 2 && v <= 1024) { ix->opt_growth = (int)v; ix->plan.k = -1; }
   else if (n == "first_segment_rows" && v >= 1024 && v <= 8192 && v % kChunkRows == 0) { ix->opt_s0 = v; ix->plan.k = -1; }
-  else if (n == "tiles_per_wave" && (v == 1 || v == 2 || v == 4)) ix->opt_tpw = (int)v;
   else if (n == "replay_threads" && v >= 1 && v <= 256) ix->opt_replay_threads = (int)v;
   else if (n == "force_dense" && (v == 0 || v == 1)) ix->opt_force_dense = (int)v;
   else return fail(BBQ_ERR_INVALID_ARG, "bbq_set_option: unknown option or value out of range: %s=%lld", name, (long long)v);

@@ -12,16 +12,26 @@ constexpr uint32_t kFlagNaN = 2u;        // a NaN score was produced: order stat
 
 // Device layout of one index storage (DESIGN.md "HBM layout").  A tile record holds 64 rows:
 //   [w16][64] uint4    16-byte code chunk j of row r at (j*64 + r)*16      -> 1 KiB coalesced per wave load
+// followed by the corrections, in one of two layouts:
+//  kLayoutInline (exact corrections streamed with the codes, 24 or 32 B/row)
 //   [64] double2       {lowerInterval, upperInterval}                      -> 1 KiB
 //   [64] double        additionalCorrection                                -> 512 B
 //   [64] double        quantizedComponentSum (only if has_x1)              -> 512 B
+//  kLayoutCompact (8 B/row streamed; exact corrections in a side array, gathered only for rows whose score BOUND
+//  passes the threshold)
+//   [64] uint2         {bf16(lower) | bf16(upper) << 16 (f32 bits truncated), f32 bits of additionalCorrection}
+//   side array exact[row] = {lower, upper, additional, 0} as 4 doubles (32 B/row)
+constexpr int kLayoutInline = 0;
+constexpr int kLayoutCompact = 1;
 struct IndexView {
   const uint8_t *tiles;
+  const double *exact;  // kLayoutCompact: [n_rows padded to 64][4]
   int64_t n_rows;       // valid rows in this storage
   int32_t w16;          // 16-byte chunks per row = ceil(ceil(dim/8)/16)
   int32_t tile_stride;  // bytes per tile record
   int32_t has_x1;       // 0: quantizedComponentSum == popcount(row), recomputed on the fly
   int32_t dim;
+  int32_t layout;
 };
 
 // Per-query uniforms of the score formula (src/batchDotProduct.ts:478-617)

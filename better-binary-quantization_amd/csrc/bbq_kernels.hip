@@ -82,11 +82,61 @@ __device__ __forceinline__ void tile_popcounts(const uint8_t *__restrict__ tp, i
   }
 }
 
-// grid = (chunks, queries); block = 16 waves / TPW; wave w handles tiles [w*TPW, (w+1)*TPW) of its chunk
-template <int QB, int W, bool DENSE, int TPW>
-__global__ __launch_bounds__(1024 / TPW) void bbq_scan_kernel(const ScanArgs a) {
+// Upper bound of the score when only the COMPACT corrections are known (kLayoutCompact).
+// The raw score s is linear in (lower, upper): with x1 and qcDist fixed,
+//     s(lower, upper) = lower * A + upper * B,   A = ay*(dim - x1) + ly*(y1 - qc),   B = ay*x1 + ly*qc,
+// so replacing (lower, upper, add) by their compact values (al, au, aadd) changes s by exactly
+// (lower-al)*A + (upper-au)*B and the additive term by (add-aadd).  |lower-al| <= |al|*kBf16Rel + kAbsSlack
+// (f32 rounding + truncation to the upper 16 bits), |add-aadd| <= |aadd|*2^-23 + kAbsSlack.  All three similarity
+// transforms are monotone in s (resp. in t), and a generous rounding allowance (kRoundRel, ~7 orders of magnitude
+// above the real f64 round-off of these ~20 operations) covers the difference between exact-arithmetic reasoning and
+// IEEE evaluation.  Returns a value U with  exact f64 score <= U  (NaN or +inf when no finite bound can be given:
+// the caller then takes the exact path).  tests/test_bound_math_cpu.py restates this in numpy and checks dominance.
+constexpr double kBf16Rel = 0.0078125 * (1.0 + 1.0 / 65536.0);  // 2^-7 (1 + 2^-16)
+constexpr double kF32Rel = 1.1920928955078125e-07;             // 2^-23
+constexpr double kAbsSlack = 1e-37;
+constexpr double kRoundRel = 1e-9;
+
+__device__ __forceinline__ double score_upper_bound(double qc, double al, double au, double aadd, double x1, const QueryParams &p) {
+  const double lx = au - al;
+  const double t1 = (al * p.ay) * p.dimd;
+  const double t2 = (p.ay * lx) * x1;
+  const double t3 = (al * p.ly) * p.y1;
+  const double t4 = (lx * p.ly) * qc;
+  const double s = ((t1 + t2) + t3) + t4;
+  const double A = p.ay * (p.dimd - x1) + p.ly * (p.y1 - qc);
+  const double B = p.ay * x1 + p.ly * qc;
+  const double mag = fabs(t1) + fabs(t2) + fabs(t3) + fabs(t4) + fabs(p.qadd) + fabs(aadd) + fabs(p.cdp) + 1.0;
+  if (!(mag < 1e290)) return __longlong_as_double(0x7ff8000000000000ll);  // non-finite / huge: no bound
+  const double es = fabs(A) * (fabs(al) * kBf16Rel + kAbsSlack) + fabs(B) * (fabs(au) * kBf16Rel + kAbsSlack);
+  const double eadd = fabs(aadd) * kF32Rel + kAbsSlack;
+  const double slop = kRoundRel * (mag + fabs(A) + fabs(B));
+  if (p.sim == 0) {  // EUCLIDEAN: score = max(1/(1+e), 0), decreasing in e while 1+e > 0
+    const double e_low = ((p.qadd + aadd) - (2.0 * s)) - (2.0 * es + eadd + slop);
+    const double den = 1.0 + e_low;
+    if (!(den > 0.0)) return __longlong_as_double(0x7ff0000000000000ll);  // +inf: cannot exclude a tiny positive denominator
+    const double u = 1.0 / den;
+    return u + kRoundRel * (u + 1.0);
+  }
+  const double t_up = (((s + p.qadd) + aadd) - p.cdp) + (es + eadd + slop);
+  double u;
+  if (p.sim == 1) u = js_max0((1.0 + t_up) / 2.0);
+  else if (p.one_bit) u = t_up < 0.0 ? 1.0 / (1.0 - t_up) : t_up + 1.0;
+  else {
+    const double FBS = 1.0 / 15.0;
+    u = t_up < 0.0 ? 1.0 / (1.0 - t_up / FBS) : t_up / FBS + 1.0;
+  }
+  return u + kRoundRel * (fabs(u) + 1.0);
+}
+
+// MODE: 0 sparse / inline corrections, 1 dense / inline, 2 sparse / compact corrections + exact gather, 3 dense / compact
+// grid = (chunks of 1024 rows, queries); block = 16 waves: wave w handles tile w of its chunk (one row per lane)
+template <int QB, int W, int MODE>
+__global__ __launch_bounds__(1024) void bbq_scan_kernel(const ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NT = 1024 / TPW;
+  constexpr int NT = 1024;
+  constexpr bool DENSE = (MODE & 1) != 0;
+  constexpr bool COMPACT = (MODE & 2) != 0;
   const int w16 = W > 0 ? W : a.idx.w16;
   u32x4 *s_planes = reinterpret_cast<u32x4 *>(smem);
   uint64_t *s_ent = reinterpret_cast<uint64_t *>(smem + (size_t)w16 * QB * 16);
@@ -108,31 +158,60 @@ __global__ __launch_bounds__(1024 / TPW) void bbq_scan_kernel(const ScanArgs a) 
 
   const int64_t chunk = a.chunk_begin + blockIdx.x;
   const int64_t n_tiles = (a.idx.n_rows + kTileRows - 1) / kTileRows;
+  const int64_t tile = chunk * kTilesPerChunk + wave;
   bool nan_seen = false;
 
-#pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    const int64_t tile = chunk * kTilesPerChunk + wave * TPW + t;
-    if (tile < n_tiles) {  // wave-uniform
-      const uint8_t *__restrict__ tp = a.idx.tiles + tile * (int64_t)a.idx.tile_stride;
-      const uint8_t *__restrict__ cr = tp + (size_t)w16 * (kTileRows * 16);
-      const f64x2 lu = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(cr) + lane);
-      const double xadd = __builtin_nontemporal_load(reinterpret_cast<const double *>(cr + 1024) + lane);
-      double x1 = 0.0;
+  if (tile < n_tiles) {  // wave-uniform
+    const uint8_t *__restrict__ tp = a.idx.tiles + tile * (int64_t)a.idx.tile_stride;
+    const uint8_t *__restrict__ cr = tp + (size_t)w16 * (kTileRows * 16);
+    const int64_t row = tile * kTileRows + lane;
+    const bool valid = row < a.idx.n_rows;
+
+    // corrections: issue their loads before the popcount loop so they are in flight with the code loads
+    f64x2 lu = {0.0, 0.0};
+    double xadd = 0.0, x1 = 0.0;
+    uint32_t cpk0 = 0, cpk1 = 0;
+    if constexpr (!COMPACT) {
+      lu = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(cr) + lane);
+      xadd = __builtin_nontemporal_load(reinterpret_cast<const double *>(cr + 1024) + lane);
       if (a.idx.has_x1) x1 = __builtin_nontemporal_load(reinterpret_cast<const double *>(cr + 1536) + lane);
+    } else if constexpr (DENSE) {
+      const f64x2 *__restrict__ ex = reinterpret_cast<const f64x2 *>(a.idx.exact + row * 4);
+      lu = __builtin_nontemporal_load(ex);
+      xadd = __builtin_nontemporal_load(reinterpret_cast<const double *>(ex + 1));
+    } else {
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(cr) + lane);
+      cpk0 = c.x;
+      cpk1 = c.y;
+    }
 
-      uint32_t acc[QB], ones;
-      tile_popcounts<QB, W>(tp, lane, w16, s_planes, acc, ones);
-      uint32_t qc = 0;
+    uint32_t acc[QB], ones;
+    tile_popcounts<QB, W>(tp, lane, w16, s_planes, acc, ones);
+    uint32_t qc = 0;
 #pragma unroll
-      for (int pl = 0; pl < QB; ++pl) qc += acc[pl] << pl;
-      if (!a.idx.has_x1) x1 = (double)ones;  // quantizedComponentSum of a 1-bit row is its popcount
+    for (int pl = 0; pl < QB; ++pl) qc += acc[pl] << pl;
+    if (!a.idx.has_x1) x1 = (double)ones;  // quantizedComponentSum of a 1-bit row is its popcount
 
+    bool need_exact = true;
+    if constexpr (COMPACT && !DENSE) {
+      const double al = (double)__uint_as_float(cpk0 << 16);
+      const double au = (double)__uint_as_float(cpk0 & 0xffff0000u);
+      const double aadd = (double)__uint_as_float(cpk1);
+      const double ub = score_upper_bound((double)qc, al, au, aadd, x1, p);
+      const float ub32 = (float)ub;
+      // NaN (no bound) passes; otherwise the row can only matter if even its upper bound beats the threshold
+      need_exact = valid && ((ub32 != ub32) || key_of_bits(__float_as_uint(ub32)) > theta);
+      if (need_exact) {
+        const f64x2 *__restrict__ ex = reinterpret_cast<const f64x2 *>(a.idx.exact + row * 4);
+        lu = ex[0];
+        xadd = reinterpret_cast<const double *>(ex + 1)[0];
+      }
+    }
+    if (need_exact) {
       const double s64 = score_f64((double)qc, lu.x, lu.y, xadd, x1, p);
       const float s32 = (float)s64;  // Float32Array store, src/binaryQuantizationFormat.ts:353,378
       const uint32_t bits = __float_as_uint(s32);
-      const int64_t row = tile * kTileRows + lane;
-      const bool valid = row < a.idx.n_rows;
       if (valid && (s32 != s32)) nan_seen = true;
       if constexpr (DENSE) {
         if (valid) {
@@ -314,9 +393,12 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
 // ---------------------------------------------------------------------------------------------------
 // index build: row-major (codes [n][pb], corr [n][4]) -> tile records.  One thread per (row, chunk).
 
+__device__ __forceinline__ uint32_t bf16_trunc_bits(double v) { return __float_as_uint((float)v) >> 16; }
+
 __global__ __launch_bounds__(256) void bbq_retile_kernel(const uint8_t *__restrict__ codes, const double *__restrict__ corr,
                                                         int64_t n_rows, int32_t pb, uint8_t *__restrict__ tiles, int32_t w16,
-                                                        int32_t tile_stride, int32_t has_x1, int64_t n_rows_padded) {
+                                                        int32_t tile_stride, int32_t has_x1, int64_t n_rows_padded, int32_t layout,
+                                                        double *__restrict__ exact) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t row = gid / (w16 + 1);
   const int j = (int)(gid % (w16 + 1));
@@ -343,9 +425,19 @@ __global__ __launch_bounds__(256) void bbq_retile_kernel(const uint8_t *__restri
     if (row < n_rows) {
       lu.x = corr[row * 4 + 0]; lu.y = corr[row * 4 + 1]; add = corr[row * 4 + 2]; x1 = corr[row * 4 + 3];
     }
-    reinterpret_cast<f64x2 *>(cr)[r] = lu;
-    reinterpret_cast<double *>(cr + 1024)[r] = add;
-    if (has_x1) reinterpret_cast<double *>(cr + 1536)[r] = x1;
+    if (layout == kLayoutCompact) {
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      u32x2 c;
+      c.x = bf16_trunc_bits(lu.x) | (bf16_trunc_bits(lu.y) << 16);
+      c.y = __float_as_uint((float)add);
+      reinterpret_cast<u32x2 *>(cr)[r] = c;
+      double *e = exact + row * 4;
+      e[0] = lu.x; e[1] = lu.y; e[2] = add; e[3] = 0.0;
+    } else {
+      reinterpret_cast<f64x2 *>(cr)[r] = lu;
+      reinterpret_cast<double *>(cr + 1024)[r] = add;
+      if (has_x1) reinterpret_cast<double *>(cr + 1536)[r] = x1;
+    }
   }
 }
 
@@ -402,51 +494,44 @@ __global__ __launch_bounds__(256) void bbq_pack_copy_kernel(const uint64_t *__re
 // ---------------------------------------------------------------------------------------------------
 // launch wrappers (declared in bbq_launch.h)
 
-template <int QB, int W, bool DENSE, int TPW>
+template <int QB, int W, int MODE>
 static hipError_t launch_scan_t(const ScanArgs &a, int n_queries, int n_chunks, hipStream_t s) {
   const int w16 = W > 0 ? W : a.idx.w16;
-  const size_t smem = (size_t)w16 * QB * 16 + (DENSE ? 0 : (size_t)a.cap * 8) + 16;
-  dim3 grid((unsigned)n_chunks, (unsigned)n_queries, 1), block(1024 / TPW, 1, 1);
-  hipLaunchKernelGGL((bbq_scan_kernel<QB, W, DENSE, TPW>), grid, block, smem, s, a);
+  const size_t smem = (size_t)w16 * QB * 16 + ((MODE & 1) ? 0 : (size_t)a.cap * 8) + 16;
+  dim3 grid((unsigned)n_chunks, (unsigned)n_queries, 1), block(1024, 1, 1);
+  hipLaunchKernelGGL((bbq_scan_kernel<QB, W, MODE>), grid, block, smem, s, a);
   return hipGetLastError();
 }
 
-template <int QB, int W, bool DENSE>
-static hipError_t launch_scan_tpw(const ScanArgs &a, int nq, int nc, int tpw, hipStream_t s) {
-  switch (tpw) {
-    case 2: return launch_scan_t<QB, W, DENSE, 2>(a, nq, nc, s);
-    case 4: return launch_scan_t<QB, W, DENSE, 4>(a, nq, nc, s);
-    default: return launch_scan_t<QB, W, DENSE, 1>(a, nq, nc, s);
-  }
-}
-
-template <int QB, bool DENSE>
-static hipError_t launch_scan_w(const ScanArgs &a, int nq, int nc, int tpw, hipStream_t s) {
+template <int QB, int MODE>
+static hipError_t launch_scan_w(const ScanArgs &a, int nq, int nc, hipStream_t s) {
   switch (a.idx.w16) {
-    case 1: return launch_scan_tpw<QB, 1, DENSE>(a, nq, nc, tpw, s);    // dim <= 128
-    case 6: return launch_scan_tpw<QB, 6, DENSE>(a, nq, nc, tpw, s);    // dim 768
-    case 8: return launch_scan_tpw<QB, 8, DENSE>(a, nq, nc, tpw, s);    // dim 1024
-    case 12: return launch_scan_tpw<QB, 12, DENSE>(a, nq, nc, tpw, s);  // dim 1536
-    default: return launch_scan_tpw<QB, 0, DENSE>(a, nq, nc, tpw, s);
+    case 1: return launch_scan_t<QB, 1, MODE>(a, nq, nc, s);    // dim <= 128
+    case 6: return launch_scan_t<QB, 6, MODE>(a, nq, nc, s);    // dim 768
+    case 8: return launch_scan_t<QB, 8, MODE>(a, nq, nc, s);    // dim 1024
+    case 12: return launch_scan_t<QB, 12, MODE>(a, nq, nc, s);  // dim 1536
+    default: return launch_scan_t<QB, 0, MODE>(a, nq, nc, s);
   }
 }
 
-hipError_t launch_scan(const ScanArgs &a, int planes, bool dense, int n_queries, int n_chunks, int tiles_per_wave,
-                       hipStream_t s) {
-  if (n_chunks <= 0 || n_queries <= 0) return hipSuccess;
-  if (dense) {
-    switch (planes) {
-      case 1: return launch_scan_w<1, true>(a, n_queries, n_chunks, tiles_per_wave, s);
-      case 2: return launch_scan_w<2, true>(a, n_queries, n_chunks, tiles_per_wave, s);
-      case 4: return launch_scan_w<4, true>(a, n_queries, n_chunks, tiles_per_wave, s);
-      default: return launch_scan_w<8, true>(a, n_queries, n_chunks, tiles_per_wave, s);
-    }
-  }
+template <int MODE>
+static hipError_t launch_scan_q(const ScanArgs &a, int planes, int nq, int nc, hipStream_t s) {
   switch (planes) {
-    case 1: return launch_scan_w<1, false>(a, n_queries, n_chunks, tiles_per_wave, s);
-    case 2: return launch_scan_w<2, false>(a, n_queries, n_chunks, tiles_per_wave, s);
-    case 4: return launch_scan_w<4, false>(a, n_queries, n_chunks, tiles_per_wave, s);
-    default: return launch_scan_w<8, false>(a, n_queries, n_chunks, tiles_per_wave, s);
+    case 1: return launch_scan_w<1, MODE>(a, nq, nc, s);
+    case 2: return launch_scan_w<2, MODE>(a, nq, nc, s);
+    case 4: return launch_scan_w<4, MODE>(a, nq, nc, s);
+    default: return launch_scan_w<8, MODE>(a, nq, nc, s);
+  }
+}
+
+hipError_t launch_scan(const ScanArgs &a, int planes, bool dense, int n_queries, int n_chunks, hipStream_t s) {
+  if (n_chunks <= 0 || n_queries <= 0) return hipSuccess;
+  const int mode = (dense ? 1 : 0) | (a.idx.layout == kLayoutCompact ? 2 : 0);
+  switch (mode) {
+    case 0: return launch_scan_q<0>(a, planes, n_queries, n_chunks, s);
+    case 1: return launch_scan_q<1>(a, planes, n_queries, n_chunks, s);
+    case 2: return launch_scan_q<2>(a, planes, n_queries, n_chunks, s);
+    default: return launch_scan_q<3>(a, planes, n_queries, n_chunks, s);
   }
 }
 
@@ -464,13 +549,13 @@ hipError_t launch_pack(const int32_t *counts, const uint64_t *lists, int64_t lis
 }
 
 hipError_t launch_retile(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t pb, uint8_t *tiles, int32_t w16,
-                         int32_t tile_stride, int32_t has_x1, hipStream_t s) {
+                         int32_t tile_stride, int32_t has_x1, int32_t layout, double *exact, hipStream_t s) {
   const int64_t n_pad = (n_rows + kTileRows - 1) / kTileRows * kTileRows;
   const int64_t threads = n_pad * (w16 + 1);
   if (threads == 0) return hipSuccess;
   const int64_t blocks = (threads + 255) / 256;
   hipLaunchKernelGGL(bbq_retile_kernel, dim3((unsigned)blocks), dim3(256), 0, s, codes, corr, n_rows, pb, tiles, w16, tile_stride,
-                     has_x1, n_pad);
+                     has_x1, n_pad, layout, exact);
   return hipGetLastError();
 }
 

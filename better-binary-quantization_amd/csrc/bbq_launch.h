@@ -5,14 +5,13 @@
 
 namespace bbq {
 
-// planes: number of query bit-planes (1, 2, 4 or 8); tiles_per_wave: 1, 2 or 4
-hipError_t launch_scan(const ScanArgs &a, int planes, bool dense, int n_queries, int n_chunks, int tiles_per_wave,
-                       hipStream_t s);
+// planes: number of query bit-planes (1, 2, 4 or 8)
+hipError_t launch_scan(const ScanArgs &a, int planes, bool dense, int n_queries, int n_chunks, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, int n_queries, hipStream_t s);
 hipError_t launch_pack(const int32_t *counts, const uint64_t *lists, int64_t list_cap, int32_t nq, int64_t *offsets, int32_t *flags_out,
                        int64_t *total_out, uint64_t *packed, int64_t packed_cap, hipStream_t s);
 hipError_t launch_retile(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t pb, uint8_t *tiles, int32_t w16,
-                         int32_t tile_stride, int32_t has_x1, hipStream_t s);
+                         int32_t tile_stride, int32_t has_x1, int32_t layout, double *exact, hipStream_t s);
 hipError_t launch_check_x1(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t pb, uint32_t *mismatch,
                            hipStream_t s);
 

@@ -39,10 +39,26 @@ def _index_from_case(g):
     return sim, base, queries, codes, corr, cen, cdp
 
 
-def _check(name, options=None):
+def _make_index(codes, corr, dim, cdp, compact=True, **kw):
+    """compact=False streams the exact f64 corrections (inline layout); True (default) the 8-byte compact ones"""
+    import os
+    old = os.environ.get("BBQ_COMPACT_CORRECTIONS")
+    os.environ["BBQ_COMPACT_CORRECTIONS"] = "1" if compact else "0"
+    try:
+        return B.Index(codes, corr, dim, cdp, **kw)
+    finally:
+        if old is None:
+            del os.environ["BBQ_COMPACT_CORRECTIONS"]
+        else:
+            os.environ["BBQ_COMPACT_CORRECTIONS"] = old
+
+
+def _check(name, options=None, compact=True):
     g = O.load_golden(name)
     sim, base, queries, codes, corr, cen, cdp = _index_from_case(g)
-    ix = B.Index(codes, corr, g["dim"], cdp)
+    ix = _make_index(codes, corr, g["dim"], cdp, compact)
+    pb16 = (g["row_bytes"] + 15) // 16 * 16
+    assert ix.bytes_per_row == pb16 + (8 if compact else 24)
     for k_, v_ in (options or {}).items():
         ix.set_option(k_, v_)
     try:
@@ -71,26 +87,26 @@ def test_golden_full(name):
     _check(name)
 
 
+@pytest.mark.parametrize("name", FULL + HASHED)
+def test_golden_inline_exact_corrections_layout(name):
+    _check(name, compact=False)
+
+
 @pytest.mark.parametrize("name", HASHED)
 def test_golden_ties_and_big(name):
     _check(name)
 
 
-@pytest.mark.parametrize("name", ["ties_cos_qb4", "ties_16d_qb1", "big_20000x128_cos", "ties_max_qb4"])
-def test_golden_many_small_segments(name):
+@pytest.mark.parametrize("compact", [True, False])
+@pytest.mark.parametrize("name", ["ties_cos_qb4", "ties_16d_qb1", "big_20000x128_cos", "ties_max_qb4", "ties_euc_qb4", "ties_cos_qb1"])
+def test_golden_many_small_segments(name, compact):
     """force the multi-segment sparse path on small indexes: 1024-row first segment, x2 growth"""
-    _check(name, {"first_segment_rows": 1024, "segment_growth": 2})
+    _check(name, {"first_segment_rows": 1024, "segment_growth": 2}, compact=compact)
 
 
 @pytest.mark.parametrize("name", ["ties_euc_qb4", "c1_1000x128_cos_qb4", "big_20000x128_cos"])
 def test_golden_dense_path(name):
     _check(name, {"force_dense": 1})
-
-
-@pytest.mark.parametrize("tpw", [2, 4])
-def test_golden_tiles_per_wave(tpw):
-    _check("big_20000x128_cos", {"tiles_per_wave": tpw})
-    _check("m_768d_cos_qb4", {"tiles_per_wave": tpw})
 
 
 def _oracle_topk(codes, corr, dim, qq, qc, qb, sim, cdp, k):
@@ -227,3 +243,85 @@ def test_python_api_mirror_quicksearch_c1():
     res = B.quickSearch(queries[0], list(base), 10)
     assert [r["index"] for r in res] == [438, 839, 190, 656, 637, 545, 630, 174, 862, 42]
     assert res[0]["score"] == 0.6655263304710388
+
+
+@pytest.mark.parametrize("sim", [0, 1, 2])
+@pytest.mark.parametrize("qb", [1, 4, 8])
+def test_bound_filter_never_drops_a_candidate(sim, qb):
+    """compact corrections: the score upper bound must never reject a row the exact score would admit.
+    Hostile magnitudes (huge / tiny / zero / negative corrections), many sparse segments, both layouts must agree with
+    the oracle bit for bit."""
+    rng = np.random.default_rng(100 + 10 * sim + qb)
+    n, dim, k = 40000, 96, 64
+    codes = rng.integers(0, 256, size=(n, dim // 8), dtype=np.uint8)
+    pop = np.unpackbits(codes, axis=1).sum(axis=1).astype(np.float64)
+    corr = np.zeros((n, 4))
+    scale = 10.0 ** rng.uniform(-6, 3, n)                        # six decades of magnitude, row by row
+    corr[:, 0] = -scale * rng.uniform(0.1, 1.0, n)
+    corr[:, 1] = scale * rng.uniform(0.1, 1.0, n)
+    corr[:, 2] = rng.standard_normal(n) * 10.0 ** rng.uniform(-8, 2, n)
+    if sim == 0:
+        corr[:, 2] = np.abs(corr[:, 2])                          # EUCLIDEAN additional correction is a norm
+    corr[::97, 0] = 0.0
+    corr[::89, 1] = 0.0
+    corr[::83, 2] = 0.0
+    corr[:, 3] = pop
+    qq = rng.integers(0, 1 << qb, dim).astype(np.uint8)
+    qc = np.array([-0.7, 0.9, 0.01 if sim else 1.3, float(qq.sum())])
+    cdp = 0.02
+    od, os64, os32 = O.score_all(codes, corr, dim, qq, qc, qb, sim, cdp)
+    assert not np.isnan(os32).any()
+    for compact in (True, False):
+        ix = _make_index(codes, corr, dim, cdp, compact)
+        try:
+            ix.set_option("first_segment_rows", 1024)
+            ix.set_option("segment_growth", 2)
+            for kk in (1, k, 700):
+                idx, sc = ix.search(qq, qc, qb, sim, kk)
+                oi, osc = O.heap_topk(os32, kk)
+                np.testing.assert_array_equal(idx, oi)
+                np.testing.assert_array_equal(sc.view(np.uint32), osc.view(np.uint32))
+            assert ix.stats()["dense_fallbacks"] == 0
+            d, s64, s32 = ix.score_rows(qq, qc, qb, sim)
+            np.testing.assert_array_equal(s64.view(np.uint64), os64.view(np.uint64))
+        finally:
+            ix.close()
+
+
+def test_bound_filter_nonfinite_corrections_take_the_exact_path():
+    """inf / NaN / overflowing corrections cannot be bounded: such rows must reach the exact path (and a NaN score
+    must flag the dense fallback), never be silently dropped"""
+    g = O.load_golden("m_64d_cos_qb4")
+    sim, base, queries, codes, corr, cen, cdp = _index_from_case(g)
+    n = 30000
+    rng = np.random.default_rng(9)
+    pick = rng.integers(0, codes.shape[0], n)
+    codes, corr = codes[pick].copy(), corr[pick].copy()
+    corr[5000, 1] = 1e300          # overflows f32 -> no finite bound
+    corr[12345, 2] = 3.0e38        # f32-representable, huge
+    corr[20000, 0] = -1e-320       # f64 subnormal
+    qq, qc = B.quantize_query(queries[0], cen, sim, 4)
+    od, os64, os32 = O.score_all(codes, corr, g["dim"], qq, qc, 4, sim, cdp)
+    ix = _make_index(codes, corr, g["dim"], cdp, True)
+    try:
+        ix.set_option("first_segment_rows", 1024)
+        ix.set_option("segment_growth", 2)
+        idx, sc = ix.search(qq, qc, 4, sim, 20)
+        oi, osc = O.heap_topk(os32, 20)
+        np.testing.assert_array_equal(idx, oi)
+        np.testing.assert_array_equal(canon32(sc), canon32(osc))
+        assert 5000 in idx.tolist() or 12345 in idx.tolist()
+    finally:
+        ix.close()
+    corr[25000, 2] = np.nan         # NaN score deep inside a sparse segment
+    od, os64, os32 = O.score_all(codes, corr, g["dim"], qq, qc, 4, sim, cdp)
+    ix = _make_index(codes, corr, g["dim"], cdp, True)
+    try:
+        ix.set_option("first_segment_rows", 1024)
+        ix.set_option("segment_growth", 2)
+        idx, sc = ix.search(qq, qc, 4, sim, 20)
+        oi, osc = O.heap_topk(os32, 20)
+        np.testing.assert_array_equal(idx, oi)
+        assert ix.stats()["dense_fallbacks"] == 1
+    finally:
+        ix.close()
