@@ -238,11 +238,12 @@ void add_storage_segments(const bbq_index *ix, Plan &p, int storage, const Stora
     b = rows;
   }
   while (b < R) {
+    // the threshold of a segment comes from every row seen before it (pilot replica + this storage's earlier
+    // segments); the next boundary multiplies that count by `growth`, so every segment emits ~k*(growth-1) candidates
     const int64_t before = rows_before + b;
     int64_t e = R;
-    const int64_t nb = (b == 0 ? p.s0 : b) * ix->opt_growth;
-    if (b > 0 && nb <= R / 2) e = nb;
-    if (b == 0) e = R;  // shard behind a pilot replica: one sweep
+    const int64_t nb = (before * ix->opt_growth - rows_before) / kChunkRows * kChunkRows;
+    if (before > 0 && nb > b && nb <= R / 2) e = nb;
     const int cap = cap_for(p.k, before);
     const int64_t rows = e - b;
     p.segs.push_back(Segment{storage, b / kChunkRows, (rows + kChunkRows - 1) / kChunkRows, rows, false, emit, true, false, cap});

@@ -325,3 +325,45 @@ def test_bound_filter_nonfinite_corrections_take_the_exact_path():
         assert ix.stats()["dense_fallbacks"] == 1
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("name,shards,pilot", [("ties_cos_qb4", 3, 1024), ("big_20000x128_cos", 4, 2048), ("ties_euc_qb4", 2, 0),
+                                               ("big_50000x768_cos", 5, 4096)])
+def test_sharded_scan_and_replay_single_process(name, shards, pilot):
+    """row shards (each with its pilot replica of the global prefix) swept one after the other on the same GPU,
+    packed candidate lists replayed in shard order: must equal the reference's global top-k (ties included)"""
+    import torch
+    g = O.load_golden(name)
+    sim, base, queries, codes, corr, cen, cdp = _index_from_case(g)
+    n, dim = g["n"], g["dim"]
+    per = (n + shards - 1) // shards
+    nq = len(queries)
+    qs = [B.quantize_query(q, cen, sim, g["qb"], g["lambda"], g["iters"]) for q in queries]
+    qq, qc = np.stack([a for a, _ in qs]), np.stack([b for _, b in qs])
+    for k in sorted({t["k"] for t in g["queries"][0]["topk"]}):
+        if k > 2048:
+            continue
+        packed, offsets = [], []
+        for r in range(shards):
+            r0, r1 = r * per, min((r + 1) * per, n)
+            P = min(pilot, r0) // 1024 * 1024 if r > 0 else 0
+            ix = B.Index(codes[r0:r1], corr[r0:r1], dim, cdp, row_base=r0,
+                         pilot_codes=codes[:P] if P else None, pilot_corr=corr[:P] if P else None)
+            ix.set_option("first_segment_rows", 1024)
+            ix.set_option("segment_growth", 2)
+            cap = int(ix.shard_list_cap(k)) * nq
+            d_packed = torch.zeros(cap, dtype=torch.int64, device="cuda")
+            d_off = torch.zeros(nq + 1, dtype=torch.int64, device="cuda")
+            d_flags = torch.zeros(nq, dtype=torch.int32, device="cuda")
+            total = ix.shard_scan(qq, qc, g["qb"], sim, k, d_packed.data_ptr(), cap, d_off.data_ptr(), d_flags.data_ptr())
+            assert int(d_flags.abs().sum().item()) == 0
+            off = d_off.cpu().numpy()
+            assert off[-1] == total
+            packed.append(d_packed[:total].cpu().numpy().view(np.uint64))
+            offsets.append(off)
+            ix.close()
+        idx, sc, cnt = B.replay_batch(packed, offsets, nq, n, k, n_threads=3)
+        for qi in range(nq):
+            tk = [t for t in g["queries"][qi]["topk"] if t["k"] == k][0]
+            np.testing.assert_array_equal(idx[qi, :cnt[qi]], O.dec(tk["idx_i32"], "<i4"), err_msg="%s shards=%d k=%d q%d" % (name, shards, k, qi))
+            np.testing.assert_array_equal(canon32(sc[qi, :cnt[qi]]), canon32(O.dec(tk["score_f32"], "<f4")))
