@@ -40,7 +40,9 @@ _lib = None
 
 
 def lib():
-    """loads libbbq.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')"""
+    """loads libbbq.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()').
+    Note: PyTorch-ROCm wheels bundle their own libamdhip64 with the system's soname; a process that uses both must
+    import torch BEFORE the first call into libbbq so that one HIP runtime serves both."""
     global _lib
     if _lib is not None:
         return _lib
