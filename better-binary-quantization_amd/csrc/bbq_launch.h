@@ -15,4 +15,15 @@ hipError_t launch_retile(const uint8_t *codes, const double *corr, int64_t n_row
 hipError_t launch_check_x1(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t pb, uint32_t *mismatch,
                            hipStream_t s);
 
+// index build on the device (bbq_build_kernels.hip); vT4 is the [ceil(dim/4)][npad] float4 transposed copy
+hipError_t launch_build_transpose(const float *in, int64_t n, int32_t dim, int64_t npad, float *vT4, hipStream_t s);
+hipError_t launch_build_normalize(float *vT4, int64_t n, int32_t dim, int64_t npad, hipStream_t s);
+hipError_t launch_build_validate(const float *vT4, int64_t n, int32_t dim, int64_t npad, unsigned long long *first_bad, hipStream_t s);
+hipError_t launch_build_centroid(const float *vT4, int64_t n, int32_t dim, int64_t npad, float *centroid, hipStream_t s);
+hipError_t launch_build_quantize1(const float *vT4, int64_t n, int32_t dim, int64_t npad, const float *centroid, int32_t sim,
+                                  double lambda, int32_t iters, uint8_t *tiles, double *exact, double *corr_rm, int32_t w16,
+                                  int32_t tile_stride, int32_t layout, hipStream_t s);
+hipError_t launch_build_untile(const uint8_t *tiles, int64_t n, int32_t pb, int32_t w16, int32_t tile_stride, uint8_t *codes_rm,
+                               hipStream_t s);
+
 }  // namespace bbq

@@ -16,7 +16,7 @@ SIMS = {"EUCLIDEAN": 0, "COSINE": 1, "MAXIMUM_INNER_PRODUCT": 2}
 
 # every symbol include/bbq.h declares (tests/test_capi_symbols.py checks the library exports all of them)
 SYMBOLS = [
-    "bbq_last_error", "bbq_abi_version", "bbq_device_count", "bbq_index_create", "bbq_index_create_shard",
+    "bbq_last_error", "bbq_abi_version", "bbq_device_count", "bbq_index_create", "bbq_index_create_shard", "bbq_index_build",
     "bbq_index_destroy", "bbq_index_size", "bbq_index_dimension", "bbq_index_bytes_per_row", "bbq_search",
     "bbq_search_batch", "bbq_score_rows", "bbq_shard_scan", "bbq_shard_list_cap", "bbq_replay", "bbq_replay_batch",
     "bbq_quantize_vectors", "bbq_quantize_query", "bbq_quantize_query_vector", "bbq_centroid_dp", "bbq_get_stats",
@@ -55,6 +55,7 @@ def lib():
     L.bbq_device_count.restype = C.c_int
     L.bbq_index_create.argtypes = [vp, vp, i64, i32, i32, dbl, i32, C.POINTER(vp)]
     L.bbq_index_create_shard.argtypes = [vp, vp, i64, i32, i32, dbl, i64, vp, vp, i64, i32, C.POINTER(vp)]
+    L.bbq_index_build.argtypes = [vp, i64, i32, i32, dbl, i32, i32, C.POINTER(vp), vp, vp, vp, vp, vp]
     L.bbq_index_destroy.argtypes = [vp]
     L.bbq_index_destroy.restype = None
     L.bbq_index_size.argtypes = [vp]
@@ -151,6 +152,23 @@ class Index:
         self._h = h
         self.dim = dim
         self.n = n
+
+    @classmethod
+    def build(cls, vectors, sim, lam=0.1, iters=5, device=0, want_host_copy=True):
+        """quantizeVectors on the device (bbq_index_build): returns (index, codes, corr, centroid); codes/corr are None
+        unless want_host_copy"""
+        v = np.ascontiguousarray(vectors, np.float32)
+        if v.ndim != 2:
+            raise BBQError(ERR_INVALID_ARG, "vectors must be [n, dim]")
+        n, dim = v.shape
+        cen = np.zeros(dim, np.float32)
+        codes = np.zeros((n, (dim + 7) // 8), np.uint8) if want_host_copy else None
+        corr = np.zeros((n, 4), np.float64) if want_host_copy else None
+        h = C.c_void_p()
+        _chk(lib().bbq_index_build(_ptr(v), n, dim, sim, lam, iters, device, C.byref(h), _ptr(cen), _ptr(codes), _ptr(corr), None, None))
+        self = cls.__new__(cls)
+        self._h, self.dim, self.n = h, dim, n
+        return self, codes, corr, cen
 
     def close(self):
         if self._h:

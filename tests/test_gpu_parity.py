@@ -367,3 +367,61 @@ def test_sharded_scan_and_replay_single_process(name, shards, pilot):
             tk = [t for t in g["queries"][qi]["topk"] if t["k"] == k][0]
             np.testing.assert_array_equal(idx[qi, :cnt[qi]], O.dec(tk["idx_i32"], "<i4"), err_msg="%s shards=%d k=%d q%d" % (name, shards, k, qi))
             np.testing.assert_array_equal(canon32(sc[qi, :cnt[qi]]), canon32(O.dec(tk["score_f32"], "<f4")))
+
+
+BUILD_CASES = [n for n in CASES if O.load_golden(n)["ib"] == 1]
+
+
+@pytest.mark.parametrize("compact", [True, False])
+@pytest.mark.parametrize("name", BUILD_CASES)
+def test_device_index_build_matches_reference(name, compact):
+    """bbq_index_build: quantizeVectors as HIP kernels - centroid, packed codes, f64 corrections bit-exact vs the golden
+    vectors, and the index it leaves on the device answers searches exactly"""
+    import os
+    g = O.load_golden(name)
+    sim = O.SIMS[g["sim"]]
+    base, queries = O.golden_inputs(g)
+    os.environ["BBQ_COMPACT_CORRECTIONS"] = "1" if compact else "0"
+    try:
+        ix, codes, corr, cen = B.Index.build(base, sim, g["lambda"], g["iters"])
+    finally:
+        del os.environ["BBQ_COMPACT_CORRECTIONS"]
+    try:
+        assert O.sha(cen) == O.sha(O.dec(g["centroid_f32"], "<f4")), "centroid"
+        assert O.sha(codes) == g["codes_sha256"], "packed codes"
+        ocodes, ocorr, ocen = O.build_index(base, sim, g["lambda"], g["iters"])
+        np.testing.assert_array_equal(canon64(corr), canon64(ocorr))
+        for qi, rec in enumerate(g["queries"]):
+            qq, qc = B.quantize_query(queries[qi], cen, sim, g["qb"], g["lambda"], g["iters"])
+            for tk in rec["topk"]:
+                idx, sc = ix.search(qq, qc, g["qb"], sim, tk["k"])
+                np.testing.assert_array_equal(idx, O.dec(tk["idx_i32"], "<i4"))
+                np.testing.assert_array_equal(canon32(sc), canon32(O.dec(tk["score_f32"], "<f4")))
+    finally:
+        ix.close()
+
+
+def test_device_index_build_errors_and_odd_shapes():
+    with pytest.raises(B.BBQError) as e:
+        B.Index.build(np.zeros((0, 4), np.float32), 0)
+    assert e.value.code == 10
+    v = np.ones((300, 7), np.float32)
+    v[200, 5] = np.nan
+    v[250, 1] = np.inf
+    with pytest.raises(B.BBQError) as e:
+        B.Index.build(v, 0)
+    assert e.value.code == 8 and "向量 200 位置 5 包含NaN值" in str(e.value)
+    v[200, 5] = 1.0
+    with pytest.raises(B.BBQError) as e:
+        B.Index.build(v, 2)
+    assert e.value.code == 9 and "向量 250 位置 1 包含Infinity值" in str(e.value)
+    # dims that are not multiples of 4 / 8 / 128, row counts that are not multiples of 64
+    rng = np.random.default_rng(12)
+    for n, dim, sim in ((1, 1, 0), (65, 3, 1), (130, 13, 2), (999, 131, 1), (64, 129, 0)):
+        base = rng.standard_normal((n, dim)).astype(np.float32)
+        ix, codes, corr, cen = B.Index.build(base, sim)
+        ocodes, ocorr, ocen = O.build_index(base, sim)
+        np.testing.assert_array_equal(codes, ocodes)
+        np.testing.assert_array_equal(canon64(corr), canon64(ocorr))
+        np.testing.assert_array_equal(cen.view(np.uint32), ocen.view(np.uint32))
+        ix.close()
