@@ -6,7 +6,7 @@
 //   validate       first NaN / Infinity in row-major order (src/binaryQuantizationFormat.ts:196-211)
 //   centroid       computeCentroid (src/vectorOperations.ts:126-163): the Float32Array accumulator is rounded after EVERY
 //                  += and the sum runs over the vectors in order, so it is a serial chain per dimension; one wave per
-//                  4 dimensions streams its vT4 row with coalesced 1 KiB loads and walks the 64 values with readlane
+//                  4 dimensions streams its vT4 row with coalesced 1 KiB loads and walks the 64 values through LDS broadcasts
 //   quantize       OptimizedScalarQuantizer.scalarQuantize (src/optimizedScalarQuantizer.ts:108-227, getInitialInterval
 //                  :245-265, optimizeIntervals :280-353, computeLoss :373-407), one thread per vector, every reduction in
 //                  the reference's index order, f64 without FMA contraction; the last pass packs the bits
@@ -135,35 +135,35 @@ __global__ __launch_bounds__(256) void bbq_validate_kernel(const f32x4 *__restri
 }
 
 // ------------------------------------------------------------------------------------------------ centroid
-// one wave per float4 row (4 dimensions): serial, exactly rounded f32 accumulation over the vectors in order
+// one wave per float4 row (4 dimensions): serial, exactly rounded f32 accumulation over the vectors in order.
+// The wave loads 64 consecutive vectors' values with one coalesced 1 KiB load, parks them in LDS and every lane walks
+// them in order (uniform LDS reads broadcast); the next 1 KiB is already in flight while the chain runs.
 __global__ __launch_bounds__(64) void bbq_centroid_kernel(const f32x4 *__restrict__ vT4, int64_t n, int32_t dim, int64_t npad,
                                                          float *__restrict__ centroid) {
+  __shared__ f32x4 s_buf[2][64];
   const int i4 = blockIdx.x;
   const int lane = threadIdx.x;
   const f32x4 *__restrict__ row = vT4 + (int64_t)i4 * npad;
   float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
   f32x4 x = row[lane];  // npad is a multiple of 64: always in bounds
-  for (int64_t j0 = 0; j0 < n; j0 += 64) {
-    const f32x4 cur = x;
-    if (j0 + 64 < n) x = row[j0 + 64 + lane];  // prefetch the next 1 KiB while the chain below runs
+  int pb = 0;
+  for (int64_t j0 = 0; j0 < n; j0 += 64, pb ^= 1) {
+    s_buf[pb][lane] = x;
+    if (j0 + 64 < n) x = row[j0 + 64 + lane];  // prefetch
+    __syncthreads();
     const int cnt = (int)((n - j0) < 64 ? (n - j0) : 64);
-#pragma unroll
-    for (int t = 0; t < 64; ++t) {
-      if (t < cnt) {  // wave-uniform
-        const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.x), t));
-        const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.y), t));
-        const float a2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.z), t));
-        const float a3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.w), t));
-        if (j0 == 0 && t == 0) {  // centroid[i] = vectors[0][i]
-          c0 = a0; c1 = a1; c2 = a2; c3 = a3;
-        } else {                  // centroid[i] += val  (Float32Array element: f64 add, then round to f32)
-          c0 = (float)((double)c0 + (double)a0);
-          c1 = (float)((double)c1 + (double)a1);
-          c2 = (float)((double)c2 + (double)a2);
-          c3 = (float)((double)c3 + (double)a3);
-        }
+    for (int t = 0; t < cnt; ++t) {
+      const f32x4 a = s_buf[pb][t];
+      if (j0 == 0 && t == 0) {  // centroid[i] = vectors[0][i]
+        c0 = a.x; c1 = a.y; c2 = a.z; c3 = a.w;
+      } else {                  // centroid[i] += val  (Float32Array element: f64 add, then round to f32)
+        c0 = (float)((double)c0 + (double)a.x);
+        c1 = (float)((double)c1 + (double)a.y);
+        c2 = (float)((double)c2 + (double)a.z);
+        c3 = (float)((double)c3 + (double)a.w);
       }
     }
+    // the other buffer is overwritten next iteration; every lane has finished reading it one iteration ago
   }
   if (lane == 0) {
     const double dn = (double)n;
