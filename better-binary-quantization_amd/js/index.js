@@ -183,12 +183,19 @@ class BinaryQuantizationFormat {
       if (v.length !== dim) throw new Error('向量 ' + i + ' 维度 ' + v.length + ' 与第一个向量维度 ' + dim + ' 不匹配');
     }
     const q = this.quantizer;
-    const r = native.quantizeVectors(flatten(vectors, dim), vectors.length, dim, simOrdinal(q.similarityFunction),
-      this.config.indexBits, q.lambda, q.iters, Number(process.env.BBQ_THREADS || 0));
-    return {
-      quantizedVectors: new BinarizedByteVectorValuesImpl(r.codes, r.corr, r.centroid, this.config.indexBits, vectors.length),
-      queryQuantizer: this.quantizer,
-    };
+    let values;
+    if (this.config.indexBits === 1 && process.env.BBQ_HOST_QUANTIZER !== '1' && native.deviceCount() > 0) {
+      // quantizeVectors as HIP kernels; the device index is ready when this returns (no second upload on first search)
+      const r = native.indexBuild(flatten(vectors, dim), vectors.length, dim, simOrdinal(q.similarityFunction), q.lambda, q.iters,
+        Number(process.env.BBQ_DEVICE || 0));
+      values = new BinarizedByteVectorValuesImpl(r.codes, r.corr, r.centroid, 1, vectors.length);
+      values._device = r.handle;
+    } else {
+      const r = native.quantizeVectors(flatten(vectors, dim), vectors.length, dim, simOrdinal(q.similarityFunction),
+        this.config.indexBits, q.lambda, q.iters, Number(process.env.BBQ_THREADS || 0));
+      values = new BinarizedByteVectorValuesImpl(r.codes, r.corr, r.centroid, this.config.indexBits, vectors.length);
+    }
+    return { quantizedVectors: values, queryQuantizer: this.quantizer };
   }
 
   /** quantizeQueryVector(queryVector, centroid) -> {quantizedQuery, queryCorrections}  (:271-299) */

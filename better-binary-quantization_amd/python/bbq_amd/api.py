@@ -85,11 +85,18 @@ class BinaryQuantizationFormat:
             if len(v) != dim:
                 raise Exception("向量 %d 维度 %d 与第一个向量维度 %d 不匹配" % (i, len(v), dim))
         try:
-            codes, corr, cen = capi.quantize_vectors(np.asarray(vectors, np.float32), capi.SIMS[self._sim],
-                                                     self._config["indexBits"], self._lambda, self._iters)
+            if self._config["indexBits"] == 1 and capi.device_count() > 0:
+                # quantizeVectors as HIP kernels; the device index is ready when this returns
+                ix, codes, corr, cen = capi.Index.build(np.asarray(vectors, np.float32), capi.SIMS[self._sim], self._lambda, self._iters)
+                values = BinarizedByteVectorValues(codes, corr, cen, 1)
+                values._device_index = ix
+            else:
+                codes, corr, cen = capi.quantize_vectors(np.asarray(vectors, np.float32), capi.SIMS[self._sim],
+                                                         self._config["indexBits"], self._lambda, self._iters)
+                values = BinarizedByteVectorValues(codes, corr, cen, self._config["indexBits"])
         except capi.BBQError as e:
             raise Exception(str(e))
-        return {"quantizedVectors": BinarizedByteVectorValues(codes, corr, cen, self._config["indexBits"]), "queryQuantizer": self}
+        return {"quantizedVectors": values, "queryQuantizer": self}
 
     def quantizeQueryVector(self, queryVector, centroid):
         qq, qc = capi.quantize_query(queryVector, centroid, capi.SIMS[self._sim], self._config["queryBits"], self._lambda,
