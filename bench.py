@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value")
+    ap.add_argument("--shared-sweep", type=int, default=8, help="also time the batched mode (queries per shared sweep; 0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1: nccl (= RCCL) or gloo (rehearsal)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -215,6 +216,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = ix.stats()
+    batched = None
+    if world == 1 and args.shared_sweep in (4, 8):
+        # API extension, reported separately: `shared_sweep` queries share one sweep of the index
+        ix.set_option("sweep_share", args.shared_sweep)
+        res_b = ix.search_batch(batches[args.warmup][0], batches[args.warmup][1], QB, SIM, k)
+        same = bool((res_b[0] == results[args.warmup][0]).all() and (res_b[1].view(np.uint32) == results[args.warmup][1].view(np.uint32)).all())
+        ix.reset_stats()
+        barrier()
+        tb = time.perf_counter()
+        for qq_b, qc_b in batches[args.warmup:]:
+            ix.search_batch(qq_b, qc_b, QB, SIM, k)
+        barrier()
+        dtb = time.perf_counter() - tb
+        stb = ix.stats()
+        lb = stb["total_scan_bytes"] / max(stb["total_scan_launches"], 1)
+        lms = stb["total_scan_ms"] / max(stb["total_scan_launches"], 1)
+        batched = {"queries_per_sweep": args.shared_sweep, "value": args.steps * Q / dtb, "unit": "queries/s",
+                   "identical_to_unshared": same, "bound": "valu (popcount + f64 bound per query; HBM bytes amortised over the sweep)",
+                   "index_stream_GBps": lb / (lms * 1e-3) / 1e9 if lms > 0 else None}
+        ix.set_option("sweep_share", 1)
 
     if rank == 0:
         qps = args.steps * Q / dt
@@ -245,6 +266,8 @@ def main():
             "candidates_per_query": st["candidates"] / float(Q) if world == 1 else None,
             "dense_fallbacks": st["dense_fallbacks"],
         }
+        if batched is not None:
+            out["batched"] = batched
         if not args.no_cpu_baseline:
             us_row, done, rows, secs = cpu_baseline(dim, k, codes, corr, qq_all, qc_all, cdp, QB, SIM)
             out["cpu_baseline"] = {"value": 1e6 / (us_row * N), "unit": "queries/s", "cores": 1, "kind": "port",

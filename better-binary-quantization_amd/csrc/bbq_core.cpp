@@ -116,7 +116,7 @@ struct bbq_index {
   int32_t *d_shard_counts = nullptr;
   int64_t shard_q_cap = 0, shard_list_cap = 0;
   // options
-  int opt_batch = 32, opt_slots = 2, opt_growth = 8, opt_replay_threads = 1, opt_force_dense = 0;
+  int opt_batch = 32, opt_slots = 2, opt_growth = 8, opt_replay_threads = 1, opt_force_dense = 0, opt_share = 1;
   int64_t opt_s0 = 4096;
   bbq_stats stats{};
 };
@@ -454,7 +454,10 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
     if (g.big && ix->ctx->last_big_slot >= 0 && ix->ctx->last_big_slot != my_slot)
       HIPCHK(hipStreamWaitEvent(st, ix->slots[ix->ctx->last_big_slot].ev_big, 0));  // one big sweep at a time on the device
     if (g.dominant) HIPCHK(hipEventRecord(s.ev0, st));
-    HIPCHK(launch_scan(a, c.planes, g.dense, nq, (int)g.n_chunks, st));
+    if (!g.dense && ix->opt_share > 1 && shared_sweep_supported(a, ix->opt_share))
+      HIPCHK(launch_scan_shared(a, c.planes, ix->opt_share, nq, (int)g.n_chunks, st));
+    else
+      HIPCHK(launch_scan(a, c.planes, g.dense, nq, (int)g.n_chunks, st));
     if (g.big) {
       HIPCHK(hipEventRecord(s.ev_big, st));
       ix->ctx->last_big_slot = my_slot;
@@ -463,7 +466,9 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
       HIPCHK(hipEventRecord(s.ev1, st));
       s.timed = true;
       s.timed_rows = g.rows * nq;
-      s.timed_bytes = g.rows * nq * (int64_t)ix->bytes_per_row;
+      // a shared sweep reads each row once for `share` queries
+      const int share = (!g.dense && ix->opt_share > 1 && shared_sweep_supported(a, ix->opt_share)) ? ix->opt_share : 1;
+      s.timed_bytes = g.rows * ((nq + share - 1) / share) * (int64_t)ix->bytes_per_row;
     }
     FinalizeArgs f{};
     f.counts = s.d_counts;
@@ -1078,6 +1083,7 @@ int bbq_set_option(bbq_index *ix, const char *name, int64_t v) {
   else if (n == "first_segment_rows" && v >= 1024 && v <= 8192 && v % kChunkRows == 0) { ix->opt_s0 = v; ix->plan.k = -1; }
   else if (n == "replay_threads" && v >= 1 && v <= 256) ix->opt_replay_threads = (int)v;
   else if (n == "force_dense" && (v == 0 || v == 1)) ix->opt_force_dense = (int)v;
+  else if (n == "sweep_share" && (v == 1 || v == 4 || v == 8)) ix->opt_share = (int)v;
   else return fail(BBQ_ERR_INVALID_ARG, "bbq_set_option: unknown option or value out of range: %s=%lld", name, (long long)v);
   ix->plan.k = -1;  // workspace is grow-only and re-checked by ensure_slot on the next call
   return BBQ_OK;

@@ -249,6 +249,133 @@ __global__ __launch_bounds__(1024) void bbq_scan_kernel(const ScanArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Shared sweep (API extension; reported separately from the one-sweep-per-query metric): one workgroup
+// scores its 1024 rows against NB queries.  The codes (and corrections) of a row are loaded ONCE into registers and
+// reused for every query, so HBM traffic per query drops NB-fold and the kernel becomes VALU-bound (popcounts + f64
+// bound/score per query).  Results are identical to NB separate sweeps: same thresholds, same slots, same lists.
+template <int QB, int W, bool COMPACT, int NB>
+__global__ __launch_bounds__(1024) void bbq_scan_shared_kernel(const ScanArgs a, const int nq_total) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NT = 1024;
+  u32x4 *s_planes = reinterpret_cast<u32x4 *>(smem);                               // [NB][W*QB]
+  QueryParams *s_qp = reinterpret_cast<QueryParams *>(smem + (size_t)NB * W * QB * 16);  // [NB]
+  uint64_t *s_ent = reinterpret_cast<uint64_t *>(s_qp + NB);                        // [NB][cap]
+  uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_ent + (size_t)NB * a.cap);       // [NB]
+  uint32_t *s_theta = s_cnt + NB;                                                   // [NB]
+
+  const int q0 = blockIdx.y * NB;
+  const int nb = min(NB, nq_total - q0);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  {
+    const u32x4 *__restrict__ gp = reinterpret_cast<const u32x4 *>(a.qplanes) + (size_t)q0 * W * QB;
+    for (int i = tid; i < nb * W * QB; i += NT) s_planes[i] = gp[i];
+    if (tid < nb) {
+      s_qp[tid] = a.qparams[q0 + tid];
+      s_cnt[tid] = 0;
+      s_theta[tid] = a.theta[q0 + tid];
+    }
+  }
+  __syncthreads();
+
+  const int64_t chunk = a.chunk_begin + blockIdx.x;
+  const int64_t n_tiles = (a.idx.n_rows + kTileRows - 1) / kTileRows;
+  const int64_t tile = chunk * kTilesPerChunk + wave;
+  uint32_t nan_mask = 0;
+
+  if (tile < n_tiles) {  // wave-uniform
+    const uint8_t *__restrict__ tp = a.idx.tiles + tile * (int64_t)a.idx.tile_stride;
+    const uint8_t *__restrict__ cr = tp + (size_t)W * (kTileRows * 16);
+    const int64_t row = tile * kTileRows + lane;
+    const bool valid = row < a.idx.n_rows;
+    const u32x4 *__restrict__ cp = reinterpret_cast<const u32x4 *>(tp) + lane;
+    u32x4 c[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) c[j] = __builtin_nontemporal_load(cp + j * kTileRows);
+    f64x2 lu = {0.0, 0.0};
+    double xadd = 0.0, x1 = 0.0, al = 0.0, au = 0.0, aadd = 0.0;
+    bool have_exact = false;
+    if constexpr (!COMPACT) {
+      lu = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(cr) + lane);
+      xadd = __builtin_nontemporal_load(reinterpret_cast<const double *>(cr + 1024) + lane);
+      if (a.idx.has_x1) x1 = __builtin_nontemporal_load(reinterpret_cast<const double *>(cr + 1536) + lane);
+      have_exact = true;
+    } else {
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 cc = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(cr) + lane);
+      al = (double)__uint_as_float(cc.x << 16);
+      au = (double)__uint_as_float(cc.x & 0xffff0000u);
+      aadd = (double)__uint_as_float(cc.y);
+    }
+    uint32_t ones = 0;
+#pragma unroll
+    for (int j = 0; j < W; ++j) ones += popc4(c[j]);
+    if (!a.idx.has_x1) x1 = (double)ones;
+
+#pragma unroll 1
+    for (int b = 0; b < nb; ++b) {
+      const u32x4 *__restrict__ pl = s_planes + (size_t)b * W * QB;
+      uint32_t acc[QB];
+#pragma unroll
+      for (int pq = 0; pq < QB; ++pq) acc[pq] = 0;
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+#pragma unroll
+        for (int pq = 0; pq < QB; ++pq) acc[pq] += popc4(c[j] & pl[j * QB + pq]);
+      }
+      uint32_t qc = 0;
+#pragma unroll
+      for (int pq = 0; pq < QB; ++pq) qc += acc[pq] << pq;
+      const QueryParams p = s_qp[b];
+      const uint32_t theta = s_theta[b];
+      bool need_exact = valid;
+      if constexpr (COMPACT) {
+        const double ub = score_upper_bound((double)qc, al, au, aadd, x1, p);
+        const float ub32 = (float)ub;
+        need_exact = valid && ((ub32 != ub32) || key_of_bits(__float_as_uint(ub32)) > theta);
+        if (need_exact && !have_exact) {
+          const f64x2 *__restrict__ ex = reinterpret_cast<const f64x2 *>(a.idx.exact + row * 4);
+          lu = ex[0];
+          xadd = reinterpret_cast<const double *>(ex + 1)[0];
+          have_exact = true;
+        }
+      }
+      if (need_exact) {
+        const double s64 = score_f64((double)qc, lu.x, lu.y, xadd, x1, p);
+        const float s32 = (float)s64;
+        const uint32_t bits = __float_as_uint(s32);
+        if (s32 != s32) nan_mask |= 1u << b;
+        if ((s32 == s32) && key_of_bits(bits) > theta) {
+          const uint32_t slot = atomicAdd(&s_cnt[b], 1u);
+          if (slot < (uint32_t)a.cap) s_ent[(size_t)b * a.cap + slot] = ((uint64_t)(uint32_t)(a.row_id_base + row) << 32) | bits;
+        }
+      }
+    }
+  }
+  for (int b = 0; b < nb; ++b)
+    if (__any((nan_mask >> b) & 1u) && lane == 0) atomicOr(a.flags + q0 + b, kFlagNaN);
+
+  __syncthreads();
+  for (int b = 0; b < nb; ++b) {
+    uint32_t cnt = s_cnt[b];
+    if (cnt > (uint32_t)a.cap) {
+      if (tid == 0) atomicOr(a.flags + q0 + b, kFlagOverflow);
+      cnt = (uint32_t)a.cap;
+    }
+    const uint64_t *__restrict__ src = s_ent + (size_t)b * a.cap;
+    uint64_t *__restrict__ out = a.entries + ((size_t)(q0 + b) * a.n_chunks + blockIdx.x) * (size_t)a.cap;
+    for (uint32_t i = tid; i < cnt; i += NT) {
+      const uint64_t e = src[i];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < cnt; ++j) rank += (src[j] < e) ? 1u : 0u;
+      out[rank] = e;
+    }
+    if (tid == 0) a.counts[(size_t)(q0 + b) * a.n_chunks + blockIdx.x] = cnt;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // finalize: one workgroup (1024 threads) per query
 
 __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t *s_wave, uint32_t &total) {
@@ -522,6 +649,46 @@ static hipError_t launch_scan_q(const ScanArgs &a, int planes, int nq, int nc, h
     case 4: return launch_scan_w<4, MODE>(a, nq, nc, s);
     default: return launch_scan_w<8, MODE>(a, nq, nc, s);
   }
+}
+
+template <int QB, int W, bool COMPACT, int NB>
+static hipError_t launch_shared_t(const ScanArgs &a, int nq, int nc, hipStream_t s) {
+  const size_t smem = (size_t)NB * W * QB * 16 + (size_t)NB * sizeof(QueryParams) + (size_t)NB * a.cap * 8 + (size_t)NB * 8 + 16;
+  dim3 grid((unsigned)nc, (unsigned)((nq + NB - 1) / NB), 1), block(1024, 1, 1);
+  hipLaunchKernelGGL((bbq_scan_shared_kernel<QB, W, COMPACT, NB>), grid, block, smem, s, a, nq);
+  return hipGetLastError();
+}
+template <int QB, bool COMPACT, int NB>
+static hipError_t launch_shared_w(const ScanArgs &a, int nq, int nc, hipStream_t s) {
+  switch (a.idx.w16) {
+    case 1: return launch_shared_t<QB, 1, COMPACT, NB>(a, nq, nc, s);
+    case 6: return launch_shared_t<QB, 6, COMPACT, NB>(a, nq, nc, s);
+    case 8: return launch_shared_t<QB, 8, COMPACT, NB>(a, nq, nc, s);
+    case 12: return launch_shared_t<QB, 12, COMPACT, NB>(a, nq, nc, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+template <bool COMPACT, int NB>
+static hipError_t launch_shared_q(const ScanArgs &a, int planes, int nq, int nc, hipStream_t s) {
+  switch (planes) {
+    case 1: return launch_shared_w<1, COMPACT, NB>(a, nq, nc, s);
+    case 2: return launch_shared_w<2, COMPACT, NB>(a, nq, nc, s);
+    case 4: return launch_shared_w<4, COMPACT, NB>(a, nq, nc, s);
+    default: return launch_shared_w<8, COMPACT, NB>(a, nq, nc, s);
+  }
+}
+
+bool shared_sweep_supported(const ScanArgs &a, int share) {
+  const int w = a.idx.w16;
+  return (share == 4 || share == 8) && (w == 1 || w == 6 || w == 8 || w == 12) && (size_t)share * a.cap * 8 < 48 * 1024;
+}
+
+// sparse segments only; `share` queries per workgroup read each row once
+hipError_t launch_scan_shared(const ScanArgs &a, int planes, int share, int n_queries, int n_chunks, hipStream_t s) {
+  if (n_chunks <= 0 || n_queries <= 0) return hipSuccess;
+  const bool compact = a.idx.layout == kLayoutCompact;
+  if (share == 8) return compact ? launch_shared_q<true, 8>(a, planes, n_queries, n_chunks, s) : launch_shared_q<false, 8>(a, planes, n_queries, n_chunks, s);
+  return compact ? launch_shared_q<true, 4>(a, planes, n_queries, n_chunks, s) : launch_shared_q<false, 4>(a, planes, n_queries, n_chunks, s);
 }
 
 hipError_t launch_scan(const ScanArgs &a, int planes, bool dense, int n_queries, int n_chunks, hipStream_t s) {

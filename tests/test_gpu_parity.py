@@ -425,3 +425,33 @@ def test_device_index_build_errors_and_odd_shapes():
         np.testing.assert_array_equal(canon64(corr), canon64(ocorr))
         np.testing.assert_array_equal(cen.view(np.uint32), ocen.view(np.uint32))
         ix.close()
+
+
+@pytest.mark.parametrize("compact", [True, False])
+@pytest.mark.parametrize("share", [4, 8])
+@pytest.mark.parametrize("name", ["ties_cos_qb4", "big_20000x128_cos", "ties_16d_qb1", "m_768d_max_qb4", "big_30000x1536_mip"])
+def test_shared_sweep_gives_identical_results(name, share, compact):
+    """API extension: several queries per sweep (one load of each row, `share` queries scored from registers).
+    Must return exactly what one-sweep-per-query returns."""
+    g = O.load_golden(name)
+    sim, base, queries, codes, corr, cen, cdp = _index_from_case(g)
+    ix = _make_index(codes, corr, g["dim"], cdp, compact)
+    try:
+        ix.set_option("first_segment_rows", 1024)
+        ix.set_option("segment_growth", 2)
+        ix.set_option("sweep_share", share)
+        rng = np.random.default_rng(4)
+        extra = rng.standard_normal((11, g["dim"])).astype(np.float32)       # 11 + nq queries: not a multiple of `share`
+        allq = np.concatenate([queries, extra])
+        qs = [B.quantize_query(q, cen, sim, g["qb"], g["lambda"], g["iters"]) for q in allq]
+        qq, qc = np.stack([a for a, _ in qs]), np.stack([b for _, b in qs])
+        k = g["k"]
+        idx, sc, cnt = ix.search_batch(qq, qc, g["qb"], sim, k)
+        for qi in range(len(allq)):
+            d, s64, s32 = O.score_all(codes, corr, g["dim"], qq[qi], qc[qi], g["qb"], sim, cdp)
+            oi, osc = O.heap_topk(s32, k)
+            np.testing.assert_array_equal(idx[qi, :cnt[qi]], oi, err_msg="query %d" % qi)
+            np.testing.assert_array_equal(canon32(sc[qi, :cnt[qi]]), canon32(osc))
+        assert ix.stats()["dense_fallbacks"] == 0
+    finally:
+        ix.close()
