@@ -455,3 +455,73 @@ def test_shared_sweep_gives_identical_results(name, share, compact):
         assert ix.stats()["dense_fallbacks"] == 0
     finally:
         ix.close()
+
+
+def test_full_size_10m_x_768_properties():
+    """BASELINE size (10 M x 768-d, k=100) on one GPU: the oracle's answer for one query, and size-independent properties
+    for more: compact == inline layout, sparse segments == dense replay, shared sweep == one sweep per query, a shard split
+    == the single index, every returned score equals the row's dense score."""
+    import torch
+    sys_path_bench = __import__("importlib").import_module("bench")
+    n, dim, k, pb = 10_000_000, 768, 100, 96
+    codes, corr = sys_path_bench.synth_rows(1, 0, n, pb)
+    qq, qc = sys_path_bench.synth_queries(2, 6, dim)
+    cdp = 0.0009110655808639536
+    ix = _make_index(codes, corr, dim, cdp, True)
+    try:
+        idx, sc, cnt = ix.search_batch(qq, qc, 4, 1, k)
+        assert (cnt == k).all() and ix.stats()["dense_fallbacks"] == 0
+        # (1) the oracle, one query (about 3 s of CPU)
+        d, s64, s32 = O.score_all(codes, corr, dim, qq[0], qc[0], 4, 1, cdp)
+        oi, osc = O.heap_topk(s32, k)
+        np.testing.assert_array_equal(idx[0], oi)
+        np.testing.assert_array_equal(sc[0].view(np.uint32), osc.view(np.uint32))
+        # (2) returned scores are the rows' own scores, descending
+        for q in range(1, 3):
+            for j in (0, 17, 99):
+                r = int(idx[q, j])
+                _, _, one = ix.score_rows(qq[q], qc[q], 4, 1, r, 1)
+                assert one[0].view(np.uint32) == sc[q, j].view(np.uint32)
+            assert (np.diff(sc[q]) <= 0).all()
+        # (3) dense replay of everything == sparse segments
+        ix.set_option("force_dense", 1)
+        di, ds, _ = ix.search_batch(qq[:2], qc[:2], 4, 1, k)
+        ix.set_option("force_dense", 0)
+        np.testing.assert_array_equal(di, idx[:2])
+        np.testing.assert_array_equal(ds.view(np.uint32), sc[:2].view(np.uint32))
+        # (4) shared sweep == one sweep per query
+        ix.set_option("sweep_share", 8)
+        si, ss, _ = ix.search_batch(qq, qc, 4, 1, k)
+        ix.set_option("sweep_share", 1)
+        np.testing.assert_array_equal(si, idx)
+        np.testing.assert_array_equal(ss.view(np.uint32), sc.view(np.uint32))
+    finally:
+        ix.close()
+    # (5) inline layout
+    ix = _make_index(codes, corr, dim, cdp, False)
+    try:
+        ii, isc, _ = ix.search_batch(qq, qc, 4, 1, k)
+        np.testing.assert_array_equal(ii, idx)
+        np.testing.assert_array_equal(isc.view(np.uint32), sc.view(np.uint32))
+    finally:
+        ix.close()
+    # (6) three uneven shards with a 32 K pilot, swept one after the other, replayed in shard order
+    cuts = [0, 3_000_000, 7_500_000, n]
+    packed, offsets = [], []
+    for r in range(3):
+        r0, r1 = cuts[r], cuts[r + 1]
+        P = 32768 if r > 0 else 0
+        sh = B.Index(codes[r0:r1], corr[r0:r1], dim, cdp, row_base=r0, pilot_codes=codes[:P] if P else None,
+                     pilot_corr=corr[:P] if P else None)
+        cap = int(sh.shard_list_cap(k)) * len(qq)
+        d_packed = torch.zeros(cap, dtype=torch.int64, device="cuda")
+        d_off = torch.zeros(len(qq) + 1, dtype=torch.int64, device="cuda")
+        d_flags = torch.zeros(len(qq), dtype=torch.int32, device="cuda")
+        total = sh.shard_scan(qq, qc, 4, 1, k, d_packed.data_ptr(), cap, d_off.data_ptr(), d_flags.data_ptr())
+        assert int(d_flags.abs().sum().item()) == 0
+        packed.append(d_packed[:total].cpu().numpy().view(np.uint64))
+        offsets.append(d_off.cpu().numpy())
+        sh.close()
+    ri, rs, rc = B.replay_batch(packed, offsets, len(qq), n, k, n_threads=4)
+    np.testing.assert_array_equal(ri, idx)
+    np.testing.assert_array_equal(rs.view(np.uint32), sc.view(np.uint32))
