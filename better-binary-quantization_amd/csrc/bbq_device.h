@@ -5,7 +5,10 @@
 namespace bbq {
 
 constexpr int kTileRows = 64;        // one wavefront = one tile: lane r owns row r of the tile
-constexpr int kChunkRows = 1024;     // one workgroup = 16 tiles; candidate slots are per chunk
+#ifndef BBQ_CHUNK_ROWS
+#define BBQ_CHUNK_ROWS 512
+#endif
+constexpr int kChunkRows = BBQ_CHUNK_ROWS;  // rows per workgroup (one 64-row tile per wave); candidate slots are per chunk
 constexpr int kTilesPerChunk = kChunkRows / kTileRows;
 constexpr uint32_t kFlagOverflow = 1u;   // a candidate slot / list / key buffer overflowed
 constexpr uint32_t kFlagNaN = 2u;        // a NaN score was produced: order statistics are meaningless

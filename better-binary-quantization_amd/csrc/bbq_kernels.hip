@@ -130,11 +130,11 @@ __device__ __forceinline__ double score_upper_bound(double qc, double al, double
 }
 
 // MODE: 0 sparse / inline corrections, 1 dense / inline, 2 sparse / compact corrections + exact gather, 3 dense / compact
-// grid = (chunks of 1024 rows, queries); block = 16 waves: wave w handles tile w of its chunk (one row per lane)
+// grid = (chunks of kChunkRows rows, queries); block = kChunkRows/64 waves: wave w handles tile w of its chunk (one row per lane)
 template <int QB, int W, int MODE>
-__global__ __launch_bounds__(1024) void bbq_scan_kernel(const ScanArgs a) {
+__global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NT = 1024;
+  constexpr int NT = kChunkRows;
   constexpr bool DENSE = (MODE & 1) != 0;
   constexpr bool COMPACT = (MODE & 2) != 0;
   const int w16 = W > 0 ? W : a.idx.w16;
@@ -254,9 +254,9 @@ __global__ __launch_bounds__(1024) void bbq_scan_kernel(const ScanArgs a) {
 // reused for every query, so HBM traffic per query drops NB-fold and the kernel becomes VALU-bound (popcounts + f64
 // bound/score per query).  Results are identical to NB separate sweeps: same thresholds, same slots, same lists.
 template <int QB, int W, bool COMPACT, int NB>
-__global__ __launch_bounds__(1024) void bbq_scan_shared_kernel(const ScanArgs a, const int nq_total) {
+__global__ __launch_bounds__(kChunkRows) void bbq_scan_shared_kernel(const ScanArgs a, const int nq_total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NT = 1024;
+  constexpr int NT = kChunkRows;
   u32x4 *s_planes = reinterpret_cast<u32x4 *>(smem);                               // [NB][W*QB]
   QueryParams *s_qp = reinterpret_cast<QueryParams *>(smem + (size_t)NB * W * QB * 16);  // [NB]
   uint64_t *s_ent = reinterpret_cast<uint64_t *>(s_qp + NB);                        // [NB][cap]
@@ -625,7 +625,7 @@ template <int QB, int W, int MODE>
 static hipError_t launch_scan_t(const ScanArgs &a, int n_queries, int n_chunks, hipStream_t s) {
   const int w16 = W > 0 ? W : a.idx.w16;
   const size_t smem = (size_t)w16 * QB * 16 + ((MODE & 1) ? 0 : (size_t)a.cap * 8) + 16;
-  dim3 grid((unsigned)n_chunks, (unsigned)n_queries, 1), block(1024, 1, 1);
+  dim3 grid((unsigned)n_chunks, (unsigned)n_queries, 1), block(kChunkRows, 1, 1);
   hipLaunchKernelGGL((bbq_scan_kernel<QB, W, MODE>), grid, block, smem, s, a);
   return hipGetLastError();
 }
@@ -654,7 +654,7 @@ static hipError_t launch_scan_q(const ScanArgs &a, int planes, int nq, int nc, h
 template <int QB, int W, bool COMPACT, int NB>
 static hipError_t launch_shared_t(const ScanArgs &a, int nq, int nc, hipStream_t s) {
   const size_t smem = (size_t)NB * W * QB * 16 + (size_t)NB * sizeof(QueryParams) + (size_t)NB * a.cap * 8 + (size_t)NB * 8 + 16;
-  dim3 grid((unsigned)nc, (unsigned)((nq + NB - 1) / NB), 1), block(1024, 1, 1);
+  dim3 grid((unsigned)nc, (unsigned)((nq + NB - 1) / NB), 1), block(kChunkRows, 1, 1);
   hipLaunchKernelGGL((bbq_scan_shared_kernel<QB, W, COMPACT, NB>), grid, block, smem, s, a, nq);
   return hipGetLastError();
 }

@@ -7,7 +7,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))            # better-binary-quantization_amd/
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libbbq.so")
+LIB_PATH = os.environ.get("BBQ_LIB") or os.path.join(PKG_ROOT, "lib", "libbbq.so")  # BBQ_LIB: experiments with alternative builds
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED = 0, 1, 2, 3, 4, 5
 ERR_DIM_MISMATCH, ERR_NEGATIVE_K, ERR_NAN_INPUT, ERR_INF_INPUT, ERR_EMPTY = 6, 7, 8, 9, 10
