@@ -525,3 +525,36 @@ def test_full_size_10m_x_768_properties():
     ri, rs, rc = B.replay_batch(packed, offsets, len(qq), n, k, n_threads=4)
     np.testing.assert_array_equal(ri, idx)
     np.testing.assert_array_equal(rs.view(np.uint32), sc.view(np.uint32))
+
+
+@pytest.mark.parametrize("dim,qb,sim", [(2000, 4, 1), (264, 8, 2), (4096, 2, 0), (520, 1, 1)])
+def test_generic_row_widths(dim, qb, sim):
+    """dims whose packed rows are not one of the compile-time widths take the runtime-loop kernel; the shared-sweep
+    option must quietly fall back there"""
+    rng = np.random.default_rng(dim)
+    n, k = 6000, 40
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    ix, codes, corr, cen = B.Index.build(base, sim)
+    ocodes, ocorr, ocen = O.build_index(base, sim)
+    np.testing.assert_array_equal(codes, ocodes)
+    np.testing.assert_array_equal(canon64(corr), canon64(ocorr))
+    cdp = B.centroid_dp(cen)
+    try:
+        ix.set_option("first_segment_rows", 1024)
+        ix.set_option("segment_growth", 2)
+        for share in (1, 8):
+            ix.set_option("sweep_share", share)
+            qs = [B.quantize_query(rng.standard_normal(dim).astype(np.float32), cen, sim, qb) for _ in range(5)]
+            qq, qc = np.stack([a for a, _ in qs]), np.stack([b for _, b in qs])
+            idx, sc, cnt = ix.search_batch(qq, qc, qb, sim, k)
+            for i in range(5):
+                d, s64, s32 = O.score_all(codes, corr, dim, qq[i], qc[i], qb, sim, cdp)
+                oi, osc = O.heap_topk(s32, k)
+                np.testing.assert_array_equal(idx[i], oi)
+                np.testing.assert_array_equal(canon32(sc[i]), canon32(osc))
+            gd, g64, g32 = ix.score_rows(qq[0], qc[0], qb, sim)
+            d, s64, s32 = O.score_all(codes, corr, dim, qq[0], qc[0], qb, sim, cdp)
+            np.testing.assert_array_equal(gd, d)
+            np.testing.assert_array_equal(canon64(g64), canon64(s64))
+    finally:
+        ix.close()
