@@ -119,7 +119,8 @@ def main():
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=256, help="queries per step (each sweeps the index on its own)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="queries per step (each sweeps the index on its own); default 256, 512 when sharded (amortises the per-call pipeline drain over smaller shards)")
     ap.add_argument("--sim", default="COSINE", choices=["EUCLIDEAN", "COSINE", "MAXIMUM_INNER_PRODUCT"])
     ap.add_argument("--query-bits", type=int, default=4)
     ap.add_argument("--sub-batch", type=int, default=32, help="queries per device launch sequence (pipelined inside a step)")
@@ -157,6 +158,8 @@ def main():
         raise SystemExit("bench.py: no HIP device (libbbq has no CPU fallback)")
     torch.cuda.set_device(device)
 
+    if args.batch <= 0:
+        args.batch = 256 if world == 1 else 512
     N, dim, k, Q = args.rows, args.dim, args.k, args.batch
     SIM = {"EUCLIDEAN": 0, "COSINE": 1, "MAXIMUM_INNER_PRODUCT": 2}[args.sim]
     QB = args.query_bits
