@@ -26,6 +26,13 @@
 
 namespace bbq {
 
+// streamed, read-once data: non-temporal loads (A/B on MI355X: see DESIGN.md); -DBBQ_PLAIN_LOADS for the experiment
+#ifdef BBQ_PLAIN_LOADS
+#define BBQ_STREAM_LOAD(p) (*(p))
+#else
+#define BBQ_STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#endif
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
@@ -65,7 +72,7 @@ __device__ __forceinline__ void tile_popcounts(const uint8_t *__restrict__ tp, i
   if constexpr (W > 0) {
     u32x4 c[W];
 #pragma unroll
-    for (int j = 0; j < W; ++j) c[j] = __builtin_nontemporal_load(cp + j * kTileRows);
+    for (int j = 0; j < W; ++j) c[j] = BBQ_STREAM_LOAD(cp + j * kTileRows);
 #pragma unroll
     for (int j = 0; j < W; ++j) {
 #pragma unroll
@@ -74,7 +81,7 @@ __device__ __forceinline__ void tile_popcounts(const uint8_t *__restrict__ tp, i
     }
   } else {
     for (int j = 0; j < w16; ++j) {
-      const u32x4 c = __builtin_nontemporal_load(cp + j * kTileRows);
+      const u32x4 c = BBQ_STREAM_LOAD(cp + j * kTileRows);
 #pragma unroll
       for (int p = 0; p < QB; ++p) acc[p] += popc4(c & s_planes[j * QB + p]);
       ones += popc4(c);
@@ -172,16 +179,16 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) 
     double xadd = 0.0, x1 = 0.0;
     uint32_t cpk0 = 0, cpk1 = 0;
     if constexpr (!COMPACT) {
-      lu = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(cr) + lane);
-      xadd = __builtin_nontemporal_load(reinterpret_cast<const double *>(cr + 1024) + lane);
-      if (a.idx.has_x1) x1 = __builtin_nontemporal_load(reinterpret_cast<const double *>(cr + 1536) + lane);
+      lu = BBQ_STREAM_LOAD(reinterpret_cast<const f64x2 *>(cr) + lane);
+      xadd = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(cr + 1024) + lane);
+      if (a.idx.has_x1) x1 = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(cr + 1536) + lane);
     } else if constexpr (DENSE) {
       const f64x2 *__restrict__ ex = reinterpret_cast<const f64x2 *>(a.idx.exact + row * 4);
-      lu = __builtin_nontemporal_load(ex);
-      xadd = __builtin_nontemporal_load(reinterpret_cast<const double *>(ex + 1));
+      lu = BBQ_STREAM_LOAD(ex);
+      xadd = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(ex + 1));
     } else {
       typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-      const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(cr) + lane);
+      const u32x2 c = BBQ_STREAM_LOAD(reinterpret_cast<const u32x2 *>(cr) + lane);
       cpk0 = c.x;
       cpk1 = c.y;
     }
@@ -292,18 +299,18 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_shared_kernel(const ScanA
     const u32x4 *__restrict__ cp = reinterpret_cast<const u32x4 *>(tp) + lane;
     u32x4 c[W];
 #pragma unroll
-    for (int j = 0; j < W; ++j) c[j] = __builtin_nontemporal_load(cp + j * kTileRows);
+    for (int j = 0; j < W; ++j) c[j] = BBQ_STREAM_LOAD(cp + j * kTileRows);
     f64x2 lu = {0.0, 0.0};
     double xadd = 0.0, x1 = 0.0, al = 0.0, au = 0.0, aadd = 0.0;
     bool have_exact = false;
     if constexpr (!COMPACT) {
-      lu = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(cr) + lane);
-      xadd = __builtin_nontemporal_load(reinterpret_cast<const double *>(cr + 1024) + lane);
-      if (a.idx.has_x1) x1 = __builtin_nontemporal_load(reinterpret_cast<const double *>(cr + 1536) + lane);
+      lu = BBQ_STREAM_LOAD(reinterpret_cast<const f64x2 *>(cr) + lane);
+      xadd = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(cr + 1024) + lane);
+      if (a.idx.has_x1) x1 = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(cr + 1536) + lane);
       have_exact = true;
     } else {
       typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-      const u32x2 cc = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(cr) + lane);
+      const u32x2 cc = BBQ_STREAM_LOAD(reinterpret_cast<const u32x2 *>(cr) + lane);
       al = (double)__uint_as_float(cc.x << 16);
       au = (double)__uint_as_float(cc.x & 0xffff0000u);
       aadd = (double)__uint_as_float(cc.y);
