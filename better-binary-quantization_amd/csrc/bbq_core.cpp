@@ -123,7 +123,8 @@ struct bbq_index {
 
 namespace {
 
-int64_t qbuf_bytes_per_query_w(int w16) { return (int64_t)w16 * 8 * 16 + (int64_t)sizeof(QueryParams); }
+// per query: bit-planes (up to 8) + int8 values in MFMA fragment order + score uniforms + group maxima
+int64_t qbuf_bytes_per_query_w(int w16) { return (int64_t)w16 * 8 * 16 + (int64_t)w16 * 128 + (int64_t)sizeof(QueryParams) + 16; }
 
 std::mutex g_ctx_mu;
 DeviceCtx *g_ctx[64] = {nullptr};
@@ -310,7 +311,7 @@ void free_slot_buffers(Slot &s) {
   s.q_cap = 0;
 }
 
-int64_t qbuf_bytes_per_query(const bbq_index *ix) { return (int64_t)ix->w16 * 8 * 16 + (int64_t)sizeof(QueryParams); }
+int64_t qbuf_bytes_per_query(const bbq_index *ix) { return qbuf_bytes_per_query_w(ix->w16); }
 
 int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
   const Plan &p = ix->plan;
@@ -321,7 +322,7 @@ int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
                   (!own_lists || s.d_lists != nullptr);
   if (ok) return BBQ_OK;
   free_slot_buffers(s);
-  const int Q = (std::max(nq, ix->opt_batch) + 1) / 2 * 2;
+  const int Q = (std::max(nq, ix->opt_batch) + 31) / 32 * 32;  // multiple of 32: the MFMA query layout is per group of 32
   s.qbuf_bytes = qb;
   s.chunks_cap = std::max<int64_t>(p.max_chunks, 1);
   s.slots_cap = std::max<int64_t>(p.max_slots, 1);
@@ -355,6 +356,12 @@ struct PreparedQueries {
   int planes = 4;
   int one_bit = 0;
 };
+
+int max_value(const uint8_t *q, int64_t count) {
+  uint8_t m = 0;
+  for (int64_t i = 0; i < count; ++i) m = std::max(m, q[i]);
+  return m;
+}
 
 int planes_for(const uint8_t *q, int64_t count) {
   uint8_t m = 0;
@@ -390,6 +397,24 @@ void fill_query(const bbq_index *ix, uint8_t *planes_dst, QueryParams *pp, const
   pp->one_bit = one_bit;
 }
 
+// MFMA shared sweep: the int8 query values in the order the code bits fall out of the packed words.  For 32-dim word
+// g, half h (bits 16h..16h+15 of the little-endian word), dword c, byte i: bit p = 16h + 4c + i of the word is row byte
+// 4g + (p >> 3), bit (p & 7), i.e. dimension 32g + 8*(p >> 3) + 7 - (p & 7)  (MSB-first packing, src/optimizedScalarQuantizer.ts:420-446).
+// Layout: [group][g][h][n][16 B], n = query inside its group of 32.
+void fill_query_mfma(const bbq_index *ix, uint8_t *dst, int q_in_batch, const uint8_t *q) {
+  const int words = ix->w16 * 4, group = q_in_batch / 32, n = q_in_batch % 32;
+  uint8_t *gb = dst + (size_t)group * words * 2 * 32 * 16;
+  for (int g = 0; g < words; ++g)
+    for (int h = 0; h < 2; ++h) {
+      uint8_t *o = gb + (((size_t)g * 2 + h) * 32 + n) * 16;
+      for (int ci = 0; ci < 16; ++ci) {
+        const int p = 16 * h + ci;
+        const int d = 32 * g + 8 * (p >> 3) + 7 - (p & 7);
+        o[ci] = d < ix->dim ? q[d] : 0;
+      }
+    }
+}
+
 int validate_query_args(const bbq_index *ix, int32_t nq, const uint8_t *qquant, const double *qcorr, int32_t query_bits,
                         int32_t sim, int64_t k) {
   if (!ix) return fail(BBQ_ERR_INVALID_ARG, "目标向量集合不能为空");
@@ -412,6 +437,7 @@ struct BatchCtx {
   const double *qcorr;
   int planes, one_bit, sim;
   int64_t k;
+  int maxq = 255;  // largest quantized query value of the call (the MFMA sweep needs <= 127)
 };
 
 int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64_t *d_lists_ext, int64_t list_cap_ext,
@@ -424,7 +450,28 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
   for (int i = 0; i < nq; ++i)
     fill_query(ix, hp + (size_t)i * qb, hq + i, c.qquant + (size_t)(q_first + i) * ix->dim, c.qcorr + (size_t)(q_first + i) * 4,
                c.planes, c.one_bit, c.sim);
-  const size_t bytes = (size_t)nq * qb + (size_t)nq * sizeof(QueryParams);
+  size_t bytes = (size_t)nq * qb + (size_t)nq * sizeof(QueryParams);
+  const bool use_mfma = ix->opt_share == 32 && c.maxq <= 127;
+  size_t off_qbytes = 0, off_qmax = 0;
+  if (use_mfma) {  // second copy of the queries as int8 values in MFMA fragment order + per-group maxima for the pre-filter slack
+    const int groups = (nq + 31) / 32;
+    off_qbytes = (bytes + 15) / 16 * 16;
+    const size_t qbytes_len = (size_t)groups * 32 * ix->w16 * 128;
+    off_qmax = off_qbytes + qbytes_len;
+    bytes = off_qmax + (size_t)groups * 16;
+    memset(s.h_qbuf + off_qbytes, 0, qbytes_len);
+    float *qm = reinterpret_cast<float *>(s.h_qbuf + off_qmax);
+    for (int gidx = 0; gidx < groups; ++gidx) qm[4 * gidx] = qm[4 * gidx + 1] = qm[4 * gidx + 2] = qm[4 * gidx + 3] = 0.f;
+    for (int i = 0; i < nq; ++i) {
+      fill_query_mfma(ix, s.h_qbuf + off_qbytes, i, c.qquant + (size_t)(q_first + i) * ix->dim);
+      float *m = qm + 4 * (i / 32);
+      // upper bounds (rounded up) of the group's |ay|, |ly|, y1, |qadd - cdp|
+      m[0] = std::max(m[0], (float)(fabs(hq[i].ay) * 1.000001));
+      m[1] = std::max(m[1], (float)(fabs(hq[i].ly) * 1.000001));
+      m[2] = std::max(m[2], (float)(fabs(hq[i].y1) * 1.000001));
+      m[3] = std::max(m[3], (float)(fabs(hq[i].qadd - hq[i].cdp) * 1.000001));
+    }
+  }
   hipStream_t st = s.stream;
   HIPCHK(hipMemcpyAsync(s.d_qbuf, s.h_qbuf, bytes, hipMemcpyHostToDevice, st));
   uint64_t *d_lists = d_lists_ext ? d_lists_ext : s.d_lists;
@@ -454,7 +501,10 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
     if (g.big && ix->ctx->last_big_slot >= 0 && ix->ctx->last_big_slot != my_slot)
       HIPCHK(hipStreamWaitEvent(st, ix->slots[ix->ctx->last_big_slot].ev_big, 0));  // one big sweep at a time on the device
     if (g.dominant) HIPCHK(hipEventRecord(s.ev0, st));
-    if (!g.dense && ix->opt_share > 1 && shared_sweep_supported(a, ix->opt_share))
+    const bool mfma_here = use_mfma && !g.dense && mfma_sweep_supported(a);
+    if (mfma_here)
+      HIPCHK(launch_scan_mfma(a, s.d_qbuf + off_qbytes, reinterpret_cast<const float *>(s.d_qbuf + off_qmax), nq, (int)g.n_chunks, st));
+    else if (!g.dense && ix->opt_share > 1 && shared_sweep_supported(a, ix->opt_share))
       HIPCHK(launch_scan_shared(a, c.planes, ix->opt_share, nq, (int)g.n_chunks, st));
     else
       HIPCHK(launch_scan(a, c.planes, g.dense, nq, (int)g.n_chunks, st));
@@ -467,7 +517,7 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
       s.timed = true;
       s.timed_rows = g.rows * nq;
       // a shared sweep reads each row once for `share` queries
-      const int share = (!g.dense && ix->opt_share > 1 && shared_sweep_supported(a, ix->opt_share)) ? ix->opt_share : 1;
+      const int share = mfma_here ? 32 : (!g.dense && ix->opt_share > 1 && shared_sweep_supported(a, ix->opt_share)) ? ix->opt_share : 1;
       s.timed_bytes = g.rows * ((nq + share - 1) / share) * (int64_t)ix->bytes_per_row;
     }
     FinalizeArgs f{};
@@ -884,6 +934,7 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
 
   BatchCtx c{ix, qquant, qcorr, planes_for(qquant, (int64_t)n_queries * ix->dim), query_bits == 1 ? 1 : 0, sim, k};
   if (c.one_bit) c.planes = 1;
+  c.maxq = c.planes <= 4 ? 15 : max_value(qquant, (int64_t)n_queries * ix->dim);
   const int64_t keff = std::min<int64_t>(k, ix->n_rows);
   c.k = k;
   if (keff > kMaxFastK || ix->opt_force_dense) {
@@ -1083,7 +1134,7 @@ int bbq_set_option(bbq_index *ix, const char *name, int64_t v) {
   else if (n == "first_segment_rows" && v >= 1024 && v <= 8192 && v % kChunkRows == 0) { ix->opt_s0 = v; ix->plan.k = -1; }
   else if (n == "replay_threads" && v >= 1 && v <= 256) ix->opt_replay_threads = (int)v;
   else if (n == "force_dense" && (v == 0 || v == 1)) ix->opt_force_dense = (int)v;
-  else if (n == "sweep_share" && (v == 1 || v == 4 || v == 8)) ix->opt_share = (int)v;
+  else if (n == "sweep_share" && (v == 1 || v == 4 || v == 8 || v == 32)) ix->opt_share = (int)v;
   else return fail(BBQ_ERR_INVALID_ARG, "bbq_set_option: unknown option or value out of range: %s=%lld", name, (long long)v);
   ix->plan.k = -1;  // workspace is grow-only and re-checked by ensure_slot on the next call
   return BBQ_OK;

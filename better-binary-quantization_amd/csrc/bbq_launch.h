@@ -10,6 +10,9 @@ hipError_t launch_scan(const ScanArgs &a, int planes, bool dense, int n_queries,
 // shared sweep: `share` (4 or 8) queries per workgroup reuse every loaded row (sparse segments, fixed-width dims only)
 bool shared_sweep_supported(const ScanArgs &a, int share);
 hipError_t launch_scan_shared(const ScanArgs &a, int planes, int share, int n_queries, int n_chunks, hipStream_t s);
+// shared sweep on the matrix cores: 32 queries per workgroup (bbq_mfma_kernels.hip); query values must be <= 127
+bool mfma_sweep_supported(const ScanArgs &a);
+hipError_t launch_scan_mfma(const ScanArgs &a, const uint8_t *qbytes, const float *qmax, int n_queries, int n_chunks, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, int n_queries, hipStream_t s);
 hipError_t launch_pack(const int32_t *counts, const uint64_t *lists, int64_t list_cap, int32_t nq, int64_t *offsets, int32_t *flags_out,
                        int64_t *total_out, uint64_t *packed, int64_t packed_cap, hipStream_t s);

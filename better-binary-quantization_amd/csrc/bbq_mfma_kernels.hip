@@ -1,0 +1,321 @@
+// bbq_mfma_kernels.hip - shared sweep on the matrix cores (API extension; NOT the one-sweep-per-query path).
+//
+// With 32 queries sharing a sweep the integer dot products ARE a dense contraction,
+//     qcDist[row][query] = sum_d bit_d(row) * q[query][d],
+// and the VALU popcount formulation is bound by v_bcnt (bbq_kernels.hip: shared kernel, ~1.4x).  Here every wave expands
+// the 1-bit codes of its 64-row tile to int8 {0,1} fragments on the fly and multiplies them with the 32 queries' int8
+// values on v_mfma_i32_32x32x32_i8 (fragment layout verified on gfx950 by scripts/ubench/mfma_probe.hip:
+//   A[m = lane%32][k = 16*(lane/32)+i],  B[k][n = lane%32],  C[r] -> row (r&3) + 8*(r>>2) + 4*(lane/32), col lane%32).
+// The k -> dimension assignment is free as long as A and B agree, so the host lays the query bytes out in the order the
+// code bits fall out of the packed words (fill_query_mfma in bbq_core.cpp).
+//
+// Per (row, query) pair a cheap, provably conservative f32 pre-filter in "z-space" (the monotone argument of the
+// similarity transform) rejects almost everything; the rare survivors go through the f64 bound and the exact f64 score of
+// the one-sweep kernel, so the emitted candidates - and therefore the results - are identical.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include "bbq_device.h"
+#include "bbq_launch.h"
+
+#pragma clang fp contract(off)
+
+namespace bbq {
+
+typedef uint32_t u32x4m __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2m __attribute__((ext_vector_type(2)));
+typedef int i32x4m __attribute__((ext_vector_type(4)));
+typedef int i32x16m __attribute__((ext_vector_type(16)));
+typedef double f64x2m __attribute__((ext_vector_type(2)));
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+constexpr int kMfmaQueries = 32;
+
+// ---- exact pieces shared with bbq_kernels.hip (kept textually identical: same operation order) ----------------------
+__device__ __forceinline__ double m_js_max0(double x) { return (x != x) ? x : (x > 0.0 ? x : 0.0); }
+
+__device__ __forceinline__ double m_score_f64(double qc, double ax, double ux, double xadd, double x1, const QueryParams &p) {
+  const double lx = ux - ax;
+  const double t1 = (ax * p.ay) * p.dimd;
+  const double t2 = (p.ay * lx) * x1;
+  const double t3 = (ax * p.ly) * p.y1;
+  const double t4 = (lx * p.ly) * qc;
+  const double s = ((t1 + t2) + t3) + t4;
+  if (p.sim == 0) {
+    const double e = (p.qadd + xadd) - (2.0 * s);
+    return m_js_max0(1.0 / (1.0 + e));
+  }
+  const double t = p.one_bit ? (s + ((p.qadd + xadd) - p.cdp)) : (((s + p.qadd) + xadd) - p.cdp);
+  if (p.sim == 1) return m_js_max0((1.0 + t) / 2.0);
+  if (p.one_bit) return t < 0.0 ? 1.0 / (1.0 - t) : t + 1.0;
+  const double FBS = 1.0 / 15.0;
+  return t < 0.0 ? 1.0 / (1.0 - t / FBS) : t / FBS + 1.0;
+}
+
+// spread 4 bits (b0..b3 in the low nibble of x) to 4 bytes 0/1: bit i -> byte i
+__device__ __forceinline__ uint32_t spread4(uint32_t x) { return ((x & 0xFu) * 0x00204081u) & 0x01010101u; }
+
+// conservative lower edge, in z-space, of "score > theta" for one query (see the pre-filter below).
+//   COSINE / MIP: z = s + xadd,  score = f(z + qadd - cdp) with f increasing
+//   EUCLIDEAN   : z = 2s - xadd, score = 1/(1 + qadd - z)  increasing in z while the denominator is positive
+// Returns zmin with:  exact f32 score > theta_score  =>  z > zmin.   -inf accepts everything.
+__device__ __forceinline__ double z_threshold(uint32_t theta_key, const QueryParams &p) {
+  if (theta_key == 0u) return -DBL_MAX;
+  const uint32_t bits = (theta_key & 0x80000000u) ? (theta_key & 0x7fffffffu) : ~theta_key;
+  const double th = (double)__uint_as_float(bits);  // the threshold score (a float the reference produced)
+  if (!(th == th)) return -DBL_MAX;
+  double z;
+  if (p.sim == 1) {                 // max((1+t)/2, 0) > th  =>  t > 2 th - 1        (th >= 0 always for scores)
+    if (th < 0.0) return -DBL_MAX;
+    z = (2.0 * th - 1.0) - (p.qadd - p.cdp);
+  } else if (p.sim == 2) {
+    double t;
+    if (p.one_bit) t = th >= 1.0 ? th - 1.0 : (th > 0.0 ? 1.0 - 1.0 / th : -DBL_MAX);
+    else {
+      const double FBS = 1.0 / 15.0;
+      t = th >= 1.0 ? (th - 1.0) * FBS : (th > 0.0 ? (1.0 - 1.0 / th) * FBS : -DBL_MAX);
+    }
+    if (t == -DBL_MAX) return -DBL_MAX;
+    z = t - (p.qadd - p.cdp);
+  } else {                          // 1/(1+e) > th, e = qadd + xadd - 2s = qadd - z   =>  z > qadd + 1 - 1/th
+    if (!(th > 0.0)) return -DBL_MAX;
+    z = p.qadd + 1.0 - 1.0 / th;
+  }
+  if (!(fabs(z) <= DBL_MAX)) return -DBL_MAX;
+  return z - 1e-9 * (fabs(z) + fabs(p.qadd) + fabs(p.cdp) + 1.0);  // rounding allowance of this inversion
+}
+
+struct MfmaArgs {
+  ScanArgs s;
+  const uint8_t *qbytes;   // [groups][W*4 words][2 halves][32 queries][16 B]  int8 query values in fragment order
+  const float *qmax;       // [groups][4]: max |ay|, max |ly|, max y1, max |qadd - cdp| over the group's queries
+  int32_t nq_total;
+};
+
+// row constants of the pre-filter, per tile row (LDS): 3 x float4
+//   c0 = {R1, Rdx, x1, al}   c1 = {lx, addz, ea, eu}   c2 = {slack, -, -, -}
+template <int W, bool COMPACT>
+__global__ __launch_bounds__(kChunkRows) void bbq_scan_mfma_kernel(const MfmaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NT = kChunkRows;
+  constexpr int NW = kChunkRows / 64;
+  constexpr int WORDS = W * 4;
+  u32x4m *s_B = reinterpret_cast<u32x4m *>(smem);                                    // [WORDS*2][32]
+  f32x4m *s_row = reinterpret_cast<f32x4m *>(smem + (size_t)WORDS * 2 * 32 * 16);    // [NW][64][3]
+  QueryParams *s_qp = reinterpret_cast<QueryParams *>(s_row + NW * 64 * 3);          // [32]
+  double *s_zth = reinterpret_cast<double *>(s_qp + kMfmaQueries);                   // [32]
+  uint32_t *s_theta = reinterpret_cast<uint32_t *>(s_zth + kMfmaQueries);            // [32]
+  uint32_t *s_cnt = s_theta + kMfmaQueries;                                          // [32]
+  uint64_t *s_ent = reinterpret_cast<uint64_t *>(s_cnt + kMfmaQueries);              // [32][cap]
+
+  const int group = blockIdx.y;
+  const int q0 = group * kMfmaQueries;
+  const int nb = min(kMfmaQueries, a.nq_total - q0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, h = lane >> 5;
+  {
+    const u32x4m *__restrict__ gb = reinterpret_cast<const u32x4m *>(a.qbytes) + (size_t)group * WORDS * 2 * 32;
+    for (int i = tid; i < WORDS * 2 * 32; i += NT) s_B[i] = gb[i];
+    if (tid < kMfmaQueries) {
+      QueryParams p{};
+      uint32_t th = 0xFFFFFFFFu;  // lanes without a query accept nothing
+      if (tid < nb) { p = a.s.qparams[q0 + tid]; th = a.s.theta[q0 + tid]; }
+      s_qp[tid] = p;
+      s_theta[tid] = th;
+      s_zth[tid] = tid < nb ? z_threshold(th, p) : DBL_MAX;
+      s_cnt[tid] = 0;
+    }
+  }
+  __syncthreads();
+
+  const int64_t chunk = a.s.chunk_begin + blockIdx.x;
+  const int64_t n_tiles = (a.s.idx.n_rows + kTileRows - 1) / kTileRows;
+  const int64_t tile = chunk * kTilesPerChunk + wave;
+  uint32_t nan_seen = 0;
+
+  if (tile < n_tiles) {  // wave-uniform
+    const QueryParams p = s_qp[n];          // this lane's query (column n of the C tile)
+    const float zth = (float)s_zth[n];       // rounded; the compare below carries its own margin
+    const float zth_margin = 1e-6f * (fabsf(zth) + 1.0f);
+    const int sim = s_qp[0].sim;            // uniform over the call (lanes without a query hold zeros in p)
+    // per-query pre-filter constants, scaled into z-space (c_s = 2 for EUCLIDEAN, 1 otherwise)
+    const float cs = sim == 0 ? 2.0f : 1.0f;
+    const float ayq = (float)p.ay, lyq = (float)p.ly, y1q = (float)p.y1;
+    const float ayz = cs * ayq, lyz = cs * lyq;
+    const float *__restrict__ gm = a.qmax + (size_t)group * 4;
+    const float AYmax = gm[0], LYmax = gm[1], Y1max = gm[2];
+
+    const uint8_t *__restrict__ tp = a.s.idx.tiles + tile * (int64_t)a.s.idx.tile_stride;
+    const uint8_t *__restrict__ cr = tp + (size_t)W * (kTileRows * 16);
+    const int64_t row_l = tile * kTileRows + lane;  // the row whose codes this lane loads
+    const u32x4m *__restrict__ cp = reinterpret_cast<const u32x4m *>(tp) + lane;
+    u32x4m c[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) c[j] = __builtin_nontemporal_load(cp + j * kTileRows);
+    double al, au, aadd, ea, eu, eadd;
+    if constexpr (COMPACT) {
+      const u32x2m cc = __builtin_nontemporal_load(reinterpret_cast<const u32x2m *>(cr) + lane);
+      al = (double)__uint_as_float(cc.x << 16);
+      au = (double)__uint_as_float(cc.x & 0xffff0000u);
+      aadd = (double)__uint_as_float(cc.y);
+      const double rel = 0.0078125 * (1.0 + 1.0 / 65536.0);
+      ea = fabs(al) * rel + 1e-37;
+      eu = fabs(au) * rel + 1e-37;
+      eadd = fabs(aadd) * 1.1920928955078125e-07 + 1e-37;
+    } else {
+      const f64x2m lu = __builtin_nontemporal_load(reinterpret_cast<const f64x2m *>(cr) + lane);
+      al = lu.x; au = lu.y;
+      aadd = __builtin_nontemporal_load(reinterpret_cast<const double *>(cr + 1024) + lane);
+      // the f32 copies used by the pre-filter are rounded: 2^-24 relative
+      ea = fabs(al) * 6e-8 + 1e-37; eu = fabs(au) * 6e-8 + 1e-37; eadd = fabs(aadd) * 6e-8 + 1e-37;
+    }
+    uint32_t ones = 0;
+#pragma unroll
+    for (int j = 0; j < W; ++j) ones += __popc(c[j].x) + __popc(c[j].y) + __popc(c[j].z) + __popc(c[j].w);
+    double x1row = (double)ones;  // quantizedComponentSum of a 1-bit row is its popcount ...
+    if (a.s.idx.has_x1) x1row = reinterpret_cast<const double *>(cr + 1536)[lane];  // ... unless the index says otherwise
+    {  // row constants of the pre-filter for MY row -> LDS (read back per C element by the lanes that own it)
+      const double D = s_qp[0].dimd;   // same for every query of the batch
+      const double x1 = x1row, lx = au - al;
+      const double R1 = al * D + lx * x1;
+      const double cs_d = sim == 0 ? 2.0 : 1.0, ca_d = sim == 0 ? -1.0 : 1.0;
+      // f32 evaluation slack: 8 roundings of terms bounded with the group's largest query constants, doubled
+      const double F = (double)AYmax * fabs(R1) + (double)LYmax * (double)Y1max * (fabs(al) + fabs(lx)) + fabs(aadd) + 1.0;
+      const double slack = cs_d * (2e-6 * F + 1e-3 * (ea + eu) * ((double)AYmax * D + 2.0 * (double)LYmax * (double)Y1max)) + eadd * 1.001;
+      f32x4m k0, k1, k2;
+      k0.x = (float)R1; k0.y = (float)(D - x1); k0.z = (float)x1; k0.w = (float)al;
+      k1.x = (float)lx; k1.y = (float)(ca_d * aadd); k1.z = (float)(cs_d * ea * 1.001); k1.w = (float)(cs_d * eu * 1.001);
+      // non-finite or huge rows: force a pass (NaN slack compares false below -> handled by the explicit flag)
+      const bool weird = !(fabs(R1) + fabs(al) + fabs(lx) + fabs(aadd) < 1e30);
+      k2.x = weird ? __uint_as_float(0x7f800000u) : (float)slack * 1.001f + 1e-30f;
+      k2.y = k2.z = k2.w = 0.f;
+      f32x4m *dst = s_row + ((size_t)wave * 64 + lane) * 3;
+      dst[0] = k0; dst[1] = k1; dst[2] = k2;
+    }
+
+    // ---- the contraction: 2 row groups x WORDS k-steps of 32 dims
+    i32x16m acc0 = {0}, acc1 = {0};
+#pragma unroll
+    for (int g = 0; g < WORDS; ++g) {
+      const uint32_t w = (g & 3) == 0 ? c[g >> 2].x : (g & 3) == 1 ? c[g >> 2].y : (g & 3) == 2 ? c[g >> 2].z : c[g >> 2].w;
+      const uint32_t sw = (uint32_t)__shfl_xor((int)w, 32, 64);  // partner half's word (rows +-32)
+      const uint32_t a0w = h == 0 ? w : sw;   // row group 0 (tile rows 0..31):  A row m = lane%32
+      const uint32_t a1w = h == 0 ? sw : w;   // row group 1 (tile rows 32..63)
+      const uint32_t b0 = (a0w >> (16 * h)) & 0xFFFFu, b1 = (a1w >> (16 * h)) & 0xFFFFu;
+      i32x4m A0, A1;
+      A0.x = (int)spread4(b0); A0.y = (int)spread4(b0 >> 4); A0.z = (int)spread4(b0 >> 8); A0.w = (int)spread4(b0 >> 12);
+      A1.x = (int)spread4(b1); A1.y = (int)spread4(b1 >> 4); A1.z = (int)spread4(b1 >> 8); A1.w = (int)spread4(b1 >> 12);
+      const u32x4m bq = s_B[(g * 2 + h) * 32 + n];
+      i32x4m Bf;
+      Bf.x = (int)bq.x; Bf.y = (int)bq.y; Bf.z = (int)bq.z; Bf.w = (int)bq.w;
+      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, Bf, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, Bf, acc1, 0, 0, 0);
+    }
+
+    // ---- per (row, query) pre-filter; this lane owns query n and 16 rows of each row group
+    const bool have_q = n < nb;
+    const uint32_t theta = s_theta[n];
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rit = 32 * rg + (r & 3) + 8 * (r >> 2) + 4 * h;  // row in tile
+        const int qc = rg == 0 ? acc0[r] : acc1[r];
+        const f32x4m *__restrict__ rc = s_row + ((size_t)wave * 64 + rit) * 3;
+        const f32x4m k0 = rc[0], k1 = rc[1];
+        const float slack = rc[2].x;
+        const float qcf = (float)qc;
+        const float u = fmaf(k1.x, qcf, k0.w * y1q);                 // al*y1 + lx*qc
+        const float z = fmaf(lyz, u, fmaf(ayz, k0.x, k1.y));         // cs*(ay*R1 + ly*u) + ca*add
+        const float Ae = fmaf(lyq, y1q - qcf, ayq * k0.y);           // ay*(D-x1) + ly*(y1-qc)
+        const float Be = fmaf(lyq, qcf, ayq * k0.z);                 // ay*x1 + ly*qc
+        const float err = fmaf(fabsf(Ae), k1.z, fmaf(fabsf(Be), k1.w, slack));
+        const bool pass = have_q && !((z + err) <= (zth - zth_margin));  // NaN / inf anywhere => pass
+        if (pass) {
+          const int64_t row = tile * kTileRows + rit;
+          if (row < a.s.idx.n_rows) {
+            const double *__restrict__ ex;
+            double lo, up, ad, x1d;
+            if constexpr (COMPACT) {
+              ex = a.s.idx.exact + row * 4;
+              lo = ex[0]; up = ex[1]; ad = ex[2];
+            } else {
+              const uint8_t *crr = cr;
+              lo = reinterpret_cast<const double *>(crr)[2 * rit];
+              up = reinterpret_cast<const double *>(crr)[2 * rit + 1];
+              ad = reinterpret_cast<const double *>(crr + 1024)[rit];
+            }
+            x1d = (double)k0.z;  // popcount of the row: exact in f32 (<= 2^24)
+            if (a.s.idx.has_x1) x1d = reinterpret_cast<const double *>(cr + 1536)[rit];  // explicit sums may not be f32-exact
+            const double s64 = m_score_f64((double)qc, lo, up, ad, x1d, p);
+            const float s32 = (float)s64;
+            const uint32_t bits = __float_as_uint(s32);
+            if (s32 != s32) nan_seen = 1;
+            if ((s32 == s32) && key_of_bits(bits) > theta) {
+              const uint32_t slot = atomicAdd(&s_cnt[n], 1u);
+              if (slot < (uint32_t)a.s.cap) s_ent[(size_t)n * a.s.cap + slot] = ((uint64_t)(uint32_t)(a.s.row_id_base + row) << 32) | bits;
+            }
+          }
+        }
+      }
+    }
+    (void)row_l;
+  }
+  if (nan_seen && n < nb) atomicOr(a.s.flags + q0 + n, kFlagNaN);
+
+  __syncthreads();
+  for (int b = 0; b < nb; ++b) {
+    uint32_t cnt = s_cnt[b];
+    if (cnt > (uint32_t)a.s.cap) {
+      if (tid == 0) atomicOr(a.s.flags + q0 + b, kFlagOverflow);
+      cnt = (uint32_t)a.s.cap;
+    }
+    const uint64_t *__restrict__ src = s_ent + (size_t)b * a.s.cap;
+    uint64_t *__restrict__ out = a.s.entries + ((size_t)(q0 + b) * a.s.n_chunks + blockIdx.x) * (size_t)a.s.cap;
+    for (uint32_t i = tid; i < cnt; i += NT) {
+      const uint64_t e = src[i];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < cnt; ++j) rank += (src[j] < e) ? 1u : 0u;
+      out[rank] = e;
+    }
+    if (tid == 0) a.s.counts[(size_t)(q0 + b) * a.s.n_chunks + blockIdx.x] = cnt;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+
+template <int W, bool COMPACT>
+static hipError_t launch_mfma_t(const MfmaArgs &a, int nq, int nc, hipStream_t s) {
+  constexpr int NW = kChunkRows / 64;
+  const size_t smem = (size_t)W * 4 * 2 * 32 * 16 + (size_t)NW * 64 * 3 * 16 + kMfmaQueries * (sizeof(QueryParams) + 8 + 4 + 4) +
+                      (size_t)kMfmaQueries * a.s.cap * 8 + 64;
+  dim3 grid((unsigned)nc, (unsigned)((nq + kMfmaQueries - 1) / kMfmaQueries), 1), block(kChunkRows, 1, 1);
+  auto kern = bbq_scan_mfma_kernel<W, COMPACT>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, grid, block, smem, s, a);
+  return hipGetLastError();
+}
+
+bool mfma_sweep_supported(const ScanArgs &a) {
+  const int w = a.idx.w16;
+  if (!(w == 1 || w == 6 || w == 8 || w == 12)) return false;
+  const size_t smem = (size_t)w * 4 * 2 * 32 * 16 + (size_t)(kChunkRows / 64) * 64 * 3 * 16 + 4096 + (size_t)kMfmaQueries * a.cap * 8;
+  return smem <= 150 * 1024;
+}
+
+hipError_t launch_scan_mfma(const ScanArgs &sa, const uint8_t *qbytes, const float *qmax, int n_queries, int n_chunks, hipStream_t s) {
+  if (n_chunks <= 0 || n_queries <= 0) return hipSuccess;
+  MfmaArgs a{sa, qbytes, qmax, n_queries};
+  const bool compact = sa.idx.layout == kLayoutCompact;
+  switch (sa.idx.w16) {
+    case 1: return compact ? launch_mfma_t<1, true>(a, n_queries, n_chunks, s) : launch_mfma_t<1, false>(a, n_queries, n_chunks, s);
+    case 6: return compact ? launch_mfma_t<6, true>(a, n_queries, n_chunks, s) : launch_mfma_t<6, false>(a, n_queries, n_chunks, s);
+    case 8: return compact ? launch_mfma_t<8, true>(a, n_queries, n_chunks, s) : launch_mfma_t<8, false>(a, n_queries, n_chunks, s);
+    case 12: return compact ? launch_mfma_t<12, true>(a, n_queries, n_chunks, s) : launch_mfma_t<12, false>(a, n_queries, n_chunks, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace bbq

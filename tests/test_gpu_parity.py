@@ -428,8 +428,9 @@ def test_device_index_build_errors_and_odd_shapes():
 
 
 @pytest.mark.parametrize("compact", [True, False])
-@pytest.mark.parametrize("share", [4, 8])
-@pytest.mark.parametrize("name", ["ties_cos_qb4", "big_20000x128_cos", "ties_16d_qb1", "m_768d_max_qb4", "big_30000x1536_mip"])
+@pytest.mark.parametrize("share", [4, 8, 32])
+@pytest.mark.parametrize("name", ["ties_cos_qb4", "big_20000x128_cos", "ties_16d_qb1", "m_768d_max_qb4", "big_30000x1536_mip",
+                                  "ties_euc_qb4", "ties_max_qb4", "m_768d_euc_qb1", "qb8_128d_cos", "big_50000x768_cos"])
 def test_shared_sweep_gives_identical_results(name, share, compact):
     """API extension: several queries per sweep (one load of each row, `share` queries scored from registers).
     Must return exactly what one-sweep-per-query returns."""
@@ -441,7 +442,7 @@ def test_shared_sweep_gives_identical_results(name, share, compact):
         ix.set_option("segment_growth", 2)
         ix.set_option("sweep_share", share)
         rng = np.random.default_rng(4)
-        extra = rng.standard_normal((11, g["dim"])).astype(np.float32)       # 11 + nq queries: not a multiple of `share`
+        extra = rng.standard_normal((37, g["dim"])).astype(np.float32)       # 37 + nq queries: not a multiple of `share`
         allq = np.concatenate([queries, extra])
         qs = [B.quantize_query(q, cen, sim, g["qb"], g["lambda"], g["iters"]) for q in allq]
         qq, qc = np.stack([a for a, _ in qs]), np.stack([b for _, b in qs])
@@ -489,12 +490,13 @@ def test_full_size_10m_x_768_properties():
         ix.set_option("force_dense", 0)
         np.testing.assert_array_equal(di, idx[:2])
         np.testing.assert_array_equal(ds.view(np.uint32), sc[:2].view(np.uint32))
-        # (4) shared sweep == one sweep per query
-        ix.set_option("sweep_share", 8)
-        si, ss, _ = ix.search_batch(qq, qc, 4, 1, k)
+        # (4) shared sweeps (VALU and matrix-core variants) == one sweep per query
+        for share in (8, 32):
+            ix.set_option("sweep_share", share)
+            si, ss, _ = ix.search_batch(qq, qc, 4, 1, k)
+            np.testing.assert_array_equal(si, idx)
+            np.testing.assert_array_equal(ss.view(np.uint32), sc.view(np.uint32))
         ix.set_option("sweep_share", 1)
-        np.testing.assert_array_equal(si, idx)
-        np.testing.assert_array_equal(ss.view(np.uint32), sc.view(np.uint32))
     finally:
         ix.close()
     # (5) inline layout
