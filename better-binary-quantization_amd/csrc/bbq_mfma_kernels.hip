@@ -91,8 +91,11 @@ struct MfmaArgs {
   int32_t nq_total;
 };
 
-// row constants of the pre-filter, per tile row (LDS): 3 x float4
-//   c0 = {R1, Rdx, x1, al}   c1 = {lx, addz, ea, eu}   c2 = {slack, -, -, -}
+// row constants of the pre-filter, per tile row (LDS): 2 x float4
+//   c0 = {R1, Rdx, x1, al}   c1 = {lx, addz + slack, ea, eu}
+// Pairs that pass the pre-filter are pushed to a per-wave LDS queue (packed qc | row-in-tile << 20 | query << 26) and
+// scored exactly afterwards by ONE copy of the exact code, 64 pairs at a time.
+constexpr int kMfmaQueueCap = 512;
 template <int W, bool COMPACT>
 __global__ __launch_bounds__(kChunkRows) void bbq_scan_mfma_kernel(const MfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -100,8 +103,10 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_mfma_kernel(const MfmaArg
   constexpr int NW = kChunkRows / 64;
   constexpr int WORDS = W * 4;
   u32x4m *s_B = reinterpret_cast<u32x4m *>(smem);                                    // [WORDS*2][32]
-  f32x4m *s_row = reinterpret_cast<f32x4m *>(smem + (size_t)WORDS * 2 * 32 * 16);    // [NW][64][3]
-  QueryParams *s_qp = reinterpret_cast<QueryParams *>(s_row + NW * 64 * 3);          // [32]
+  f32x4m *s_row = reinterpret_cast<f32x4m *>(smem + (size_t)WORDS * 2 * 32 * 16);    // [NW][64][2]
+  uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_row + NW * 64 * 2);             // [NW][kMfmaQueueCap]
+  uint32_t *s_qcount = s_queue + NW * kMfmaQueueCap;                                 // [NW] (+ padding to 16 B)
+  QueryParams *s_qp = reinterpret_cast<QueryParams *>(s_qcount + 8);                 // [32]
   double *s_zth = reinterpret_cast<double *>(s_qp + kMfmaQueries);                   // [32]
   uint32_t *s_theta = reinterpret_cast<uint32_t *>(s_zth + kMfmaQueries);            // [32]
   uint32_t *s_cnt = s_theta + kMfmaQueries;                                          // [32]
@@ -124,13 +129,13 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_mfma_kernel(const MfmaArg
       s_zth[tid] = tid < nb ? z_threshold(th, p) : DBL_MAX;
       s_cnt[tid] = 0;
     }
+    if (tid < NW) s_qcount[tid] = 0;
   }
   __syncthreads();
 
   const int64_t chunk = a.s.chunk_begin + blockIdx.x;
   const int64_t n_tiles = (a.s.idx.n_rows + kTileRows - 1) / kTileRows;
   const int64_t tile = chunk * kTilesPerChunk + wave;
-  uint32_t nan_seen = 0;
 
   if (tile < n_tiles) {  // wave-uniform
     const QueryParams p = s_qp[n];          // this lane's query (column n of the C tile)
@@ -181,15 +186,15 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_mfma_kernel(const MfmaArg
       // f32 evaluation slack: 8 roundings of terms bounded with the group's largest query constants, doubled
       const double F = (double)AYmax * fabs(R1) + (double)LYmax * (double)Y1max * (fabs(al) + fabs(lx)) + fabs(aadd) + 1.0;
       const double slack = cs_d * (2e-6 * F + 1e-3 * (ea + eu) * ((double)AYmax * D + 2.0 * (double)LYmax * (double)Y1max)) + eadd * 1.001;
-      f32x4m k0, k1, k2;
+      f32x4m k0, k1;
       k0.x = (float)R1; k0.y = (float)(D - x1); k0.z = (float)x1; k0.w = (float)al;
-      k1.x = (float)lx; k1.y = (float)(ca_d * aadd); k1.z = (float)(cs_d * ea * 1.001); k1.w = (float)(cs_d * eu * 1.001);
-      // non-finite or huge rows: force a pass (NaN slack compares false below -> handled by the explicit flag)
+      // non-finite or huge rows: force a pass (an infinite slack makes every compare below fail to reject)
       const bool weird = !(fabs(R1) + fabs(al) + fabs(lx) + fabs(aadd) < 1e30);
-      k2.x = weird ? __uint_as_float(0x7f800000u) : (float)slack * 1.001f + 1e-30f;
-      k2.y = k2.z = k2.w = 0.f;
-      f32x4m *dst = s_row + ((size_t)wave * 64 + lane) * 3;
-      dst[0] = k0; dst[1] = k1; dst[2] = k2;
+      const float slack32 = weird ? __uint_as_float(0x7f800000u) : (float)slack * 1.001f + 1e-30f;
+      k1.x = (float)lx; k1.y = (float)(ca_d * aadd) + slack32; k1.z = (float)(cs_d * ea * 1.001); k1.w = (float)(cs_d * eu * 1.001);
+      // (float)(ca*aadd) + slack32 rounds once more: one extra ulp of |ca*aadd| is inside the 1.001 factors of slack (eadd part)
+      f32x4m *dst = s_row + ((size_t)wave * 64 + lane) * 2;
+      dst[0] = k0; dst[1] = k1;
     }
 
     // ---- the contraction: 2 row groups x WORDS k-steps of 32 dims
@@ -213,55 +218,59 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_mfma_kernel(const MfmaArg
 
     // ---- per (row, query) pre-filter; this lane owns query n and 16 rows of each row group
     const bool have_q = n < nb;
-    const uint32_t theta = s_theta[n];
+    uint32_t *__restrict__ queue = s_queue + (size_t)wave * kMfmaQueueCap;
+    const int rows_here = (int)min((int64_t)kTileRows, a.s.idx.n_rows - tile * kTileRows);
 #pragma unroll
     for (int rg = 0; rg < 2; ++rg) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rit = 32 * rg + (r & 3) + 8 * (r >> 2) + 4 * h;  // row in tile
         const int qc = rg == 0 ? acc0[r] : acc1[r];
-        const f32x4m *__restrict__ rc = s_row + ((size_t)wave * 64 + rit) * 3;
+        const f32x4m *__restrict__ rc = s_row + ((size_t)wave * 64 + rit) * 2;
         const f32x4m k0 = rc[0], k1 = rc[1];
-        const float slack = rc[2].x;
         const float qcf = (float)qc;
         const float u = fmaf(k1.x, qcf, k0.w * y1q);                 // al*y1 + lx*qc
-        const float z = fmaf(lyz, u, fmaf(ayz, k0.x, k1.y));         // cs*(ay*R1 + ly*u) + ca*add
+        const float z = fmaf(lyz, u, fmaf(ayz, k0.x, k1.y));         // cs*(ay*R1 + ly*u) + ca*add + slack
         const float Ae = fmaf(lyq, y1q - qcf, ayq * k0.y);           // ay*(D-x1) + ly*(y1-qc)
         const float Be = fmaf(lyq, qcf, ayq * k0.z);                 // ay*x1 + ly*qc
-        const float err = fmaf(fabsf(Ae), k1.z, fmaf(fabsf(Be), k1.w, slack));
-        const bool pass = have_q && !((z + err) <= (zth - zth_margin));  // NaN / inf anywhere => pass
+        const float zu = fmaf(fabsf(Ae), k1.z, fmaf(fabsf(Be), k1.w, z));
+        const bool pass = have_q && rit < rows_here && !(zu <= (zth - zth_margin));  // NaN / inf anywhere => pass
         if (pass) {
-          const int64_t row = tile * kTileRows + rit;
-          if (row < a.s.idx.n_rows) {
-            const double *__restrict__ ex;
-            double lo, up, ad, x1d;
-            if constexpr (COMPACT) {
-              ex = a.s.idx.exact + row * 4;
-              lo = ex[0]; up = ex[1]; ad = ex[2];
-            } else {
-              const uint8_t *crr = cr;
-              lo = reinterpret_cast<const double *>(crr)[2 * rit];
-              up = reinterpret_cast<const double *>(crr)[2 * rit + 1];
-              ad = reinterpret_cast<const double *>(crr + 1024)[rit];
-            }
-            x1d = (double)k0.z;  // popcount of the row: exact in f32 (<= 2^24)
-            if (a.s.idx.has_x1) x1d = reinterpret_cast<const double *>(cr + 1536)[rit];  // explicit sums may not be f32-exact
-            const double s64 = m_score_f64((double)qc, lo, up, ad, x1d, p);
-            const float s32 = (float)s64;
-            const uint32_t bits = __float_as_uint(s32);
-            if (s32 != s32) nan_seen = 1;
-            if ((s32 == s32) && key_of_bits(bits) > theta) {
-              const uint32_t slot = atomicAdd(&s_cnt[n], 1u);
-              if (slot < (uint32_t)a.s.cap) s_ent[(size_t)n * a.s.cap + slot] = ((uint64_t)(uint32_t)(a.s.row_id_base + row) << 32) | bits;
-            }
-          }
+          const uint32_t slot = atomicAdd(&s_qcount[wave], 1u);
+          if (slot < (uint32_t)kMfmaQueueCap) queue[slot] = (uint32_t)qc | ((uint32_t)rit << 20) | ((uint32_t)n << 26);
+          else atomicOr(a.s.flags + q0 + n, kFlagOverflow);  // more survivors than the queue holds: this query goes dense
         }
+      }
+    }
+    // ---- exact scores of the survivors (same-wave LDS traffic: program order is enough)
+    const uint32_t n_pass = min(s_qcount[wave], (uint32_t)kMfmaQueueCap);
+    for (uint32_t i = lane; i < n_pass; i += 64) {
+      const uint32_t e = queue[i];
+      const int qc = (int)(e & 0xFFFFFu), rit = (int)((e >> 20) & 63u), qn = (int)(e >> 26);
+      const QueryParams pq = s_qp[qn];
+      const int64_t row = tile * kTileRows + rit;
+      double lo, up, ad;
+      if constexpr (COMPACT) {
+        const double *__restrict__ ex = a.s.idx.exact + row * 4;
+        lo = ex[0]; up = ex[1]; ad = ex[2];
+      } else {
+        lo = reinterpret_cast<const double *>(cr)[2 * rit];
+        up = reinterpret_cast<const double *>(cr)[2 * rit + 1];
+        ad = reinterpret_cast<const double *>(cr + 1024)[rit];
+      }
+      double x1d = (double)s_row[((size_t)wave * 64 + rit) * 2].z;  // popcount of the row: exact in f32 (<= 2^24)
+      if (a.s.idx.has_x1) x1d = reinterpret_cast<const double *>(cr + 1536)[rit];  // explicit sums may not be f32-exact
+      const double s64 = m_score_f64((double)qc, lo, up, ad, x1d, pq);
+      const float s32 = (float)s64;
+      const uint32_t bits = __float_as_uint(s32);
+      if (s32 != s32) atomicOr(a.s.flags + q0 + qn, kFlagNaN);
+      else if (key_of_bits(bits) > s_theta[qn]) {
+        const uint32_t slot = atomicAdd(&s_cnt[qn], 1u);
+        if (slot < (uint32_t)a.s.cap) s_ent[(size_t)qn * a.s.cap + slot] = ((uint64_t)(uint32_t)(a.s.row_id_base + row) << 32) | bits;
       }
     }
     (void)row_l;
   }
-  if (nan_seen && n < nb) atomicOr(a.s.flags + q0 + n, kFlagNaN);
-
   __syncthreads();
   for (int b = 0; b < nb; ++b) {
     uint32_t cnt = s_cnt[b];
@@ -286,8 +295,8 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_mfma_kernel(const MfmaArg
 template <int W, bool COMPACT>
 static hipError_t launch_mfma_t(const MfmaArgs &a, int nq, int nc, hipStream_t s) {
   constexpr int NW = kChunkRows / 64;
-  const size_t smem = (size_t)W * 4 * 2 * 32 * 16 + (size_t)NW * 64 * 3 * 16 + kMfmaQueries * (sizeof(QueryParams) + 8 + 4 + 4) +
-                      (size_t)kMfmaQueries * a.s.cap * 8 + 64;
+  const size_t smem = (size_t)W * 4 * 2 * 32 * 16 + (size_t)NW * 64 * 2 * 16 + (size_t)NW * kMfmaQueueCap * 4 + 32 +
+                      kMfmaQueries * (sizeof(QueryParams) + 8 + 4 + 4) + (size_t)kMfmaQueries * a.s.cap * 8 + 64;
   dim3 grid((unsigned)nc, (unsigned)((nq + kMfmaQueries - 1) / kMfmaQueries), 1), block(kChunkRows, 1, 1);
   auto kern = bbq_scan_mfma_kernel<W, COMPACT>;
   if (smem > 64 * 1024) {
@@ -301,7 +310,7 @@ static hipError_t launch_mfma_t(const MfmaArgs &a, int nq, int nc, hipStream_t s
 bool mfma_sweep_supported(const ScanArgs &a) {
   const int w = a.idx.w16;
   if (!(w == 1 || w == 6 || w == 8 || w == 12)) return false;
-  const size_t smem = (size_t)w * 4 * 2 * 32 * 16 + (size_t)(kChunkRows / 64) * 64 * 3 * 16 + 4096 + (size_t)kMfmaQueries * a.cap * 8;
+  const size_t smem = (size_t)w * 4 * 2 * 32 * 16 + (size_t)(kChunkRows / 64) * (64 * 2 * 16 + kMfmaQueueCap * 4) + 4096 + (size_t)kMfmaQueries * a.cap * 8;
   return smem <= 150 * 1024;
 }
 
