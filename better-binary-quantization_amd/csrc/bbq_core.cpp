@@ -15,6 +15,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -71,8 +75,12 @@ struct Slot {
   int32_t *d_topk_counts = nullptr, *d_list_counts = nullptr, *h_list_counts = nullptr;
   uint64_t *d_entries = nullptr, *d_lists = nullptr, *h_lists = nullptr;
   float *d_dense0 = nullptr;
-  // in-flight sub-batch
+  // in-flight sub-batch: busy = device work enqueued and not yet collected; replaying = host replay jobs outstanding
   bool busy = false;
+  bool replaying = false;
+  std::atomic<int> pending{0};
+  std::vector<std::vector<uint64_t>> tails;
+  std::vector<int> dense_q;
   int nq = 0;
   int64_t q_first = 0;
   bool timed = false;
@@ -125,6 +133,45 @@ namespace {
 
 // per query: bit-planes (up to 8) + int8 values in MFMA fragment order + score uniforms + group maxima
 int64_t qbuf_bytes_per_query_w(int w16) { return (int64_t)w16 * 8 * 16 + (int64_t)w16 * 128 + (int64_t)sizeof(QueryParams) + 16; }
+
+// Host worker pool for the heap replays: persistent threads (spawning per sub-batch cost more than the replay itself
+// once sweeps are shared), fed while the device already works on the next sub-batches.
+class ReplayPool {
+ public:
+  static ReplayPool &get() {
+    static ReplayPool *p = new ReplayPool();  // intentionally never destroyed: workers may outlive static destructors
+    return *p;
+  }
+  void ensure(int n) {
+    std::lock_guard<std::mutex> lk(m_);
+    while ((int)th_.size() < n) th_.emplace_back([this] { run(); });
+  }
+  void submit(std::function<void()> f) {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      q_.push_back(std::move(f));
+    }
+    cv_.notify_one();
+  }
+
+ private:
+  void run() {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [this] { return !q_.empty(); });
+        f = std::move(q_.front());
+        q_.pop_front();
+      }
+      f();
+    }
+  }
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<std::function<void()>> q_;
+  std::vector<std::thread> th_;
+};
 
 std::mutex g_ctx_mu;
 DeviceCtx *g_ctx[64] = {nullptr};
@@ -608,25 +655,28 @@ int dense_search_one(const BatchCtx &c, int64_t qi, int32_t *out_idx, float *out
   return BBQ_OK;
 }
 
-int complete_subbatch(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score, int64_t *out_n) {
+// device work of the slot's sub-batch is done: collect it and start the heap replays (on the pool when replay_threads > 1)
+int begin_replay(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score, int64_t *out_n) {
   bbq_index *ix = c.ix;
   HIPCHK(hipEventSynchronize(s.ev_done));
   s.busy = false;
   account_timing(ix, s);
   const int nq = s.nq;
-  std::vector<int> dense_q;
-  std::vector<std::vector<uint64_t>> tails((size_t)nq);
+  s.dense_q.clear();
+  s.tails.assign((size_t)nq, std::vector<uint64_t>());
   for (int i = 0; i < nq; ++i) {
     const int32_t cnt = s.h_list_counts[2 * i], flags = s.h_list_counts[2 * i + 1];
-    if (flags != 0) { dense_q.push_back(i); continue; }
+    if (flags != 0) { s.dense_q.push_back(i); continue; }
     if (cnt > s.hprefix) {  // rare: fetch what the prefix copy did not cover
-      tails[(size_t)i].resize((size_t)(cnt - s.hprefix));
-      HIPCHK(hipMemcpy(tails[(size_t)i].data(), s.d_lists + (size_t)i * s.list_cap + s.hprefix, (size_t)(cnt - s.hprefix) * 8,
+      s.tails[(size_t)i].resize((size_t)(cnt - s.hprefix));
+      HIPCHK(hipMemcpy(s.tails[(size_t)i].data(), s.d_lists + (size_t)i * s.list_cap + s.hprefix, (size_t)(cnt - s.hprefix) * 8,
                        hipMemcpyDeviceToHost));
     }
   }
   const int64_t k = c.k, n_total = ix->main.row_id_base + ix->main.view.n_rows;
-  auto replay_range = [&](int lo, int hi) {
+  Slot *sp = &s;
+  auto replay_range = [sp, k, n_total, out_idx, out_score, out_n](int lo, int hi) {
+    Slot &s = *sp;
     for (int i = lo; i < hi; ++i) {
       const int32_t cnt = s.h_list_counts[2 * i], flags = s.h_list_counts[2 * i + 1];
       if (flags != 0) continue;
@@ -639,7 +689,7 @@ int complete_subbatch(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_s
         memcpy(&sc, &bits, 4);
         hr.offer(sc, (int32_t)(uint32_t)(l[j] >> 32));
       }
-      for (uint64_t e : tails[(size_t)i]) {
+      for (uint64_t e : s.tails[(size_t)i]) {
         const uint32_t bits = (uint32_t)e;
         float sc;
         memcpy(&sc, &bits, 4);
@@ -650,21 +700,48 @@ int complete_subbatch(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_s
     }
   };
   const int T = std::min(ix->opt_replay_threads, nq);
+  s.replaying = true;
   if (T <= 1) {
     replay_range(0, nq);
   } else {
-    std::vector<std::thread> th;
-    for (int t = 0; t < T; ++t) th.emplace_back(replay_range, (int)((int64_t)nq * t / T), (int)((int64_t)nq * (t + 1) / T));
-    for (auto &x : th) x.join();
+    ReplayPool &pool = ReplayPool::get();
+    pool.ensure(ix->opt_replay_threads);
+    const int jobs = std::min(nq, T * 2);  // a few more jobs than threads: uneven lists balance out
+    s.pending.store(jobs);
+    for (int t = 0; t < jobs; ++t) {
+      const int lo = (int)((int64_t)nq * t / jobs), hi = (int)((int64_t)nq * (t + 1) / jobs);
+      pool.submit([sp, replay_range, lo, hi] {
+        replay_range(lo, hi);
+        sp->pending.fetch_sub(1, std::memory_order_release);
+      });
+    }
   }
-  for (int i = 0; i < nq; ++i)
+  return BBQ_OK;
+}
+
+// waits for the slot's replays, then serves the queries the device could not bound (dense path)
+int finish_replay(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score, int64_t *out_n) {
+  bbq_index *ix = c.ix;
+  while (s.pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+  s.replaying = false;
+  const int64_t k = c.k;
+  for (int i = 0; i < s.nq; ++i)
     if (s.h_list_counts[2 * i + 1] == 0) ix->stats.candidates += s.h_list_counts[2 * i];
-  for (int i : dense_q) {
+  for (int i : s.dense_q) {
     const int64_t qi = s.q_first + i;
     int rc = dense_search_one(c, qi, out_idx + qi * k, out_score + qi * k, out_n + qi);
     if (rc != BBQ_OK) return rc;
   }
+  s.dense_q.clear();
   return BBQ_OK;
+}
+
+// brings a slot back to "free": collect + replay + wait, whatever is still outstanding
+int reclaim_slot(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score, int64_t *out_n) {
+  int rc = BBQ_OK;
+  if (s.busy) rc = begin_replay(c, s, out_idx, out_score, out_n);
+  if (rc == BBQ_OK && s.replaying) rc = finish_replay(c, s, out_idx, out_score, out_n);
+  return rc;
 }
 
 int drain(bbq_index *ix) {
@@ -952,25 +1029,34 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
   const int Q = std::max(1, ix->opt_batch);
   const int nslots = std::min(std::max(1, ix->opt_slots), kMaxSlots);
   const int64_t nsub = ((int64_t)n_queries + Q - 1) / Q;
-  auto complete = [&](Slot &s) -> int { return complete_subbatch(c, s, out_idx, out_score, out_n); };
+  auto fail_out = [&](int code) {
+    for (int i = 0; i < kMaxSlots; ++i)  // never leave pool jobs pointing at a caller's buffers
+      while (ix->slots[i].pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+    drain(ix);
+    for (int i = 0; i < kMaxSlots; ++i) ix->slots[i].busy = ix->slots[i].replaying = false;
+    return code;
+  };
   for (int64_t i = 0; i < nsub; ++i) {
     Slot &s = ix->slots[i % nslots];
-    if (s.busy) {
-      rc = complete(s);
-      if (rc != BBQ_OK) { drain(ix); return rc; }
-    }
+    rc = reclaim_slot(c, s, out_idx, out_score, out_n);
+    if (rc != BBQ_OK) return fail_out(rc);
     const int nq = (int)std::min<int64_t>(Q, n_queries - i * Q);
     rc = ensure_slot(ix, s, nq, true);
-    if (rc != BBQ_OK) { drain(ix); return rc; }
+    if (rc != BBQ_OK) return fail_out(rc);
     rc = enqueue_subbatch(cs, s, i * Q, nq, nullptr, 0, nullptr);
-    if (rc != BBQ_OK) { drain(ix); return rc; }
-  }
-  for (int64_t i = std::max<int64_t>(0, nsub - nslots); i < nsub; ++i) {
-    Slot &s = ix->slots[i % nslots];
-    if (s.busy) {
-      rc = complete(s);
-      if (rc != BBQ_OK) { drain(ix); return rc; }
+    if (rc != BBQ_OK) return fail_out(rc);
+    // hand finished sub-batches to the replay workers as early as possible (their slot is needed again soon)
+    for (int j = 0; j < nslots; ++j) {
+      Slot &t = ix->slots[j];
+      if (&t != &s && t.busy && hipEventQuery(t.ev_done) == hipSuccess) {
+        rc = begin_replay(c, t, out_idx, out_score, out_n);
+        if (rc != BBQ_OK) return fail_out(rc);
+      }
     }
+  }
+  for (int64_t i = std::max<int64_t>(0, nsub - nslots); i < nsub; ++i) {  // oldest first
+    rc = reclaim_slot(c, ix->slots[i % nslots], out_idx, out_score, out_n);
+    if (rc != BBQ_OK) return fail_out(rc);
   }
   return BBQ_OK;
 }

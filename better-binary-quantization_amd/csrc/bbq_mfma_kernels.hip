@@ -96,6 +96,7 @@ struct MfmaArgs {
 // Pairs that pass the pre-filter are pushed to a per-wave LDS queue (packed qc | row-in-tile << 20 | query << 26) and
 // scored exactly afterwards by ONE copy of the exact code, 64 pairs at a time.
 constexpr int kMfmaQueueCap = 512;
+constexpr int kMfmaChunksPerBlock = 8;
 template <int W, bool COMPACT>
 __global__ __launch_bounds__(kChunkRows) void bbq_scan_mfma_kernel(const MfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -133,8 +134,25 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_mfma_kernel(const MfmaArg
   }
   __syncthreads();
 
-  const int64_t chunk = a.s.chunk_begin + blockIdx.x;
   const int64_t n_tiles = (a.s.idx.n_rows + kTileRows - 1) / kTileRows;
+  // A workgroup is persistent over kMfmaChunksPerBlock consecutive chunks of the same 32 queries: the query fragments are
+  // staged once, and the codes of the next chunk's tile are prefetched into registers while the current one is computed.
+  const int lc0 = blockIdx.x * kMfmaChunksPerBlock;
+  u32x4m cnext[W];
+  u32x2m ccnext = {0u, 0u};
+  {
+    const int64_t t0 = (a.s.chunk_begin + lc0) * kTilesPerChunk + wave;
+    if (lc0 < a.s.n_chunks && t0 < n_tiles) {
+      const uint8_t *__restrict__ tp0 = a.s.idx.tiles + t0 * (int64_t)a.s.idx.tile_stride;
+#pragma unroll
+      for (int j = 0; j < W; ++j) cnext[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4m *>(tp0) + lane + j * kTileRows);
+      if constexpr (COMPACT) ccnext = __builtin_nontemporal_load(reinterpret_cast<const u32x2m *>(tp0 + (size_t)W * (kTileRows * 16)) + lane);
+    }
+  }
+  for (int ci = 0; ci < kMfmaChunksPerBlock; ++ci) {
+  const int lc = lc0 + ci;           // chunk index inside this launch
+  if (lc >= a.s.n_chunks) break;     // block-uniform
+  const int64_t chunk = a.s.chunk_begin + lc;
   const int64_t tile = chunk * kTilesPerChunk + wave;
 
   if (tile < n_tiles) {  // wave-uniform
@@ -155,10 +173,21 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_mfma_kernel(const MfmaArg
     const u32x4m *__restrict__ cp = reinterpret_cast<const u32x4m *>(tp) + lane;
     u32x4m c[W];
 #pragma unroll
-    for (int j = 0; j < W; ++j) c[j] = __builtin_nontemporal_load(cp + j * kTileRows);
+    for (int j = 0; j < W; ++j) c[j] = cnext[j];
+    const u32x2m cc_cur = ccnext;
+    {  // prefetch the next chunk's tile (same wave slot) while this one is computed
+      const int64_t tn = tile + kTilesPerChunk;
+      if (ci + 1 < kMfmaChunksPerBlock && lc + 1 < a.s.n_chunks && tn < n_tiles) {
+        const uint8_t *__restrict__ tpn = a.s.idx.tiles + tn * (int64_t)a.s.idx.tile_stride;
+#pragma unroll
+        for (int j = 0; j < W; ++j) cnext[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4m *>(tpn) + lane + j * kTileRows);
+        if constexpr (COMPACT) ccnext = __builtin_nontemporal_load(reinterpret_cast<const u32x2m *>(tpn + (size_t)W * (kTileRows * 16)) + lane);
+      }
+    }
+    (void)cp;
     double al, au, aadd, ea, eu, eadd;
     if constexpr (COMPACT) {
-      const u32x2m cc = __builtin_nontemporal_load(reinterpret_cast<const u32x2m *>(cr) + lane);
+      const u32x2m cc = cc_cur;
       al = (double)__uint_as_float(cc.x << 16);
       au = (double)__uint_as_float(cc.x & 0xffff0000u);
       aadd = (double)__uint_as_float(cc.y);
@@ -279,15 +308,20 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_mfma_kernel(const MfmaArg
       cnt = (uint32_t)a.s.cap;
     }
     const uint64_t *__restrict__ src = s_ent + (size_t)b * a.s.cap;
-    uint64_t *__restrict__ out = a.s.entries + ((size_t)(q0 + b) * a.s.n_chunks + blockIdx.x) * (size_t)a.s.cap;
+    uint64_t *__restrict__ out = a.s.entries + ((size_t)(q0 + b) * a.s.n_chunks + lc) * (size_t)a.s.cap;
     for (uint32_t i = tid; i < cnt; i += NT) {
       const uint64_t e = src[i];
       uint32_t rank = 0;
       for (uint32_t j = 0; j < cnt; ++j) rank += (src[j] < e) ? 1u : 0u;
       out[rank] = e;
     }
-    if (tid == 0) a.s.counts[(size_t)(q0 + b) * a.s.n_chunks + blockIdx.x] = cnt;
+    if (tid == 0) a.s.counts[(size_t)(q0 + b) * a.s.n_chunks + lc] = cnt;
   }
+  __syncthreads();                       // everybody has read the counters of this chunk ...
+  if (tid < kMfmaQueries) s_cnt[tid] = 0;
+  if (tid < NW) s_qcount[tid] = 0;
+  __syncthreads();                       // ... and sees them cleared before the next chunk's survivors arrive
+  }  // chunks of this workgroup
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -297,7 +331,8 @@ static hipError_t launch_mfma_t(const MfmaArgs &a, int nq, int nc, hipStream_t s
   constexpr int NW = kChunkRows / 64;
   const size_t smem = (size_t)W * 4 * 2 * 32 * 16 + (size_t)NW * 64 * 2 * 16 + (size_t)NW * kMfmaQueueCap * 4 + 32 +
                       kMfmaQueries * (sizeof(QueryParams) + 8 + 4 + 4) + (size_t)kMfmaQueries * a.s.cap * 8 + 64;
-  dim3 grid((unsigned)nc, (unsigned)((nq + kMfmaQueries - 1) / kMfmaQueries), 1), block(kChunkRows, 1, 1);
+  dim3 grid((unsigned)((nc + kMfmaChunksPerBlock - 1) / kMfmaChunksPerBlock), (unsigned)((nq + kMfmaQueries - 1) / kMfmaQueries), 1),
+      block(kChunkRows, 1, 1);
   auto kern = bbq_scan_mfma_kernel<W, COMPACT>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
