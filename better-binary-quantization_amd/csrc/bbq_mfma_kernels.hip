@@ -98,7 +98,7 @@ struct MfmaArgs {
 constexpr int kMfmaQueueCap = 512;
 constexpr int kMfmaChunksPerBlock = 8;
 template <int W, bool COMPACT>
-__global__ __launch_bounds__(kChunkRows) void bbq_scan_mfma_kernel(const MfmaArgs a) {
+__global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const MfmaArgs a) {  // 4 waves per SIMD = 2 workgroups per CU: caps the allocation at 128 VGPRs
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT = kChunkRows;
   constexpr int NW = kChunkRows / 64;
@@ -149,7 +149,12 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_mfma_kernel(const MfmaArg
       if constexpr (COMPACT) ccnext = __builtin_nontemporal_load(reinterpret_cast<const u32x2m *>(tp0 + (size_t)W * (kTileRows * 16)) + lane);
     }
   }
+#pragma unroll 1
   for (int ci = 0; ci < kMfmaChunksPerBlock; ++ci) {
+  // opaque zero, redefined every iteration: keeps the compiler from hoisting the 24 query-fragment LDS reads out of
+  // the chunk loop (96 VGPRs held across the loop -> 252 VGPRs, occupancy 2 and a slower kernel)
+  int lds_off;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(lds_off));
   const int lc = lc0 + ci;           // chunk index inside this launch
   if (lc >= a.s.n_chunks) break;     // block-uniform
   const int64_t chunk = a.s.chunk_begin + lc;
@@ -226,35 +231,33 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_mfma_kernel(const MfmaArg
       dst[0] = k0; dst[1] = k1;
     }
 
-    // ---- the contraction: 2 row groups x WORDS k-steps of 32 dims
-    i32x16m acc0 = {0}, acc1 = {0};
-#pragma unroll
-    for (int g = 0; g < WORDS; ++g) {
-      const uint32_t w = (g & 3) == 0 ? c[g >> 2].x : (g & 3) == 1 ? c[g >> 2].y : (g & 3) == 2 ? c[g >> 2].z : c[g >> 2].w;
-      const uint32_t sw = (uint32_t)__shfl_xor((int)w, 32, 64);  // partner half's word (rows +-32)
-      const uint32_t a0w = h == 0 ? w : sw;   // row group 0 (tile rows 0..31):  A row m = lane%32
-      const uint32_t a1w = h == 0 ? sw : w;   // row group 1 (tile rows 32..63)
-      const uint32_t b0 = (a0w >> (16 * h)) & 0xFFFFu, b1 = (a1w >> (16 * h)) & 0xFFFFu;
-      i32x4m A0, A1;
-      A0.x = (int)spread4(b0); A0.y = (int)spread4(b0 >> 4); A0.z = (int)spread4(b0 >> 8); A0.w = (int)spread4(b0 >> 12);
-      A1.x = (int)spread4(b1); A1.y = (int)spread4(b1 >> 4); A1.z = (int)spread4(b1 >> 8); A1.w = (int)spread4(b1 >> 12);
-      const u32x4m bq = s_B[(g * 2 + h) * 32 + n];
-      i32x4m Bf;
-      Bf.x = (int)bq.x; Bf.y = (int)bq.y; Bf.z = (int)bq.z; Bf.w = (int)bq.w;
-      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, Bf, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, Bf, acc1, 0, 0, 0);
-    }
-
-    // ---- per (row, query) pre-filter; this lane owns query n and 16 rows of each row group
+    // ---- the contraction, one row group (32 rows x 32 queries) at a time: WORDS k-steps of 32 dims, then the
+    //      pre-filter of its 16 x 64 pairs; keeping only one accumulator tile live keeps the kernel under 128 VGPRs
     const bool have_q = n < nb;
     uint32_t *__restrict__ queue = s_queue + (size_t)wave * kMfmaQueueCap;
     const int rows_here = (int)min((int64_t)kTileRows, a.s.idx.n_rows - tile * kTileRows);
-#pragma unroll
+#pragma unroll 1
     for (int rg = 0; rg < 2; ++rg) {
+      i32x16m acc = {0};
+#pragma unroll
+      for (int g = 0; g < WORDS; ++g) {
+        const uint32_t w = (g & 3) == 0 ? c[g >> 2].x : (g & 3) == 1 ? c[g >> 2].y : (g & 3) == 2 ? c[g >> 2].z : c[g >> 2].w;
+        const uint32_t sw = (uint32_t)__shfl_xor((int)w, 32, 64);  // partner half's word (rows +-32)
+        // A row m = lane%32 of this row group: lanes of half h == rg hold those rows themselves, the other half borrows
+        const uint32_t aw = (h == rg) ? w : sw;
+        const uint32_t bts = (aw >> (16 * h)) & 0xFFFFu;           // this half supplies k = 16h .. 16h+15
+        i32x4m A;
+        A.x = (int)spread4(bts); A.y = (int)spread4(bts >> 4); A.z = (int)spread4(bts >> 8); A.w = (int)spread4(bts >> 12);
+        const u32x4m bq = s_B[(g * 2 + h) * 32 + n + lds_off];
+        i32x4m Bf;
+        Bf.x = (int)bq.x; Bf.y = (int)bq.y; Bf.z = (int)bq.z; Bf.w = (int)bq.w;
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, Bf, acc, 0, 0, 0);
+      }
+      // per (row, query) pre-filter; this lane owns query n and 16 rows of the group
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rit = 32 * rg + (r & 3) + 8 * (r >> 2) + 4 * h;  // row in tile
-        const int qc = rg == 0 ? acc0[r] : acc1[r];
+        const int qc = acc[r];
         const f32x4m *__restrict__ rc = s_row + ((size_t)wave * 64 + rit) * 2;
         const f32x4m k0 = rc[0], k1 = rc[1];
         const float qcf = (float)qc;
