@@ -445,20 +445,21 @@ void fill_query(const bbq_index *ix, uint8_t *planes_dst, QueryParams *pp, const
 }
 
 // MFMA shared sweep: the int8 query values in the order the code bits fall out of the packed words.  For 32-dim word
-// g, half h (bits 16h..16h+15 of the little-endian word), dword c, byte i: bit p = 16h + 4c + i of the word is row byte
-// 4g + (p >> 3), bit (p & 7), i.e. dimension 32g + 8*(p >> 3) + 7 - (p & 7)  (MSB-first packing, src/optimizedScalarQuantizer.ts:420-446).
-// Layout: [group][g][h][n][16 B], n = query inside its group of 32.
+// g, half h, dword c, byte i the kernel extracts bit p = 4h + c + 8i of the little-endian word ((w >> (4h + c)) &
+// 0x01010101), which is row byte 4g + (p >> 3), bit (p & 7), i.e. dimension 32g + 8*(p >> 3) + 7 - (p & 7)
+// (MSB-first packing, src/optimizedScalarQuantizer.ts:420-446).  Layout: [group][g][h][n][16 B], n = query in its group of 32.
 void fill_query_mfma(const bbq_index *ix, uint8_t *dst, int q_in_batch, const uint8_t *q) {
   const int words = ix->w16 * 4, group = q_in_batch / 32, n = q_in_batch % 32;
   uint8_t *gb = dst + (size_t)group * words * 2 * 32 * 16;
   for (int g = 0; g < words; ++g)
     for (int h = 0; h < 2; ++h) {
       uint8_t *o = gb + (((size_t)g * 2 + h) * 32 + n) * 16;
-      for (int ci = 0; ci < 16; ++ci) {
-        const int p = 16 * h + ci;
-        const int d = 32 * g + 8 * (p >> 3) + 7 - (p & 7);
-        o[ci] = d < ix->dim ? q[d] : 0;
-      }
+      for (int cc = 0; cc < 4; ++cc)
+        for (int i = 0; i < 4; ++i) {
+          const int p = 4 * h + cc + 8 * i;
+          const int d = 32 * g + 8 * (p >> 3) + 7 - (p & 7);
+          o[4 * cc + i] = d < ix->dim ? q[d] : 0;
+        }
     }
 }
 

@@ -51,9 +51,6 @@ __device__ __forceinline__ double m_score_f64(double qc, double ax, double ux, d
   return t < 0.0 ? 1.0 / (1.0 - t / FBS) : t / FBS + 1.0;
 }
 
-// spread 4 bits (b0..b3 in the low nibble of x) to 4 bytes 0/1: bit i -> byte i
-__device__ __forceinline__ uint32_t spread4(uint32_t x) { return ((x & 0xFu) * 0x00204081u) & 0x01010101u; }
-
 // conservative lower edge, in z-space, of "score > theta" for one query (see the pre-filter below).
 //   COSINE / MIP: z = s + xadd,  score = f(z + qadd - cdp) with f increasing
 //   EUCLIDEAN   : z = 2s - xadd, score = 1/(1 + qadd - z)  increasing in z while the denominator is positive
@@ -242,12 +239,15 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
 #pragma unroll
       for (int g = 0; g < WORDS; ++g) {
         const uint32_t w = (g & 3) == 0 ? c[g >> 2].x : (g & 3) == 1 ? c[g >> 2].y : (g & 3) == 2 ? c[g >> 2].z : c[g >> 2].w;
-        const uint32_t sw = (uint32_t)__shfl_xor((int)w, 32, 64);  // partner half's word (rows +-32)
-        // A row m = lane%32 of this row group: lanes of half h == rg hold those rows themselves, the other half borrows
-        const uint32_t aw = (h == rg) ? w : sw;
-        const uint32_t bts = (aw >> (16 * h)) & 0xFFFFu;           // this half supplies k = 16h .. 16h+15
+        // v_permlane32_swap(w, w): [0] = {own | partner (lane-32)}, [1] = {partner (lane+32) | own}: exactly the word of
+        // A row m = lane%32 for row group 0 resp. 1 (lanes of the other half borrow their partner's row)
+        const auto sw2 = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+        const uint32_t aw = (rg == 0 ? sw2[0] : sw2[1]) >> (4 * h);
+        // this half supplies 16 of the word's 32 dims: bits 4h+c+8i -> byte i of dword c (one shift + one AND per dword;
+        // the host lays the query bytes out in the same order, fill_query_mfma)
         i32x4m A;
-        A.x = (int)spread4(bts); A.y = (int)spread4(bts >> 4); A.z = (int)spread4(bts >> 8); A.w = (int)spread4(bts >> 12);
+        A.x = (int)(aw & 0x01010101u); A.y = (int)((aw >> 1) & 0x01010101u);
+        A.z = (int)((aw >> 2) & 0x01010101u); A.w = (int)((aw >> 3) & 0x01010101u);
         const u32x4m bq = s_B[(g * 2 + h) * 32 + n + lds_off];
         i32x4m Bf;
         Bf.x = (int)bq.x; Bf.y = (int)bq.y; Bf.z = (int)bq.z; Bf.w = (int)bq.w;
@@ -304,21 +304,21 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
     (void)row_l;
   }
   __syncthreads();
-  for (int b = 0; b < nb; ++b) {
+  for (int b = wave; b < nb; b += NW) {  // each wave writes the lists of its share of the queries
     uint32_t cnt = s_cnt[b];
     if (cnt > (uint32_t)a.s.cap) {
-      if (tid == 0) atomicOr(a.s.flags + q0 + b, kFlagOverflow);
+      if (lane == 0) atomicOr(a.s.flags + q0 + b, kFlagOverflow);
       cnt = (uint32_t)a.s.cap;
     }
     const uint64_t *__restrict__ src = s_ent + (size_t)b * a.s.cap;
     uint64_t *__restrict__ out = a.s.entries + ((size_t)(q0 + b) * a.s.n_chunks + lc) * (size_t)a.s.cap;
-    for (uint32_t i = tid; i < cnt; i += NT) {
+    for (uint32_t i = lane; i < cnt; i += 64) {
       const uint64_t e = src[i];
       uint32_t rank = 0;
       for (uint32_t j = 0; j < cnt; ++j) rank += (src[j] < e) ? 1u : 0u;
       out[rank] = e;
     }
-    if (tid == 0) a.s.counts[(size_t)(q0 + b) * a.s.n_chunks + lc] = cnt;
+    if (lane == 0) a.s.counts[(size_t)(q0 + b) * a.s.n_chunks + lc] = cnt;
   }
   __syncthreads();                       // everybody has read the counters of this chunk ...
   if (tid < kMfmaQueries) s_cnt[tid] = 0;
