@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--query-bits", type=int, default=4)
     ap.add_argument("--sub-batch", type=int, default=32, help="queries per device launch sequence (pipelined inside a step)")
     ap.add_argument("--slots", type=int, default=3, help="pipeline slots (streams) inside the library")
-    ap.add_argument("--replay-threads", type=int, default=8, help="host threads replaying the reference heap")
+    ap.add_argument("--replay-threads", type=int, default=16, help="host threads replaying the reference heap")
     ap.add_argument("--pilot", type=int, default=32768, help="replicated pilot rows per non-root shard (multi-GPU)")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
