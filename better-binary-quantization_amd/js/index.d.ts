@@ -14,6 +14,8 @@ export interface BinarizedByteVectorValues {
   clearUnpackedVectorCache?(): void;
   /** releases the device-resident copy (extension) */
   dispose(): void;
+  /** libbbq tuning knob on the device index, e.g. ('sweep_share', 32) (extension) */
+  setDeviceOption(name: string, value: number): void;
 }
 export interface QuantizedScoreResult { score: number; bitDotProduct: number; corrections: { query: QuantizationResult; index: QuantizationResult }; }
 export declare class OptimizedScalarQuantizer {

@@ -94,6 +94,9 @@ class BinarizedByteVectorValuesImpl {
     return this._device;
   }
   dispose() { if (this._device) { native.indexDestroy(this._device); this._device = null; } }
+  /** tuning knobs of the device index (libbbq bbq_set_option), e.g. ('sweep_share', 32) for searchNearestNeighborsBatch */
+  setDeviceOption(name, value) { native.setOption(this._deviceIndex(), name, value); }
+  deviceStats() { return native.stats(this._deviceIndex()); }
 }
 
 function flatten(vectors, dim) {

@@ -64,5 +64,9 @@ function normalise(v) {
     for (let i = 0; ok && i < 10; i++) ok = batch[qi][i].index === wi[i];
   }
   T.check(ok, 'searchNearestNeighborsBatch equals per-query results');
+  index.setDeviceOption('sweep_share', 32);   // shared sweep on the matrix cores: same answers
+  const batch32 = fmt.searchNearestNeighborsBatch(io.queries, index, 10);
+  T.check(JSON.stringify(batch32) === JSON.stringify(batch), 'shared sweep (32) equals one sweep per query');
+  index.setDeviceOption('sweep_share', 1);
 })();
 T.finish('js gpu_parity');

@@ -208,6 +208,24 @@ def test_explicit_component_sum_layout():
         np.testing.assert_array_equal(idx, oi)
     finally:
         ix.close()
+    # the same through many small segments and through the shared-sweep kernels (explicit sums must reach their pre-filters)
+    rng = np.random.default_rng(21)
+    pick = rng.integers(0, codes.shape[0], 20000)
+    codes2, corr2 = codes[pick].copy(), corr[pick].copy()
+    od, os64, os32 = O.score_all(codes2, corr2, g["dim"], qq, qc, 4, sim, cdp)
+    oi, osc = O.heap_topk(os32, 25)
+    ix = B.Index(codes2, corr2, g["dim"], cdp)
+    try:
+        assert ix.bytes_per_row == 16 + 32
+        ix.set_option("first_segment_rows", 1024)
+        ix.set_option("segment_growth", 2)
+        for share in (1, 8, 32):
+            ix.set_option("sweep_share", share)
+            idx, sc = ix.search(qq, qc, 4, sim, 25)
+            np.testing.assert_array_equal(idx, oi, err_msg="share %d" % share)
+            np.testing.assert_array_equal(sc.view(np.uint32), osc.view(np.uint32))
+    finally:
+        ix.close()
 
 
 def test_empty_and_argument_errors():
