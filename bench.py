@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--shared-sweep", type=int, default=32, help="also time the batched mode (queries per shared sweep; 0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1: nccl (= RCCL) or gloo (rehearsal)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the sharded code path (process group, collectives) even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -142,8 +143,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.same_device:
             local = 0
         torch.cuda.set_device(local)
@@ -195,7 +200,7 @@ def main():
 
     results = []
     batches = [(qq_all[i * Q:(i + 1) * Q], qc_all[i * Q:(i + 1) * Q]) for i in range(n_steps)]
-    if world == 1:
+    if dist is None:
         def run(bs):
             for qq, qc in bs:
                 results.append(ix.search_batch(qq, qc, QB, SIM, k))
@@ -220,7 +225,7 @@ def main():
         dt = float(t.item())
     st = ix.stats()
     batched = None
-    if world == 1 and args.shared_sweep in (4, 8, 32):
+    if dist is None and args.shared_sweep in (4, 8, 32):
         # API extension, reported separately: `shared_sweep` queries share one sweep of the index
         ix.set_option("sweep_share", args.shared_sweep)
         res_b = ix.search_batch(batches[args.warmup][0], batches[args.warmup][1], QB, SIM, k)
@@ -269,7 +274,7 @@ def main():
                          "traffic": traffic, "kernel": "bbq_scan_kernel (largest segment launch)",
                          "bytes_per_launch": launch_bytes, "avg_launch_ms": launch_ms, "launches_timed": st["total_scan_launches"]},
             "end_to_end_hbm_frac": (qps * (N / world) * bytes_per_row / 1e9) / HBM_PEAK_GBS,
-            "candidates_per_query": st["candidates"] / float(Q) if world == 1 else None,
+            "candidates_per_query": st["candidates"] / float(Q) if dist is None else None,
             "dense_fallbacks": st["dense_fallbacks"],
         }
         if batched is not None:
