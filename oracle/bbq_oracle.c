@@ -444,6 +444,57 @@ int64_t orc_oversampled_topk(const float *query, const float *base, const uint8_
   return m;
 }
 
+/* src/vectorSimilarity.ts:14-126: EUCLIDEAN 1/(1+sqrt(sum (a-b)^2)), COSINE, MAXIMUM_INNER_PRODUCT; all f64, in index order */
+double orc_true_similarity(const float *a, const float *b, int dim, int sim) {
+  if (sim == ORC_COSINE) return orc_cosine_similarity(a, b, dim);
+  if (sim == ORC_EUCLIDEAN) {
+    double sum = 0;
+    for (int i = 0; i < dim; i++) { double diff = (double)a[i] - (double)b[i]; sum += diff * diff; }
+    return 1.0 / (1.0 + sqrt(sum));
+  }
+  double dp = 0;
+  for (int i = 0; i < dim; i++) dp += (double)a[i] * (double)b[i];
+  return dp;
+}
+
+/* src/topKSelector.ts:40-78 from the candidates' true scores (candidate order = the oversampled search's result order):
+ * min-heap of k on trueScore, pop all, stable sort descending.  out_pos = positions into the candidate list. */
+int64_t orc_rerank_select_heap(const double *true_scores, int64_t cnt, int64_t k, int32_t *out_pos) {
+  min_heap h; h.a = (heap_item *)malloc(sizeof(heap_item) * (size_t)(k + 1)); h.len = 0;
+  for (int64_t i = 0; i < cnt; i++) {
+    heap_item it = {true_scores[i], (int32_t)i};
+    if (h.len < k) heap_push(&h, it);
+    else if (h.len > 0 && it.score > h.a[0].score) { heap_pop(&h); heap_push(&h, it); }
+  }
+  int64_t m = h.len;
+  heap_item *asc = (heap_item *)malloc(sizeof(heap_item) * (size_t)(m + 1));
+  for (int64_t j = 0; j < m; j++) asc[j] = heap_pop(&h);
+  for (int64_t i = 1; i < m; i++) {   /* stable, like V8's sort with a consistent comparator */
+    heap_item key = asc[i]; int64_t j = i - 1;
+    while (j >= 0 && (key.score - asc[j].score) > 0) { asc[j + 1] = asc[j]; j--; }
+    asc[j + 1] = key;
+  }
+  for (int64_t j = 0; j < m; j++) out_pos[j] = asc[j].index;
+  free(asc); free(h.a);
+  return m;
+}
+
+/* src/topKSelector.ts:102-115: stable sort of all candidates by trueScore descending, first k */
+int64_t orc_rerank_select_sort(const double *true_scores, int64_t cnt, int64_t k, int32_t *out_pos) {
+  heap_item *v = (heap_item *)malloc(sizeof(heap_item) * (size_t)(cnt + 1));
+  for (int64_t i = 0; i < cnt; i++) { v[i].score = true_scores[i]; v[i].index = (int32_t)i; }
+  for (int64_t i = 1; i < cnt; i++) {
+    heap_item key = v[i]; int64_t j = i - 1;
+    while (j >= 0 && (key.score - v[j].score) > 0) { v[j + 1] = v[j]; j--; }
+    v[j + 1] = key;
+  }
+  int64_t m = cnt < k ? cnt : k;
+  if (m < 0) m = 0;
+  for (int64_t j = 0; j < m; j++) out_pos[j] = v[j].index;
+  free(v);
+  return m;
+}
+
 /* ------------------------------------------------------------------ synthetic inputs */
 
 void orc_mulberry32_fill(uint32_t seed, float *out, int64_t count) {

@@ -88,6 +88,13 @@ int64_t orc_oversampled_topk(const float *query, const float *base, const uint8_
                              const float *centroid, int64_t n, int dim, int sim, int qb, double lambda, int iters,
                              int64_t k, int factor, int32_t *out_idx);
 
+/* src/vectorSimilarity.ts:14-126 (computeSimilarity: the exact f64 score the rerank recipe uses) */
+double orc_true_similarity(const float *a, const float *b, int dim, int sim);
+/* src/topKSelector.ts:40-78 / :102-115 from the candidates' true scores, candidate order = the oversampled search's
+ * result order.  out_pos = positions into that list, in result order; returns the count. */
+int64_t orc_rerank_select_heap(const double *true_scores, int64_t cnt, int64_t k, int32_t *out_pos);
+int64_t orc_rerank_select_sort(const double *true_scores, int64_t cnt, int64_t k, int32_t *out_pos);
+
 /* SURVEY 8(d) synthetic input generator: mulberry32(seed), value f32(2u-1), row-major fill */
 void orc_mulberry32_fill(uint32_t seed, float *out, int64_t count);
 

@@ -26,7 +26,8 @@ const OUT = process.argv[2] || path.join(__dirname, '..', '..', 'tests', 'golden
 const { BinaryQuantizationFormat } = require(path.join(ERASED, 'binaryQuantizationFormat'));
 const { normalizeVector } = require(path.join(ERASED, 'vectorOperations'));
 const { computeQuantizedDotProduct } = require(path.join(ERASED, 'bitwiseDotProduct'));
-const { getOversampledTopKWithHeap } = require(path.join(ERASED, 'topKSelector'));
+const { getOversampledTopKWithHeap, getOversampledTopKWithSort } = require(path.join(ERASED, 'topKSelector'));
+const { computeSimilarity } = require(path.join(ERASED, 'vectorSimilarity'));
 
 // ---------------------------------------------------------------- PRNG (SURVEY 8d)
 function mulberry32(seed) {
@@ -188,6 +189,45 @@ function runCase(c) {
   console.log(c.name, 'n=' + n, 'dim=' + dim, 'warnings=' + warnings.length, (Date.now() - t0) + ' ms');
 }
 
+// ---------------------------------------------------------------- exact rerank pin (SURVEY 8f-3)
+// computeSimilarity (src/vectorSimilarity.ts:14-126) for every (query, row) under all three functions, and both
+// oversample-then-rerank selectors (src/topKSelector.ts:29-115) on a COSINE index of the same rows.
+function runRerank(c) {
+  const base = randMatrix(c.base_seed, c.n, c.dim), queries = randMatrix(c.query_seed, c.nq, c.dim);
+  // hostile rows: zero vector (norm 0 -> cosine 0), huge and tiny magnitudes, a copy of query 0 (cosine ~1, distance 0)
+  if (c.n > 12) {
+    base[5].fill(0);
+    for (let j = 0; j < c.dim; j++) { base[7][j] *= 1e18; base[9][j] *= 1e-30; base[11][j] = queries[0][j]; }
+  }
+  if (c.zero_query) queries[c.nq - 1].fill(0);
+  const flat = new Float32Array(c.n * c.dim), qflat = new Float32Array(c.nq * c.dim);
+  base.forEach(function (v, i) { flat.set(v, i * c.dim); });
+  queries.forEach(function (v, i) { qflat.set(v, i * c.dim); });
+  const out = { name: c.name, dim: c.dim, n: c.n, nq: c.nq, k: c.k, lambda: 0.1, iters: 5,
+    base_f32: b64(flat), queries_f32: b64(qflat), true_f64: {}, oversample: [] };
+  SIMS.forEach(function (sim) {
+    const t = new Float64Array(c.nq * c.n);
+    for (let qi = 0; qi < c.nq; qi++) for (let i = 0; i < c.n; i++) t[qi * c.n + i] = computeSimilarity(queries[qi], base[i], sim);
+    out.true_f64[sim] = b64(t);
+  });
+  const format = new BinaryQuantizationFormat({ queryBits: 4, indexBits: 1, quantizer: { similarityFunction: 'COSINE', lambda: 0.1, iters: 5 } });
+  const index = format.quantizeVectors(base).quantizedVectors;
+  const pack = function (r) {
+    const idx = new Int32Array(r.length), qs = new Float32Array(r.length), ts = new Float64Array(r.length);
+    for (let i = 0; i < r.length; i++) { idx[i] = r[i].index; qs[i] = r[i].quantizedScore; ts[i] = r[i].trueScore; }
+    return { idx_i32: b64(idx), quantized_f32: b64(qs), true_f64: b64(ts) };
+  };
+  c.factors.forEach(function (f) {
+    for (let qi = 0; qi < c.nq; qi++) {
+      out.oversample.push({ query: qi, factor: f,
+        heap: pack(getOversampledTopKWithHeap(queries[qi], index, base, c.k, f, format)),
+        sort: pack(getOversampledTopKWithSort(queries[qi], index, base, c.k, f, format)) });
+    }
+  });
+  fs.writeFileSync(path.join(OUT, c.name + '.json'), JSON.stringify(out));
+  console.log(c.name, 'n=' + c.n, 'dim=' + c.dim);
+}
+
 // ---------------------------------------------------------------- integer-dot pin for multi-bit index (H4: float score unpinned)
 function runIntDot(c) {
   const base = randMatrix(c.base_seed, c.n, c.dim), queries = randMatrix(c.query_seed, c.nq, c.dim);
@@ -321,5 +361,10 @@ cases.forEach(function (c) { if (!only || only.test(c.name)) runCase(c); });
 if (!only || only.test('intdot')) {
   runIntDot({ name: 'intdot_ib2_qb8_64d', sim: 'EUCLIDEAN', qb: 8, ib: 2, dim: 64, n: 200, nq: 2, base_seed: 51, query_seed: 52 });
   runIntDot({ name: 'intdot_ib2_qb4_100d', sim: 'COSINE', qb: 4, ib: 2, dim: 100, n: 150, nq: 2, base_seed: 53, query_seed: 54 });
+}
+if (!only || only.test('rerank')) {
+  runRerank({ name: 'rerank_768d', dim: 768, n: 300, nq: 3, k: 10, factors: [1, 3, 5], base_seed: 301, query_seed: 302, zero_query: true });
+  runRerank({ name: 'rerank_100d', dim: 100, n: 500, nq: 4, k: 25, factors: [2, 4], base_seed: 303, query_seed: 304, zero_query: false });
+  runRerank({ name: 'rerank_3d', dim: 3, n: 40, nq: 2, k: 5, factors: [3, 10], base_seed: 305, query_seed: 306, zero_query: false });
 }
 if (!only || only.test('api_behaviour')) runApiBehaviour();

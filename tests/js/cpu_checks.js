@@ -39,7 +39,7 @@ T.check(JSON.stringify(f.getConfig()) === JSON.stringify(byLabel['getConfig'].re
 T.check(bbq.DEFAULT_CONFIG.queryBits === 4 && bbq.DEFAULT_CONFIG.quantizer.similarityFunction === 'COSINE' && bbq.VERSION === '1.0.0', 'DEFAULT_CONFIG / VERSION');
 
 // --- index build + query quantization against the golden vectors
-T.goldenNames().filter(function (n) { return !/^(intdot_|api_|big_)/.test(n); }).forEach(function (name) {
+T.goldenNames().filter(function (n) { return !/^(intdot_|api_|rerank_|big_)/.test(n); }).forEach(function (name) {
   const g = T.loadGolden(name), io = T.inputs(g);
   const fmt = new bbq.BinaryQuantizationFormat({ queryBits: g.qb, indexBits: g.ib, quantizer: { similarityFunction: g.sim, lambda: g.lambda, iters: g.iters } });
   const index = fmt.quantizeVectors(io.base).quantizedVectors;

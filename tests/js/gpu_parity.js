@@ -4,7 +4,7 @@ const T = require('./common');
 const bbq = T.bbq;
 if (bbq.deviceCount() < 1) { console.error('no HIP device'); process.exit(2); }
 
-T.goldenNames().filter(function (n) { return !/^(intdot_|api_)/.test(n); }).forEach(function (name) {
+T.goldenNames().filter(function (n) { return !/^(intdot_|api_|rerank_)/.test(n); }).forEach(function (name) {
   if (/^big_(50000|30000)/.test(name)) return;  // covered by pytest; keeps the node run short
   const g = T.loadGolden(name), io = T.inputs(g);
   const fmt = new bbq.BinaryQuantizationFormat({ queryBits: g.qb, indexBits: g.ib, quantizer: { similarityFunction: g.sim, lambda: g.lambda, iters: g.iters } });

@@ -62,6 +62,12 @@ def lib():
                                            C.c_int, C.c_int64, C.c_int, i32p]
         L.orc_oversampled_topk.restype = C.c_int64
         L.orc_mulberry32_fill.argtypes = [C.c_uint32, f32p, C.c_int64]
+        L.orc_true_similarity.argtypes = [f32p, f32p, C.c_int, C.c_int]
+        L.orc_true_similarity.restype = C.c_double
+        L.orc_rerank_select_heap.argtypes = [f64p, C.c_int64, C.c_int64, i32p]
+        L.orc_rerank_select_heap.restype = C.c_int64
+        L.orc_rerank_select_sort.argtypes = [f64p, C.c_int64, C.c_int64, i32p]
+        L.orc_rerank_select_sort.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -161,6 +167,28 @@ def search(query, codes, corr, cen, sim, qb, k, lam=0.1, iters=5):
     if cnt < 0:
         return cnt, None
     return idx[:cnt].copy(), sc[:cnt].copy()
+
+
+def true_similarity(queries, base, sim):
+    """computeSimilarity for every (query, row): f64 [nq, n]"""
+    queries = np.ascontiguousarray(queries, np.float32)
+    base = np.ascontiguousarray(base, np.float32)
+    nq, dim = queries.shape
+    out = np.zeros((nq, base.shape[0]), np.float64)
+    L = lib()
+    for qi in range(nq):
+        for i in range(base.shape[0]):
+            out[qi, i] = L.orc_true_similarity(f32p(queries[qi]), f32p(base[i]), dim, sim)
+    return out
+
+
+def rerank_select(true_scores, k, how="heap"):
+    """positions into the candidate list, in the order getOversampledTopKWith{Heap,Sort} return them"""
+    t = np.ascontiguousarray(true_scores, np.float64)
+    out = np.zeros(max(min(k, t.shape[0]), 0) + 1, np.int32)
+    fn = lib().orc_rerank_select_heap if how == "heap" else lib().orc_rerank_select_sort
+    cnt = fn(f64p(t), t.shape[0], k, i32p(out))
+    return out[:cnt].copy()
 
 
 # ---------------------------------------------------------------- golden fixtures

@@ -8,7 +8,7 @@ from bbqlib import bbq_amd as B
 
 pytestmark = pytest.mark.gpu
 
-CASES = [n for n in O.golden_names() if not n.startswith(("intdot_", "api_"))]
+CASES = [n for n in O.golden_names() if not n.startswith(("intdot_", "api_", "rerank_"))]
 FULL = [n for n in CASES if O.load_golden(n)["full"]]
 HASHED = [n for n in CASES if not O.load_golden(n)["full"]]
 

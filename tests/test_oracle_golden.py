@@ -32,7 +32,7 @@ def same_or_sha(arr, sha, full_b64, dt):
         assert O.sha(arr) == sha
 
 
-CASES = [n for n in O.golden_names() if not n.startswith(("intdot_", "api_"))]
+CASES = [n for n in O.golden_names() if not n.startswith(("intdot_", "api_", "rerank_"))]
 SMALL = [n for n in CASES if not n.startswith("big_")]
 
 
@@ -165,3 +165,28 @@ def test_reference_recall_thresholds_closed_form():
             got = set(O.dec(g["queries"][qi]["topk"][0]["idx_i32"], "<i4").tolist())
             rec.append(len(truth & got) / 10.0)
         assert np.mean(rec) >= thr
+
+
+# ---------------------------------------------------------------- exact rerank
+
+@pytest.mark.parametrize("name", O.golden_names("rerank_*"))
+def test_true_similarity_and_rerank_selectors(name):
+    """computeSimilarity (all three functions, every (query,row)) and both oversample selectors of the reference"""
+    g = O.load_golden(name)
+    n, dim, nq, k = g["n"], g["dim"], g["nq"], g["k"]
+    base = O.dec(g["base_f32"], np.float32).reshape(n, dim)
+    queries = O.dec(g["queries_f32"], np.float32).reshape(nq, dim)
+    true = {}
+    for sim_name, sim in O.SIMS.items():
+        true[sim] = O.true_similarity(queries, base, sim)
+        np.testing.assert_array_equal(b64(true[sim].ravel()), b64(O.dec(g["true_f64"][sim_name], np.float64)))
+    codes, corr, cen = O.build_index(base, 1, g["lambda"], g["iters"])
+    for rec in g["oversample"]:
+        qi, f = rec["query"], rec["factor"]
+        cand, qsc = O.search(queries[qi], codes, corr, cen, 1, 4, k * f, g["lambda"], g["iters"])
+        t = true[1][qi][cand]
+        for how in ("heap", "sort"):
+            pos = O.rerank_select(t, k, how)
+            np.testing.assert_array_equal(cand[pos], O.dec(rec[how]["idx_i32"], np.int32))
+            np.testing.assert_array_equal(b32(qsc[pos]), b32(O.dec(rec[how]["quantized_f32"], np.float32)))
+            np.testing.assert_array_equal(b64(t[pos]), b64(O.dec(rec[how]["true_f64"], np.float64)))
