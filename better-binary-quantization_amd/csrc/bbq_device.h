@@ -93,6 +93,18 @@ struct FinalizeArgs {
   int32_t need_theta;          // 0 on the last segment
 };
 
+// exact rerank (bbq_rerank_kernels.hip): candidates of query q are rows[offsets[q] .. offsets[q+1])
+struct RerankArgs {
+  const float *vecs;       // [n][dim] original fp32 rows, row-major
+  int64_t n;
+  int32_t dim;
+  int32_t sim;             // 0 EUCLIDEAN, 1 COSINE, 2 MAXIMUM_INNER_PRODUCT
+  const float *queries;    // [Q][dim] raw fp32 queries
+  const int64_t *offsets;  // [Q+1]
+  const int32_t *rows;     // [offsets[Q]] row numbers, all in [0, n)
+  double *out;             // [offsets[Q]] computeSimilarity(query, row)
+};
+
 constexpr int kFinalizeThreads = 1024;
 constexpr int kFinalizeKeyCap = 12288;   // LDS key buffer of the finalize kernel (new keys + running top-k)
 

@@ -27,6 +27,16 @@ class HeapReplay {
   }
   // pops everything (ascending) and writes it reversed = descending, like topKResults.reverse()
   int64_t finish(int32_t *out_idx, float *out_score);
+  // the same heap keyed by an f64 (the rerank selector's trueScore, src/topKSelector.ts:40-66); drain pops ascending
+  inline void offer64(double s, int32_t tag) {
+    if ((int64_t)heap_.size() < k2_) {
+      push(s, tag);
+    } else if (k2_ > 0 && s > heap_[0].score) {
+      pop();
+      push(s, tag);
+    }
+  }
+  int64_t drain_ascending(int32_t *out_tag, double *out_score);
   int64_t mutations() const { return mutations_; }
 
  private:

@@ -32,4 +32,7 @@ hipError_t launch_build_quantize1(const float *vT4, int64_t n, int32_t dim, int6
 hipError_t launch_build_untile(const uint8_t *tiles, int64_t n, int32_t pb, int32_t w16, int32_t tile_stride, uint8_t *codes_rm,
                                hipStream_t s);
 
+// exact rerank (bbq_rerank_kernels.hip): one wave per 64 candidates of a query; max_count = longest candidate list
+hipError_t launch_rerank(const RerankArgs &a, int n_queries, int64_t max_count, hipStream_t s);
+
 }  // namespace bbq

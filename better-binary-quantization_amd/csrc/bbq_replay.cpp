@@ -86,6 +86,16 @@ int64_t HeapReplay::finish(int32_t *out_idx, float *out_score) {
   return n;
 }
 
+int64_t HeapReplay::drain_ascending(int32_t *out_tag, double *out_score) {
+  const int64_t n = (int64_t)heap_.size();
+  for (int64_t j = 0; j < n; ++j) {
+    const Item it = pop();
+    out_tag[j] = it.index;
+    out_score[j] = it.score;
+  }
+  return n;
+}
+
 }  // namespace bbq
 
 extern "C" {

@@ -40,8 +40,20 @@ export declare class BinaryQuantizationFormat {
   getScorer(): BinaryQuantizedScorer;
 }
 export interface TopKCandidate { index: number; quantizedScore: number; trueScore: number; }
-export declare function getOversampledTopKWithHeap(query: Float32Array, quantizedVectors: any, vectors: Float32Array[], k: number, oversampleFactor: number, format: BinaryQuantizationFormat): TopKCandidate[];
-export declare function getOversampledTopKWithSort(query: Float32Array, quantizedVectors: any, vectors: Float32Array[], k: number, oversampleFactor: number, format: BinaryQuantizationFormat): TopKCandidate[];
+/** the original fp32 vectors resident on the GPU; accepted wherever the selectors take `vectors` */
+export declare class DeviceVectors {
+  constructor(vectors: Float32Array[], device?: number);
+  readonly length: number;
+  readonly dim: number;
+  /** computeSimilarity(query, vectors[rows[j]]) (f64, bit-identical to src/vectorSimilarity.ts); default COSINE */
+  trueScores(query: Float32Array, rows: ArrayLike<number>, similarityFunction?: VectorSimilarityFunction): Float64Array;
+  dispose(): void;
+}
+export declare function createDeviceVectors(vectors: Float32Array[], device?: number): DeviceVectors;
+export declare function getOversampledTopKWithHeap(query: Float32Array, quantizedVectors: any, vectors: Float32Array[] | DeviceVectors, k: number, oversampleFactor: number, format: BinaryQuantizationFormat): TopKCandidate[];
+export declare function getOversampledTopKWithSort(query: Float32Array, quantizedVectors: any, vectors: Float32Array[] | DeviceVectors, k: number, oversampleFactor: number, format: BinaryQuantizationFormat): TopKCandidate[];
+/** extension: the whole recipe for many queries in one native call */
+export declare function getOversampledTopKBatch(queries: Float32Array[], quantizedVectors: any, vectors: DeviceVectors, k: number, oversampleFactor: number, format: BinaryQuantizationFormat, selector?: 'heap' | 'sort'): TopKCandidate[][];
 export declare const DEFAULT_CONFIG: { readonly queryBits: 4; readonly indexBits: 1; readonly quantizer: { readonly similarityFunction: VectorSimilarityFunction.COSINE; readonly lambda: 0.1; readonly iters: 5 } };
 export declare function createBinaryQuantizationFormat(config?: BinaryQuantizationConfig): BinaryQuantizationFormat;
 export declare function quickQuantize(vectors: Float32Array[], similarityFunction?: VectorSimilarityFunction): { quantizedVectors: BinarizedByteVectorValues; queryQuantizer: OptimizedScalarQuantizer };

@@ -300,17 +300,54 @@ function computeCosineSimilarity(a, b) {
   return dp / (Math.sqrt(na) * Math.sqrt(nb));
 }
 
+/**
+ * The original fp32 vectors resident on the GPU (libbbq bbq_vectors_*).  Pass it wherever the reference's selectors
+ * take `vectors: Float32Array[]`: the per-candidate computeCosineSimilarity then runs on the device
+ * (bbq_rerank_scores: f64, index order, bit-identical), everything else stays as in the reference.
+ */
+class DeviceVectors {
+  constructor(vectors, device) {
+    if (!vectors || vectors.length === 0) throw new Error('向量集合不能为空');
+    this.length = vectors.length;
+    this.dim = vectors[0].length;
+    for (let i = 0; i < vectors.length; i++) if (!vectors[i] || vectors[i].length !== this.dim) throw new Error('向量维度不匹配');
+    this._h = native.vectorsCreate(flatten(vectors, this.dim), this.length, this.dim, device === undefined ? 0 : device);
+  }
+  /** computeSimilarity(query, vectors[rows[j]]) for all j (similarity: a VectorSimilarityFunction; default COSINE) */
+  trueScores(query, rows, similarityFunction) {
+    if (!query) throw new Error('向量不能为空');
+    if (query.length !== this.dim) throw new Error('向量维度不匹配');
+    const sim = similarityFunction === undefined ? 1 : simOrdinal(similarityFunction);
+    return native.rerankScores(this._handle(), 1, Float32Array.from(query), Float64Array.of(0, rows.length), Int32Array.from(rows), sim);
+  }
+  _handle() { if (!this._h) throw new Error('向量不能为空'); return this._h; }
+  dispose() { if (this._h) { native.vectorsDestroy(this._h); this._h = null; } }
+}
+function createDeviceVectors(vectors, device) { return new DeviceVectors(vectors, device); }
+
+// candidates of the oversampled search with their true scores; host arrays follow the reference line by line,
+// a DeviceVectors handle moves the similarity loop to the GPU (missing vectors cannot occur there: rows < length)
+function rerankCandidates(query, results, vectors) {
+  if (vectors instanceof DeviceVectors) {
+    const rows = new Int32Array(results.length);
+    for (let i = 0; i < results.length; i++) rows[i] = results[i].index;
+    const ts = results.length ? vectors.trueScores(query, rows) : [];
+    return results.map(function (r, i) { return { index: r.index, quantizedScore: r.score, trueScore: ts[i] }; });
+  }
+  return results.map(function (r) {
+    const v = vectors[r.index];
+    return v ? { index: r.index, quantizedScore: r.score, trueScore: computeCosineSimilarity(query, v) } : null;
+  });
+}
+
 /** getOversampledTopKWithHeap, src/topKSelector.ts:29-79 */
 function getOversampledTopKWithHeap(query, quantizedVectors, vectors, k, oversampleFactor, format) {
   const results = format.searchNearestNeighbors(query, quantizedVectors, k * oversampleFactor);
   const heap = new MinHeap(function (a, b) { return a.trueScore - b.trueScore; });
-  for (const result of results) {
-    const vector = vectors[result.index];
-    if (!vector) continue;
-    const trueScore = computeCosineSimilarity(query, vector);
-    const cand = { index: result.index, quantizedScore: result.score, trueScore: trueScore };
+  for (const cand of rerankCandidates(query, results, vectors)) {
+    if (!cand) continue;
     if (heap.size() < k) heap.push(cand);
-    else { const p = heap.peek(); if (p && trueScore > p.trueScore) { heap.pop(); heap.push(cand); } }
+    else { const p = heap.peek(); if (p && cand.trueScore > p.trueScore) { heap.pop(); heap.push(cand); } }
   }
   const topK = [];
   while (!heap.isEmpty()) { const it = heap.pop(); if (it) topK.push(it); }
@@ -321,12 +358,40 @@ function getOversampledTopKWithHeap(query, quantizedVectors, vectors, k, oversam
 /** getOversampledTopKWithSort, src/topKSelector.ts:92-115 */
 function getOversampledTopKWithSort(query, quantizedVectors, vectors, k, oversampleFactor, format) {
   const results = format.searchNearestNeighbors(query, quantizedVectors, k * oversampleFactor);
-  const cands = results.map(function (r) {
-    const v = vectors[r.index];
-    return v ? { index: r.index, quantizedScore: r.score, trueScore: computeCosineSimilarity(query, v) } : null;
-  }).filter(function (c) { return c !== null; });
+  const cands = rerankCandidates(query, results, vectors).filter(function (c) { return c !== null; });
   cands.sort(function (a, b) { return b.trueScore - a.trueScore; });
   return cands.slice(0, k);
+}
+
+/**
+ * extension (not in the reference): the whole recipe for many queries in one native call (bbq_search_rerank_batch):
+ * oversampled search, true scores and the selector ('heap' | 'sort') all behind the C ABI.
+ */
+function getOversampledTopKBatch(queries, quantizedVectors, deviceVectors, k, oversampleFactor, format, selector) {
+  if (!(deviceVectors instanceof DeviceVectors)) throw new Error('getOversampledTopKBatch needs createDeviceVectors(vectors)');
+  if (k < 0) throw new Error('k值不能为负数');
+  const dim = quantizedVectors.dimension(), nq = queries.length;
+  if (k === 0) return queries.map(function () { return []; });
+  const q = format.getQuantizer(), sim = simOrdinal(q.similarityFunction), qb = format.getConfig().queryBits;
+  const flat = new Float32Array(nq * dim), qq = new Uint8Array(nq * dim), qc = new Float64Array(nq * 4);
+  for (let i = 0; i < nq; i++) {
+    const v = queries[i];
+    if (!v) throw new Error('查询向量不能为空');
+    if (v.length !== dim) throw new Error('查询向量维度与目标向量维度不匹配');
+    flat.set(v, i * dim);
+    const r = native.quantizeQuery(Float32Array.from(v), quantizedVectors.getCentroid(), sim, qb, q.lambda, q.iters, true);
+    qq.set(r.quantizedQuery, i * dim);
+    qc.set(r.corrections, i * 4);
+  }
+  const r = native.searchRerankBatch(quantizedVectors._deviceIndex(), deviceVectors._handle(), nq, flat, qq, qc, qb, sim, k,
+    oversampleFactor, selector === 'sort' ? 1 : 0, 1);
+  const out = [];
+  for (let i = 0; i < nq; i++) {
+    const res = [], n = r.counts[i], base = i * r.stride;
+    for (let j = 0; j < n; j++) res.push({ index: r.indices[base + j], quantizedScore: r.quantized[base + j], trueScore: r.trueScores[base + j] });
+    out.push(res);
+  }
+  return out;
 }
 
 // ------------------------------------------------------------------ src/index.ts:62-111
@@ -354,7 +419,8 @@ module.exports = {
   QUERY_BITS, INDEX_BITS, FOUR_BIT_SCALE, DEFAULT_LAMBDA, DEFAULT_ITERS,
   BinaryQuantizationFormat, OptimizedScalarQuantizer, BinaryQuantizedScorer, MinHeap,
   createBinaryQuantizationFormat, quickQuantize, quickSearch,
-  getOversampledTopKWithHeap, getOversampledTopKWithSort, computeCosineSimilarity,
+  getOversampledTopKWithHeap, getOversampledTopKWithSort, getOversampledTopKBatch, computeCosineSimilarity,
+  DeviceVectors, createDeviceVectors,
   deviceCount: native.deviceCount,
   _native: native,
 };

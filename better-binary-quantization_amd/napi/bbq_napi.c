@@ -307,6 +307,114 @@ static napi_value Stats(napi_env env, napi_callback_info info) {
   return o;
 }
 
+/* ---- oversample + exact rerank (bbq_vectors_*, bbq_rerank_scores, bbq_search_rerank_batch) */
+static void finalize_vectors(napi_env env, void *data, void *hint) {
+  (void)env; (void)hint;
+  bbq_vectors **box = (bbq_vectors **)data;
+  if (*box) bbq_vectors_destroy(*box);
+  free(box);
+}
+
+static bbq_vectors *unbox_vectors(napi_env env, napi_value v) {
+  void *p = NULL;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p || !*(bbq_vectors **)p) {
+    napi_throw_error(env, NULL, "向量不能为空");
+    return NULL;
+  }
+  return *(bbq_vectors **)p;
+}
+
+/* vectorsCreate(flat Float32Array, n, dim, device) -> external */
+static napi_value VectorsCreate(napi_env env, napi_callback_info info) {
+  napi_value a[4];
+  if (!get_args(env, info, 4, a)) return NULL;
+  void *vec; size_t vlen;
+  int64_t n, dim, dev;
+  if (!get_typed(env, a[0], napi_float32_array, &vec, &vlen) || !get_i64(env, a[1], &n) || !get_i64(env, a[2], &dim) ||
+      !get_i64(env, a[3], &dev)) return NULL;
+  if (n < 0 || dim <= 0 || (size_t)(n * dim) != vlen) { napi_throw_range_error(env, NULL, "bbq_napi: n*dim does not match the array"); return NULL; }
+  bbq_vectors **box = (bbq_vectors **)calloc(1, sizeof *box);
+  int rc = bbq_vectors_create((const float *)vec, n, (int32_t)dim, (int32_t)dev, box);
+  if (rc != BBQ_OK) { free(box); return throw_bbq(env, rc); }
+  napi_value ext;
+  if (napi_create_external(env, box, finalize_vectors, NULL, &ext) != napi_ok) { bbq_vectors_destroy(*box); free(box); napi_throw_error(env, NULL, "bbq_napi: external"); return NULL; }
+  return ext;
+}
+
+/* vectorsDestroy(handle) */
+static napi_value VectorsDestroy(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  void *p = NULL;
+  if (napi_get_value_external(env, a[0], &p) == napi_ok && p) {
+    bbq_vectors **box = (bbq_vectors **)p;
+    if (*box) { bbq_vectors_destroy(*box); *box = NULL; }
+  }
+  napi_value u; napi_get_undefined(env, &u); return u;
+}
+
+/* rerankScores(vectors, nq, queries Float32Array[nq*dim], offsets Float64Array[nq+1], rows Int32Array, trueSim) -> Float64Array */
+static napi_value RerankScores(napi_env env, napi_callback_info info) {
+  napi_value a[6];
+  if (!get_args(env, info, 6, a)) return NULL;
+  bbq_vectors *v = unbox_vectors(env, a[0]);
+  if (!v) return NULL;
+  void *q, *off, *rows; size_t ql, ol, rl;
+  int64_t nq, sim;
+  if (!get_i64(env, a[1], &nq) || !get_typed(env, a[2], napi_float32_array, &q, &ql) || !get_typed(env, a[3], napi_float64_array, &off, &ol) ||
+      !get_typed(env, a[4], napi_int32_array, &rows, &rl) || !get_i64(env, a[5], &sim)) return NULL;
+  if (nq < 0 || ql != (size_t)nq * (size_t)bbq_vectors_dimension(v)) { napi_throw_error(env, "BBQ6", "向量维度不匹配"); return NULL; }
+  if (ol != (size_t)nq + 1) { napi_throw_range_error(env, NULL, "bbq_napi: offsets must have nq+1 entries"); return NULL; }
+  int64_t *o64 = (int64_t *)calloc((size_t)nq + 1, sizeof(int64_t));
+  for (int64_t i = 0; i <= nq; ++i) o64[i] = (int64_t)((double *)off)[i];
+  if (o64[nq] < 0 || (size_t)o64[nq] != rl) { free(o64); napi_throw_range_error(env, NULL, "bbq_napi: offsets do not match rows"); return NULL; }
+  void *out;
+  napi_value t = new_typed(env, napi_float64_array, rl, 8, &out);
+  if (!t) { free(o64); napi_throw_error(env, NULL, "bbq_napi: allocation failed"); return NULL; }
+  int rc = bbq_rerank_scores(v, (int32_t)nq, (const float *)q, o64, (const int32_t *)rows, (int32_t)sim, (double *)out);
+  free(o64);
+  if (rc != BBQ_OK) return throw_bbq(env, rc);
+  return t;
+}
+
+/* searchRerankBatch(index, vectors, nq, queries Float32Array, qquant Uint8Array, qcorr Float64Array, queryBits, sim, k, factor, selector, trueSim)
+ *   -> {indices Int32Array[nq*k], quantized Float32Array[nq*k], trueScores Float64Array[nq*k], counts Float64Array[nq], stride} */
+static napi_value SearchRerankBatch(napi_env env, napi_callback_info info) {
+  napi_value a[12];
+  if (!get_args(env, info, 12, a)) return NULL;
+  bbq_index *ix = unbox(env, a[0]);
+  if (!ix) return NULL;
+  bbq_vectors *v = unbox_vectors(env, a[1]);
+  if (!v) return NULL;
+  void *q, *qq, *qc; size_t fl, ql, cl;
+  int64_t nq, qb, sim, k, factor, selector, tsim;
+  if (!get_i64(env, a[2], &nq) || !get_typed(env, a[3], napi_float32_array, &q, &fl) || !get_typed(env, a[4], napi_uint8_array, &qq, &ql) ||
+      !get_typed(env, a[5], napi_float64_array, &qc, &cl) || !get_i64(env, a[6], &qb) || !get_i64(env, a[7], &sim) || !get_i64(env, a[8], &k) ||
+      !get_i64(env, a[9], &factor) || !get_i64(env, a[10], &selector) || !get_i64(env, a[11], &tsim)) return NULL;
+  const size_t dim = (size_t)bbq_index_dimension(ix);
+  if (nq < 0 || ql != (size_t)nq * dim || fl != (size_t)nq * dim || cl != (size_t)nq * 4) {
+    napi_throw_error(env, "BBQ6", "查询向量维度与目标向量维度不匹配"); return NULL;
+  }
+  if (k < 0) { napi_throw_error(env, "BBQ7", "k值不能为负数"); return NULL; }
+  void *oi, *oq, *ot, *on;
+  napi_value ti = new_typed(env, napi_int32_array, (size_t)(nq * k), 4, &oi);
+  napi_value tq = new_typed(env, napi_float32_array, (size_t)(nq * k), 4, &oq);
+  napi_value tt = new_typed(env, napi_float64_array, (size_t)(nq * k), 8, &ot);
+  napi_value tn = new_typed(env, napi_float64_array, (size_t)nq, 8, &on);
+  if (!ti || !tq || !tt || !tn) { napi_throw_error(env, NULL, "bbq_napi: allocation failed"); return NULL; }
+  int64_t *cnt = (int64_t *)calloc((size_t)nq + 1, sizeof(int64_t));
+  int rc = bbq_search_rerank_batch(ix, v, (int32_t)nq, (const float *)q, (const uint8_t *)qq, (const double *)qc, (int32_t)qb, (int32_t)sim, k,
+                                   (int32_t)factor, (int32_t)selector, (int32_t)tsim, (int32_t *)oi, (float *)oq, (double *)ot, cnt);
+  if (rc != BBQ_OK) { free(cnt); return throw_bbq(env, rc); }
+  for (int64_t i = 0; i < nq; ++i) ((double *)on)[i] = (double)cnt[i];
+  free(cnt);
+  napi_value o;
+  NAPI_CALL(env, napi_create_object(env, &o));
+  set_prop(env, o, "indices", ti); set_prop(env, o, "quantized", tq); set_prop(env, o, "trueScores", tt); set_prop(env, o, "counts", tn);
+  napi_value kv; napi_create_double(env, (double)k, &kv); set_prop(env, o, "stride", kv);
+  return o;
+}
+
 static napi_value Init(napi_env env, napi_value exports) {
   napi_property_descriptor d[] = {
       {"deviceCount", NULL, DeviceCount, NULL, NULL, NULL, napi_default, NULL},
@@ -320,6 +428,10 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"scoreRows", NULL, ScoreRows, NULL, NULL, NULL, napi_default, NULL},
       {"setOption", NULL, SetOption, NULL, NULL, NULL, napi_default, NULL},
       {"stats", NULL, Stats, NULL, NULL, NULL, napi_default, NULL},
+      {"vectorsCreate", NULL, VectorsCreate, NULL, NULL, NULL, napi_default, NULL},
+      {"vectorsDestroy", NULL, VectorsDestroy, NULL, NULL, NULL, napi_default, NULL},
+      {"rerankScores", NULL, RerankScores, NULL, NULL, NULL, napi_default, NULL},
+      {"searchRerankBatch", NULL, SearchRerankBatch, NULL, NULL, NULL, napi_default, NULL},
   };
   if (napi_define_properties(env, exports, sizeof d / sizeof d[0], d) != napi_ok) return NULL;
   return exports;

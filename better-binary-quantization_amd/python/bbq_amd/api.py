@@ -136,3 +136,43 @@ def quickQuantize(vectors, similarityFunction=VectorSimilarityFunction.COSINE):
 def quickSearch(queryVector, targetVectors, k, similarityFunction=VectorSimilarityFunction.COSINE):
     f = BinaryQuantizationFormat({"quantizer": {"similarityFunction": similarityFunction, "lambda": 0.1, "iters": 5}})
     return f.searchNearestNeighbors(queryVector, f.quantizeVectors(targetVectors)["quantizedVectors"], k)
+
+
+def createDeviceVectors(vectors, device=0):
+    """upload the original fp32 vectors once; pass the handle wherever the reference's selectors take `vectors`"""
+    return capi.Vectors(np.asarray(vectors, np.float32), device)
+
+
+def _oversampled(query, quantizedVectors, vectors, k, oversampleFactor, fmt, selector):
+    # src/topKSelector.ts:29-115: searchNearestNeighbors(k*factor) -> computeCosineSimilarity per candidate -> select.
+    # Search, true scores and selection all happen behind bbq_search_rerank_batch.
+    oversampled = k * oversampleFactor
+    if oversampled < 0:
+        raise Exception("k值不能为负数")
+    if len(query) != quantizedVectors.dimension():
+        raise Exception("查询向量维度与目标向量维度不匹配")
+    if oversampled == 0:
+        return []
+    owned = not isinstance(vectors, capi.Vectors)
+    dv = createDeviceVectors(vectors) if owned else vectors
+    try:
+        sim = capi.SIMS[fmt._sim]
+        q = np.ascontiguousarray(query, np.float32)
+        qq, qc = capi.quantize_query(q, quantizedVectors.getCentroid(), sim, fmt._config["queryBits"], fmt._lambda, fmt._iters,
+                                     search_path=True)
+        idx, qs, ts, cnt = capi.search_rerank_batch(quantizedVectors._device(), dv, q[None, :], qq[None, :], qc[None, :],
+                                                    fmt._config["queryBits"], sim, k, oversampleFactor, selector, 1)
+    except capi.BBQError as e:
+        raise Exception(str(e))
+    finally:
+        if owned:
+            dv.close()
+    return [{"index": int(idx[0, j]), "quantizedScore": float(qs[0, j]), "trueScore": float(ts[0, j])} for j in range(int(cnt[0]))]
+
+
+def getOversampledTopKWithHeap(query, quantizedVectors, vectors, k, oversampleFactor, format):
+    return _oversampled(query, quantizedVectors, vectors, k, oversampleFactor, format, 0)
+
+
+def getOversampledTopKWithSort(query, quantizedVectors, vectors, k, oversampleFactor, format):
+    return _oversampled(query, quantizedVectors, vectors, k, oversampleFactor, format, 1)

@@ -20,7 +20,8 @@ SYMBOLS = [
     "bbq_index_destroy", "bbq_index_size", "bbq_index_dimension", "bbq_index_bytes_per_row", "bbq_search",
     "bbq_search_batch", "bbq_score_rows", "bbq_shard_scan", "bbq_shard_list_cap", "bbq_replay", "bbq_replay_batch",
     "bbq_quantize_vectors", "bbq_quantize_query", "bbq_quantize_query_vector", "bbq_centroid_dp", "bbq_get_stats",
-    "bbq_reset_stats", "bbq_set_option",
+    "bbq_reset_stats", "bbq_set_option", "bbq_vectors_create", "bbq_vectors_destroy", "bbq_vectors_size",
+    "bbq_vectors_dimension", "bbq_rerank_scores", "bbq_search_rerank_batch",
 ]
 
 
@@ -80,6 +81,15 @@ def lib():
     L.bbq_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.bbq_reset_stats.argtypes = [vp]
     L.bbq_set_option.argtypes = [vp, C.c_char_p, i64]
+    L.bbq_vectors_create.argtypes = [vp, i64, i32, i32, C.POINTER(vp)]
+    L.bbq_vectors_destroy.argtypes = [vp]
+    L.bbq_vectors_destroy.restype = None
+    L.bbq_vectors_size.argtypes = [vp]
+    L.bbq_vectors_size.restype = i64
+    L.bbq_vectors_dimension.argtypes = [vp]
+    L.bbq_vectors_dimension.restype = i32
+    L.bbq_rerank_scores.argtypes = [vp, i32, vp, vp, vp, i32, vp]
+    L.bbq_search_rerank_batch.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, i64, i32, i32, i32, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -235,6 +245,66 @@ class Index:
         _chk(lib().bbq_shard_scan(self._h, qq.shape[0], _ptr(qq), _ptr(qc), query_bits, sim, k, dev_packed_ptr, packed_cap,
                                  dev_offsets_ptr, dev_flags_ptr, C.byref(total)))
         return total.value
+
+
+class Vectors:
+    """the original fp32 vectors resident on one GPU (bbq_vectors_*): the `vectors` argument of the reference's
+    oversample selectors (src/topKSelector.ts:29-115)"""
+
+    def __init__(self, vectors, device=0):
+        v = np.ascontiguousarray(vectors, np.float32)
+        if v.ndim != 2:
+            raise BBQError(ERR_INVALID_ARG, "vectors must be [n, dim]")
+        self.n, self.dim = int(v.shape[0]), int(v.shape[1])
+        h = C.c_void_p()
+        _chk(lib().bbq_vectors_create(_ptr(v), self.n, self.dim, device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().bbq_vectors_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def rerank_scores(self, queries, rows_per_query, true_sim=1):
+        """computeSimilarity(queries[q], vectors[r]) for r in rows_per_query[q]; returns a list of f64 arrays"""
+        q = np.ascontiguousarray(queries, np.float32)
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise BBQError(ERR_DIM_MISMATCH, "向量维度不匹配")
+        lists = [np.ascontiguousarray(r, np.int32) for r in rows_per_query]
+        if len(lists) != q.shape[0]:
+            raise BBQError(ERR_INVALID_ARG, "one candidate list per query")
+        off = np.zeros(len(lists) + 1, np.int64)
+        off[1:] = np.cumsum([a.shape[0] for a in lists])
+        rows = np.concatenate(lists) if lists else np.zeros(0, np.int32)
+        rows = np.ascontiguousarray(rows, np.int32)
+        out = np.zeros(int(off[-1]), np.float64)
+        _chk(lib().bbq_rerank_scores(self._h, q.shape[0], _ptr(q), _ptr(off), _ptr(rows), true_sim, _ptr(out)))
+        return [out[off[i]:off[i + 1]] for i in range(len(lists))]
+
+
+def search_rerank_batch(index, vectors, queries, qquant, qcorr, query_bits, sim, k, factor, selector=0, true_sim=1):
+    """oversample k*factor on `index`, exact true scores on `vectors`, the reference's selector (0 heap, 1 sort).
+    Returns (idx [nq,k], quantized f32 [nq,k], true f64 [nq,k], counts)."""
+    q = np.ascontiguousarray(queries, np.float32)
+    qq = np.ascontiguousarray(qquant, np.uint8)
+    qc = np.ascontiguousarray(qcorr, np.float64)
+    nq = qq.shape[0]
+    if nq and (qq.shape[1] != index.dim or q.shape[1] != index.dim):
+        raise BBQError(ERR_DIM_MISMATCH, "查询向量维度与目标向量维度不匹配")
+    kk = max(int(k), 0)
+    idx = np.zeros((nq, kk), np.int32)
+    qs = np.zeros((nq, kk), np.float32)
+    ts = np.zeros((nq, kk), np.float64)
+    cnt = np.zeros(nq, np.int64)
+    _chk(lib().bbq_search_rerank_batch(index._h, vectors._h, nq, _ptr(q), _ptr(qq), _ptr(qc), query_bits, sim, k, factor,
+                                       selector, true_sim, _ptr(idx), _ptr(qs), _ptr(ts), _ptr(cnt)))
+    return idx, qs, ts, cnt
 
 
 def replay(lists, n_total, k):

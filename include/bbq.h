@@ -168,6 +168,37 @@ int bbq_replay_batch(int32_t n_sources, const bbq_cand *const *packed, const int
                      float *out_score, int64_t *out_n);
 
 /* ------------------------------------------------------------------------------------------
+ * Oversample + exact rerank (the reference's recall recipe: src/topKSelector.ts:29-115,
+ * tests/recall-common.ts:188-213).  The ORIGINAL fp32 vectors stay resident in HBM next to the 1-bit
+ * index; true scores are computeSimilarity (src/vectorSimilarity.ts:14-126): f64, accumulated in index
+ * order, bit-identical to the reference.
+ */
+typedef struct bbq_vectors bbq_vectors;
+/* vectors [n*dim] row-major (the Float32Array[] the reference's selectors take as `vectors`), copied to the device */
+int bbq_vectors_create(const float *vectors, int64_t n, int32_t dim, int32_t device, bbq_vectors **out);
+void bbq_vectors_destroy(bbq_vectors *v);
+int64_t bbq_vectors_size(const bbq_vectors *v);
+int32_t bbq_vectors_dimension(const bbq_vectors *v);
+/* computeSimilarity(queries[q], vectors[rows[j]], true_sim) for j in [offsets[q], offsets[q+1]), q < n_queries.
+ * queries [n_queries*dim] raw fp32 (NOT normalised, exactly what the caller would hand computeCosineSimilarity);
+ * offsets [n_queries+1] ascending from 0; out_true [offsets[n_queries]].  A row outside [0, n) fails with
+ * BBQ_ERR_INVALID_ARG (the reference skips / throws on a missing vector, src/topKSelector.ts:44-45). */
+int bbq_rerank_scores(bbq_vectors *v, int32_t n_queries, const float *queries, const int64_t *offsets,
+                      const int32_t *rows, int32_t true_sim, double *out_true);
+/* The whole recipe for n_queries queries: searchNearestNeighbors with k*factor on idx (arguments as
+ * bbq_search_batch), true scores of those candidates on v, then the reference's selection:
+ *   selector 0  getOversampledTopKWithHeap (src/topKSelector.ts:29-79): MinHeap of k on trueScore, drained, sorted
+ *   selector 1  getOversampledTopKWithSort (:92-115): stable sort by trueScore descending, first k
+ * true_sim is the similarity of the rerank (the reference's selectors always use COSINE = 1).
+ * out_idx / out_quantized / out_true [n_queries*k] (query q at offset q*k), out_n [n_queries].
+ * NaN true scores (non-finite inputs) make the reference's final Array.sort order engine-defined; here they sort as
+ * "equal to everything", which is what the comparator returns. */
+int bbq_search_rerank_batch(bbq_index *idx, bbq_vectors *v, int32_t n_queries, const float *queries,
+                            const uint8_t *qquant, const double *qcorr, int32_t query_bits, int32_t sim, int64_t k,
+                            int32_t factor, int32_t selector, int32_t true_sim, int32_t *out_idx,
+                            float *out_quantized, double *out_true, int64_t *out_n);
+
+/* ------------------------------------------------------------------------------------------
  * Host-side quantizer (multithreaded C++): what the JS host calls for quantizeVectors /
  * quantizeQueryVector so that the drop-in API needs no TypeScript arithmetic.
  */

@@ -69,4 +69,42 @@ function normalise(v) {
   T.check(JSON.stringify(batch32) === JSON.stringify(batch), 'shared sweep (32) equals one sweep per query');
   index.setDeviceOption('sweep_share', 1);
 })();
+// exact rerank on the device (DeviceVectors) against the reference's values: true scores, both selectors, the batch recipe
+T.goldenNames().filter(function (n) { return /^rerank_/.test(n); }).forEach(function (name) {
+  const g = T.loadGolden(name);
+  const fb = T.dec(g.base_f32, Float32Array), fq = T.dec(g.queries_f32, Float32Array);
+  const base = [], queries = [];
+  for (let i = 0; i < g.n; i++) base.push(fb.slice(i * g.dim, (i + 1) * g.dim));
+  for (let i = 0; i < g.nq; i++) queries.push(fq.slice(i * g.dim, (i + 1) * g.dim));
+  const dv = bbq.createDeviceVectors(base);
+  const all = new Int32Array(g.n); for (let i = 0; i < g.n; i++) all[i] = i;
+  ['EUCLIDEAN', 'COSINE', 'MAXIMUM_INNER_PRODUCT'].forEach(function (sim) {
+    const want = T.dec(g.true_f64[sim], Float64Array);
+    for (let qi = 0; qi < g.nq; qi++)
+      T.check(T.sameBits(dv.trueScores(queries[qi], all, sim), want.subarray(qi * g.n, (qi + 1) * g.n)), name + ' true scores ' + sim + ' q' + qi);
+  });
+  const fmt = new bbq.BinaryQuantizationFormat({ queryBits: 4, indexBits: 1, quantizer: { similarityFunction: 'COSINE', lambda: g.lambda, iters: g.iters } });
+  const index = fmt.quantizeVectors(base).quantizedVectors;
+  const same = function (got, rec) {
+    return T.sameBits(Int32Array.from(got.map(function (c) { return c.index; })), T.dec(rec.idx_i32, Int32Array)) &&
+      T.sameBits(Float32Array.from(got.map(function (c) { return c.quantizedScore; })), T.dec(rec.quantized_f32, Float32Array)) &&
+      T.sameBits(Float64Array.from(got.map(function (c) { return c.trueScore; })), T.dec(rec.true_f64, Float64Array));
+  };
+  const factors = Array.from(new Set(g.oversample.map(function (r) { return r.factor; })));
+  factors.forEach(function (f) {
+    const bh = bbq.getOversampledTopKBatch(queries, index, dv, g.k, f, fmt, 'heap');
+    const bs = bbq.getOversampledTopKBatch(queries, index, dv, g.k, f, fmt, 'sort');
+    g.oversample.filter(function (r) { return r.factor === f; }).forEach(function (rec) {
+      const q = queries[rec.query], tag = name + ' q' + rec.query + ' x' + f;
+      T.check(same(bbq.getOversampledTopKWithHeap(q, index, dv, g.k, f, fmt), rec.heap), tag + ' heap selector, device vectors');
+      T.check(same(bbq.getOversampledTopKWithSort(q, index, dv, g.k, f, fmt), rec.sort), tag + ' sort selector, device vectors');
+      T.check(same(bbq.getOversampledTopKWithHeap(q, index, base, g.k, f, fmt), rec.heap), tag + ' heap selector, host vectors');
+      T.check(same(bh[rec.query], rec.heap), tag + ' batch recipe heap');
+      T.check(same(bs[rec.query], rec.sort), tag + ' batch recipe sort');
+    });
+  });
+  dv.dispose();
+  index.dispose();
+});
+
 T.finish('js gpu_parity');

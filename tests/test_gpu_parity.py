@@ -578,3 +578,146 @@ def test_generic_row_widths(dim, qb, sim):
             np.testing.assert_array_equal(canon64(g64), canon64(s64))
     finally:
         ix.close()
+
+
+# ---------------------------------------------------------------- oversample + exact rerank
+
+RERANK = O.golden_names("rerank_*")
+
+
+def _rerank_case(name):
+    g = O.load_golden(name)
+    n, dim, nq = g["n"], g["dim"], g["nq"]
+    base = O.dec(g["base_f32"], np.float32).reshape(n, dim)
+    queries = O.dec(g["queries_f32"], np.float32).reshape(nq, dim)
+    return g, base, queries
+
+
+@pytest.mark.parametrize("name", RERANK)
+def test_rerank_true_scores_golden(name):
+    """computeSimilarity of every (query, row), all three functions, bit for bit against the reference's values"""
+    g, base, queries = _rerank_case(name)
+    dv = B.Vectors(base)
+    assert (dv.n, dv.dim) == base.shape
+    all_rows = np.arange(g["n"], dtype=np.int32)
+    for sim_name, sim in O.SIMS.items():
+        got = dv.rerank_scores(queries, [all_rows] * g["nq"], sim)
+        ref = O.dec(g["true_f64"][sim_name], np.float64).reshape(g["nq"], g["n"])
+        for qi in range(g["nq"]):
+            np.testing.assert_array_equal(canon64(got[qi]), canon64(ref[qi]))
+    dv.close()
+
+
+@pytest.mark.parametrize("name", RERANK)
+def test_search_rerank_selectors_golden(name):
+    """getOversampledTopKWithHeap / WithSort end to end (search k*factor, true scores, selection) vs the reference"""
+    g, base, queries = _rerank_case(name)
+    k = g["k"]
+    codes, corr, cen = B.quantize_vectors(base, 1, 1, g["lambda"], g["iters"])
+    ix = B.Index(codes, corr, g["dim"], B.centroid_dp(cen))
+    dv = B.Vectors(base)
+    qs = [B.quantize_query(q, cen, 1, 4, g["lambda"], g["iters"]) for q in queries]
+    qq, qc = np.stack([a for a, _ in qs]), np.stack([b for _, b in qs])
+    for f in sorted({r["factor"] for r in g["oversample"]}):
+        for sel, how in ((0, "heap"), (1, "sort")):
+            idx, qsc, tsc, cnt = B.search_rerank_batch(ix, dv, queries, qq, qc, 4, 1, k, f, sel, 1)
+            for rec in (r for r in g["oversample"] if r["factor"] == f):
+                qi = rec["query"]
+                m = int(cnt[qi])
+                np.testing.assert_array_equal(idx[qi, :m], O.dec(rec[how]["idx_i32"], np.int32))
+                np.testing.assert_array_equal(canon32(qsc[qi, :m]), canon32(O.dec(rec[how]["quantized_f32"], np.float32)))
+                np.testing.assert_array_equal(canon64(tsc[qi, :m]), canon64(O.dec(rec[how]["true_f64"], np.float64)))
+    # the Python mirror of the reference's function names goes through the same entry point
+    fmt = B.BinaryQuantizationFormat({"queryBits": 4, "indexBits": 1,
+                                            "quantizer": {"similarityFunction": "COSINE", "lambda": g["lambda"], "iters": g["iters"]}})
+    qv = fmt.quantizeVectors(base)["quantizedVectors"]
+    rec = g["oversample"][0]
+    got = B.getOversampledTopKWithHeap(queries[rec["query"]], qv, dv, k, rec["factor"], fmt)
+    assert [x["index"] for x in got] == list(O.dec(rec["heap"]["idx_i32"], np.int32))
+    got = B.getOversampledTopKWithSort(queries[rec["query"]], qv, base, k, rec["factor"], fmt)
+    assert [x["index"] for x in got] == list(O.dec(rec["sort"]["idx_i32"], np.int32))
+    np.testing.assert_array_equal(canon64([x["trueScore"] for x in got]), canon64(O.dec(rec["sort"]["true_f64"], np.float64)))
+    dv.close()
+    ix.close()
+
+
+@pytest.mark.parametrize("dim", [1, 31, 33, 130, 768, 1536])
+def test_rerank_ragged_lists_vs_oracle(dim):
+    """ragged candidate lists (0, 1, 63, 64, 65, 700 rows, repeats allowed) at dims around the 32-column stage"""
+    rng = np.random.default_rng(dim)
+    n = 3000
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    base[17] = 0
+    queries = rng.standard_normal((6, dim)).astype(np.float32)
+    lens = [0, 1, 63, 64, 65, 700]
+    lists = [rng.integers(0, n, m).astype(np.int32) for m in lens]
+    lists[3][5] = 17
+    dv = B.Vectors(base)
+    for sim in (0, 1, 2):
+        got = dv.rerank_scores(queries, lists, sim)
+        for qi, rows in enumerate(lists):
+            ref = O.true_similarity(queries[qi:qi + 1], base[rows], sim)[0] if len(rows) else np.zeros(0)
+            np.testing.assert_array_equal(canon64(got[qi]), canon64(ref))
+    dv.close()
+
+
+def test_rerank_selection_ties_and_small_k():
+    """duplicate rows give exactly equal true scores: the heap's history and the stable sort decide the order"""
+    rng = np.random.default_rng(5)
+    pool = rng.standard_normal((20, 64)).astype(np.float32)
+    base = pool[rng.integers(0, 20, 2000)]
+    queries = rng.standard_normal((5, 64)).astype(np.float32)
+    codes, corr, cen = B.quantize_vectors(base, 1, 1)
+    ix = B.Index(codes, corr, 64, B.centroid_dp(cen))
+    dv = B.Vectors(base)
+    qs = [B.quantize_query(q, cen, 1, 4) for q in queries]
+    qq, qc = np.stack([a for a, _ in qs]), np.stack([b for _, b in qs])
+    for k, f in ((1, 1), (7, 3), (50, 10), (300, 20)):
+        cidx, csc, ccnt = ix.search_batch(qq, qc, 4, 1, k * f)
+        for sel, how in ((0, "heap"), (1, "sort")):
+            idx, qsc, tsc, cnt = B.search_rerank_batch(ix, dv, queries, qq, qc, 4, 1, k, f, sel, 1)
+            for qi in range(5):
+                cand = cidx[qi, :ccnt[qi]]
+                t = O.true_similarity(queries[qi:qi + 1], base[cand], 1)[0]
+                pos = O.rerank_select(t, k, how)
+                m = int(cnt[qi])
+                assert m == len(pos)
+                np.testing.assert_array_equal(idx[qi, :m], cand[pos])
+                np.testing.assert_array_equal(canon64(tsc[qi, :m]), canon64(t[pos]))
+                np.testing.assert_array_equal(canon32(qsc[qi, :m]), canon32(csc[qi, :ccnt[qi]][pos]))
+    dv.close()
+    ix.close()
+
+
+def test_rerank_errors():
+    base = np.random.default_rng(1).standard_normal((100, 16)).astype(np.float32)
+    dv = B.Vectors(base)
+    q = base[:1]
+    with pytest.raises(B.BBQError):
+        dv.rerank_scores(q, [np.array([100], np.int32)], 1)
+    with pytest.raises(B.BBQError):
+        dv.rerank_scores(q, [np.array([-1], np.int32)], 1)
+    with pytest.raises(B.BBQError):
+        dv.rerank_scores(q, [np.array([1], np.int32)], 3)
+    with pytest.raises(B.BBQError):
+        dv.rerank_scores(base[:1, :8], [np.array([1], np.int32)], 1)
+    assert [len(x) for x in dv.rerank_scores(base[:2], [np.zeros(0, np.int32)] * 2, 1)] == [0, 0]
+    codes, corr, cen = B.quantize_vectors(base, 1, 1)
+    ix = B.Index(codes, corr, 16, B.centroid_dp(cen))
+    qq, qc = B.quantize_query(q[0], cen, 1, 4)
+    with pytest.raises(B.BBQError):
+        B.search_rerank_batch(ix, dv, q, qq[None], qc[None], 4, 1, 5, 0)
+    with pytest.raises(B.BBQError):
+        B.search_rerank_batch(ix, dv, q, qq[None], qc[None], 4, 1, -1, 3)
+    with pytest.raises(B.BBQError):
+        B.search_rerank_batch(ix, dv, q, qq[None], qc[None], 4, 1, 5, 3, selector=2)
+    short = B.Vectors(base[:50])
+    with pytest.raises(B.BBQError):
+        B.search_rerank_batch(ix, short, q, qq[None], qc[None], 4, 1, 5, 3)
+    idx, _, _, cnt = B.search_rerank_batch(ix, dv, q, qq[None], qc[None], 4, 1, 0, 3)
+    assert cnt[0] == 0
+    idx, _, ts, cnt = B.search_rerank_batch(ix, dv, q, qq[None], qc[None], 4, 1, 500, 3)   # k*factor > n
+    assert cnt[0] == 100 and idx[0, 0] == 0
+    short.close()
+    dv.close()
+    ix.close()
