@@ -35,10 +35,23 @@ export declare class BinaryQuantizationFormat {
   searchNearestNeighbors(queryVector: Float32Array, targetVectors: BinarizedByteVectorValues, k: number): Array<{ index: number; score: number }>;
   /** extension: many independent queries per call, pipelined on the device */
   searchNearestNeighborsBatch(queryVectors: Float32Array[], targetVectors: BinarizedByteVectorValues, k: number): Array<Array<{ index: number; score: number }>>;
+  /** src/binaryQuantizationFormat.ts:483-566 with the double-pack bug fixed: binaryValues is the packed row */
+  serializeVectorData(vectors: Float32Array[]): { vectorData: VectorDataFormat[]; metadata: MetadataFormat };
+  deserializeVectorData(vectorData: VectorDataFormat[], metadata: MetadataFormat): BinarizedByteVectorValues;
+  /** extension: <prefix>.veb (device tile records) + <prefix>.vemb (MetadataFormat + centroid) */
+  saveIndex(quantizedVectors: BinarizedByteVectorValues, pathPrefix: string): void;
+  loadIndex(pathPrefix: string): BinarizedByteVectorValues;
   getConfig(): BinaryQuantizationConfig;
   getQuantizer(): OptimizedScalarQuantizer;
   getScorer(): BinaryQuantizedScorer;
 }
+export interface VectorDataFormat { binaryValues: Uint8Array; lowerInterval: number; upperInterval: number; additionalCorrection: number; quantizedComponentSum: number; }
+export interface MetadataFormat { fieldNumber: number; vectorEncodingOrdinal: number; vectorSimilarityOrdinal: number; dimensions: number; vectorDataOffset: number; vectorDataLength: number; vectorCount: number; centroid: Float32Array; centroidSquareMagnitude: number; }
+export interface SiftVector { dimension: number; values: Float32Array; }
+export interface SiftDataset { vectors: SiftVector[]; count: number; dimension: number; }
+export declare function loadSiftVectors(filePath: string, maxVectors?: number): SiftDataset;
+export declare function loadSiftDataset(datasetDir: string, fileType?: 'base' | 'learn' | 'query', maxVectors?: number): SiftDataset;
+export declare function loadSiftQueries(datasetDir: string, maxQueries?: number): { queries: SiftVector[]; groundtruth: number[][] };
 export interface TopKCandidate { index: number; quantizedScore: number; trueScore: number; }
 /** the original fp32 vectors resident on the GPU; accepted wherever the selectors take `vectors` */
 export declare class DeviceVectors {

@@ -53,14 +53,22 @@ function corrObject(f64, off) {
 class BinarizedByteVectorValuesImpl {
   constructor(codes, corr, centroid, indexBits, size) {
     this._codes = codes; this._corr = corr; this._centroid = centroid; this._indexBits = indexBits;
-    this._size = size; this._rowBytes = size > 0 ? codes.length / size : 0;
+    this._size = size; this._rowBytes = (size > 0 && codes) ? codes.length / size : 0;
     this._device = null;
   }
   dimension() { return this._centroid.length; }
   size() { return this._size; }
+  /** host copies of the rows; an index loaded from disk fetches them from the device on first use (bbq_index_export) */
+  _host() {
+    if (!this._codes && this._device) {
+      const r = native.indexExport(this._device);
+      this._codes = r.codes; this._corr = r.corr;
+    }
+    return this;
+  }
   vectorValue(ord) {
     if (!(ord >= 0 && ord < this._size)) throw new Error('向量索引 ' + ord + ' 不存在');
-    return this._codes.subarray(ord * this._rowBytes, (ord + 1) * this._rowBytes);
+    return this._host()._codes.subarray(ord * this._rowBytes, (ord + 1) * this._rowBytes);
   }
   getUnpackedVector(ord) {
     if (!(ord >= 0 && ord < this._size)) throw new Error('未打包向量索引 ' + ord + ' 不存在');
@@ -73,7 +81,7 @@ class BinarizedByteVectorValuesImpl {
   clearUnpackedVectorCache() {}
   getCorrectiveTerms(ord) {
     if (!(ord >= 0 && ord < this._size)) throw new Error('修正项索引 ' + ord + ' 不存在');
-    return corrObject(this._corr, 4 * ord);
+    return corrObject(this._host()._corr, 4 * ord);
   }
   getCentroidDP(queryVector) {
     if (queryVector) {  // computeDotProduct(queryVector, centroid), src/vectorOperations.ts:171-185
@@ -88,12 +96,13 @@ class BinarizedByteVectorValuesImpl {
   /** device-resident copy (libbbq bbq_index); created lazily, released by dispose() or GC */
   _deviceIndex() {
     if (!this._device) {
+      if (!this._codes) throw new Error('目标向量集合不能为空');
       this._device = native.indexCreate(this._codes, this._corr, this._size, this.dimension(), this._indexBits,
         this.getCentroidDP(), Number(process.env.BBQ_DEVICE || 0));
     }
     return this._device;
   }
-  dispose() { if (this._device) { native.indexDestroy(this._device); this._device = null; } }
+  dispose() { if (this._device) { this._host(); native.indexDestroy(this._device); this._device = null; } }
   /** tuning knobs of the device index (libbbq bbq_set_option), e.g. ('sweep_share', 32) for searchNearestNeighborsBatch */
   setDeviceOption(name, value) { native.setOption(this._deviceIndex(), name, value); }
   deviceStats() { return native.stats(this._deviceIndex()); }
@@ -247,6 +256,60 @@ class BinaryQuantizationFormat {
     return out;
   }
 
+  /**
+   * serializeVectorData(vectors) -> {vectorData: VectorDataFormat[], metadata: MetadataFormat}  (:483-530, src/types.ts:78-113).
+   * The reference re-packs the already packed rows here and throws for any byte outside {0,1} (SURVEY §5); this returns
+   * what it meant to: binaryValues = the packed row, the four corrections, and the metadata record.
+   */
+  serializeVectorData(vectors) {
+    const qv = this.quantizeVectors(vectors).quantizedVectors, centroid = qv.getCentroid();
+    const vectorData = [];
+    for (let i = 0; i < qv.size(); i++) {
+      const c = qv.getCorrectiveTerms(i);
+      vectorData.push({ binaryValues: new Uint8Array(qv.vectorValue(i)), lowerInterval: c.lowerInterval, upperInterval: c.upperInterval,
+        additionalCorrection: c.additionalCorrection, quantizedComponentSum: c.quantizedComponentSum });
+    }
+    const metadata = { fieldNumber: 0, vectorEncodingOrdinal: 0, vectorSimilarityOrdinal: 0, dimensions: centroid.length,
+      vectorDataOffset: 0, vectorDataLength: 0, vectorCount: qv.size(), centroid: centroid, centroidSquareMagnitude: qv.getCentroidDP() };
+    qv.dispose();
+    return { vectorData: vectorData, metadata: metadata };
+  }
+
+  /** deserializeVectorData(vectorData, metadata) -> BinarizedByteVectorValues, searchable  (:538-566) */
+  deserializeVectorData(vectorData, metadata) {
+    const dim = metadata.dimensions, pb = Math.ceil(dim / 8), n = vectorData.length;
+    if (!metadata.centroid || metadata.centroid.length !== dim) throw new Error('向量和质心维度不匹配');
+    const codes = new Uint8Array(n * pb), corr = new Float64Array(n * 4);
+    for (let i = 0; i < n; i++) {
+      const d = vectorData[i];
+      if (!d || !d.binaryValues || d.binaryValues.length !== pb) throw new Error('向量 ' + i + ' 维度不匹配');
+      codes.set(d.binaryValues, i * pb);
+      corr[4 * i] = d.lowerInterval; corr[4 * i + 1] = d.upperInterval; corr[4 * i + 2] = d.additionalCorrection; corr[4 * i + 3] = d.quantizedComponentSum;
+    }
+    return new BinarizedByteVectorValuesImpl(codes, corr, Float32Array.from(metadata.centroid), 1, n);
+  }
+
+  /**
+   * extension: the declared-but-unused file pair of the reference (FILE_EXTENSIONS veb / vemb, src/constants.ts:52-57) as real
+   * files: <prefix>.veb holds the device tile records byte for byte, <prefix>.vemb the MetadataFormat fields + centroid.
+   */
+  saveIndex(quantizedVectors, pathPrefix) {
+    if (!quantizedVectors) throw new Error('目标向量集合不能为空');
+    native.indexSave(quantizedVectors._deviceIndex(), String(pathPrefix), quantizedVectors.getCentroid(), simOrdinal(this.quantizer.similarityFunction));
+  }
+  /** loads <prefix>.veb/.vemb straight into HBM; vectorValue()/getCorrectiveTerms() fetch the rows back lazily */
+  loadIndex(pathPrefix) {
+    const r = native.indexLoad(String(pathPrefix), Number(process.env.BBQ_DEVICE || 0));
+    if (r.sim !== simOrdinal(this.quantizer.similarityFunction)) {
+      native.indexDestroy(r.handle);
+      throw new Error('不支持的相似性函数: file was written for ordinal ' + r.sim);
+    }
+    const values = new BinarizedByteVectorValuesImpl(null, null, r.centroid, 1, r.n);
+    values._rowBytes = Math.ceil(r.dim / 8);
+    values._device = r.handle;
+    return values;
+  }
+
   getConfig() { return this.config; }
   getQuantizer() { return this.quantizer; }
   getScorer() { return this.scorer; }
@@ -394,6 +457,47 @@ function getOversampledTopKBatch(queries, quantizedVectors, deviceVectors, k, ov
   return out;
 }
 
+// ------------------------------------------------------------------ .fvecs / .ivecs (tests/benchmarks/siftDataLoader.ts:27-127)
+
+/** loadSiftVectors(filePath, maxVectors = 10000) -> {vectors: [{dimension, values}], count, dimension}; little-endian records */
+function loadSiftVectors(filePath, maxVectors) {
+  const max = maxVectors === undefined ? 10000 : maxVectors;
+  try {
+    const buffer = require('fs').readFileSync(filePath);
+    const dv = new DataView(buffer.buffer, buffer.byteOffset, buffer.byteLength);
+    const dimension = dv.getUint32(0, true);
+    const total = Math.floor(buffer.length / (dimension + 1) / 4), count = Math.min(max, total);
+    const vectors = [];
+    for (let i = 0; i < count; i++) {
+      const off = i * (dimension + 1) * 4, d = dv.getUint32(off, true);
+      if (d !== dimension) throw new Error('向量维度不一致: 期望' + dimension + ', 实际' + d);
+      const values = new Float32Array(dimension);
+      for (let j = 0; j < dimension; j++) values[j] = dv.getFloat32(off + 4 + j * 4, true);
+      vectors.push({ dimension: d, values: values });
+    }
+    return { vectors: vectors, count: vectors.length, dimension: dimension };
+  } catch (error) {
+    throw new Error('读取SIFT数据失败: ' + (error instanceof Error ? error.message : String(error)));
+  }
+}
+function loadSiftDataset(datasetDir, fileType, maxVectors) {
+  return loadSiftVectors(require('path').join(datasetDir, 'sift_' + (fileType === undefined ? 'base' : fileType) + '.fvecs'), maxVectors);
+}
+/** loadSiftQueries(datasetDir, maxQueries = 100) -> {queries, groundtruth: number[][]} from sift_query.fvecs + sift_groundtruth.ivecs */
+function loadSiftQueries(datasetDir, maxQueries) {
+  const max = maxQueries === undefined ? 100 : maxQueries;
+  const q = loadSiftDataset(datasetDir, 'query', max);
+  const buffer = require('fs').readFileSync(require('path').join(datasetDir, 'sift_groundtruth.ivecs'));
+  const dv = new DataView(buffer.buffer, buffer.byteOffset, buffer.byteLength);
+  const k = dv.getUint32(0, true), groundtruth = [];
+  for (let i = 0; i < Math.min(max, q.count); i++) {
+    const off = i * (k * 4 + 4), nb = [];
+    for (let j = 0; j < k; j++) nb.push(dv.getUint32(off + 4 + j * 4, true));
+    groundtruth.push(nb);
+  }
+  return { queries: q.vectors, groundtruth: groundtruth };
+}
+
 // ------------------------------------------------------------------ src/index.ts:62-111
 
 function createBinaryQuantizationFormat(config) {
@@ -420,7 +524,7 @@ module.exports = {
   BinaryQuantizationFormat, OptimizedScalarQuantizer, BinaryQuantizedScorer, MinHeap,
   createBinaryQuantizationFormat, quickQuantize, quickSearch,
   getOversampledTopKWithHeap, getOversampledTopKWithSort, getOversampledTopKBatch, computeCosineSimilarity,
-  DeviceVectors, createDeviceVectors,
+  DeviceVectors, createDeviceVectors, loadSiftVectors, loadSiftDataset, loadSiftQueries,
   deviceCount: native.deviceCount,
   _native: native,
 };

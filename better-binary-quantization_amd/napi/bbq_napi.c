@@ -415,6 +415,76 @@ static napi_value SearchRerankBatch(napi_env env, napi_callback_info info) {
   return o;
 }
 
+/* ---- on-disk format (bbq_index_save / bbq_index_load / bbq_index_export) */
+static int get_path(napi_env env, napi_value v, char *buf, size_t cap) {
+  size_t len = 0;
+  if (napi_get_value_string_utf8(env, v, buf, cap, &len) != napi_ok || len == 0 || len >= cap - 1) {
+    napi_throw_type_error(env, NULL, "bbq_napi: path string expected");
+    return 0;
+  }
+  return 1;
+}
+
+/* indexSave(handle, prefix, centroid Float32Array, sim) */
+static napi_value IndexSave(napi_env env, napi_callback_info info) {
+  napi_value a[4];
+  if (!get_args(env, info, 4, a)) return NULL;
+  bbq_index *ix = unbox(env, a[0]);
+  if (!ix) return NULL;
+  char path[4096]; void *cen; size_t cl; int64_t sim;
+  if (!get_path(env, a[1], path, sizeof path) || !get_typed(env, a[2], napi_float32_array, &cen, &cl) || !get_i64(env, a[3], &sim)) return NULL;
+  if (cl != (size_t)bbq_index_dimension(ix)) { napi_throw_error(env, "BBQ6", "向量和质心维度不匹配"); return NULL; }
+  int rc = bbq_index_save(ix, path, (const float *)cen, (int32_t)sim);
+  if (rc != BBQ_OK) return throw_bbq(env, rc);
+  napi_value u; napi_get_undefined(env, &u); return u;
+}
+
+/* indexLoad(prefix, device) -> {handle, centroid Float32Array, n, dim, sim, centroidDP, rowBase} */
+static napi_value IndexLoad(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  char path[4096]; int64_t dev;
+  if (!get_path(env, a[0], path, sizeof path) || !get_i64(env, a[1], &dev)) return NULL;
+  int64_t n = 0, rb = 0; int32_t dim = 0, sim = 0; double cdp = 0;
+  int rc = bbq_index_file_info(path, &n, &dim, &sim, &cdp, &rb);
+  if (rc != BBQ_OK) return throw_bbq(env, rc);
+  void *cen;
+  napi_value tcen = new_typed(env, napi_float32_array, (size_t)dim, 4, &cen);
+  if (!tcen) { napi_throw_error(env, NULL, "bbq_napi: allocation failed"); return NULL; }
+  bbq_index **box = (bbq_index **)calloc(1, sizeof *box);
+  rc = bbq_index_load(path, (int32_t)dev, box, (float *)cen);
+  if (rc != BBQ_OK) { free(box); return throw_bbq(env, rc); }
+  napi_value ext, o, v;
+  if (napi_create_external(env, box, finalize_index, NULL, &ext) != napi_ok) { bbq_index_destroy(*box); free(box); napi_throw_error(env, NULL, "bbq_napi: external"); return NULL; }
+  NAPI_CALL(env, napi_create_object(env, &o));
+  set_prop(env, o, "handle", ext); set_prop(env, o, "centroid", tcen);
+  napi_create_double(env, (double)n, &v); set_prop(env, o, "n", v);
+  napi_create_double(env, (double)dim, &v); set_prop(env, o, "dim", v);
+  napi_create_double(env, (double)sim, &v); set_prop(env, o, "sim", v);
+  napi_create_double(env, cdp, &v); set_prop(env, o, "centroidDP", v);
+  napi_create_double(env, (double)rb, &v); set_prop(env, o, "rowBase", v);
+  return o;
+}
+
+/* indexExport(handle) -> {codes Uint8Array[n*ceil(dim/8)], corr Float64Array[n*4]} */
+static napi_value IndexExport(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  bbq_index *ix = unbox(env, a[0]);
+  if (!ix) return NULL;
+  const size_t n = (size_t)bbq_index_size(ix), pb = (size_t)((bbq_index_dimension(ix) + 7) / 8);
+  void *codes, *corr;
+  napi_value tcodes = new_typed(env, napi_uint8_array, n * pb, 1, &codes);
+  napi_value tcorr = new_typed(env, napi_float64_array, n * 4, 8, &corr);
+  if (!tcodes || !tcorr) { napi_throw_error(env, NULL, "bbq_napi: allocation failed"); return NULL; }
+  int rc = bbq_index_export(ix, (uint8_t *)codes, (double *)corr);
+  if (rc != BBQ_OK) return throw_bbq(env, rc);
+  napi_value o;
+  NAPI_CALL(env, napi_create_object(env, &o));
+  set_prop(env, o, "codes", tcodes); set_prop(env, o, "corr", tcorr);
+  return o;
+}
+
 static napi_value Init(napi_env env, napi_value exports) {
   napi_property_descriptor d[] = {
       {"deviceCount", NULL, DeviceCount, NULL, NULL, NULL, napi_default, NULL},
@@ -432,6 +502,9 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"vectorsDestroy", NULL, VectorsDestroy, NULL, NULL, NULL, napi_default, NULL},
       {"rerankScores", NULL, RerankScores, NULL, NULL, NULL, napi_default, NULL},
       {"searchRerankBatch", NULL, SearchRerankBatch, NULL, NULL, NULL, napi_default, NULL},
+      {"indexSave", NULL, IndexSave, NULL, NULL, NULL, napi_default, NULL},
+      {"indexLoad", NULL, IndexLoad, NULL, NULL, NULL, napi_default, NULL},
+      {"indexExport", NULL, IndexExport, NULL, NULL, NULL, napi_default, NULL},
   };
   if (napi_define_properties(env, exports, sizeof d / sizeof d[0], d) != napi_ok) return NULL;
   return exports;

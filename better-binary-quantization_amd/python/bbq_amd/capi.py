@@ -21,7 +21,8 @@ SYMBOLS = [
     "bbq_search_batch", "bbq_score_rows", "bbq_shard_scan", "bbq_shard_list_cap", "bbq_replay", "bbq_replay_batch",
     "bbq_quantize_vectors", "bbq_quantize_query", "bbq_quantize_query_vector", "bbq_centroid_dp", "bbq_get_stats",
     "bbq_reset_stats", "bbq_set_option", "bbq_vectors_create", "bbq_vectors_destroy", "bbq_vectors_size",
-    "bbq_vectors_dimension", "bbq_rerank_scores", "bbq_search_rerank_batch",
+    "bbq_vectors_dimension", "bbq_rerank_scores", "bbq_search_rerank_batch", "bbq_index_save", "bbq_index_file_info",
+    "bbq_index_load", "bbq_index_export",
 ]
 
 
@@ -90,6 +91,10 @@ def lib():
     L.bbq_vectors_dimension.restype = i32
     L.bbq_rerank_scores.argtypes = [vp, i32, vp, vp, vp, i32, vp]
     L.bbq_search_rerank_batch.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, i64, i32, i32, i32, vp, vp, vp, vp]
+    L.bbq_index_save.argtypes = [vp, C.c_char_p, vp, i32]
+    L.bbq_index_file_info.argtypes = [C.c_char_p, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32), C.POINTER(dbl), C.POINTER(i64)]
+    L.bbq_index_load.argtypes = [C.c_char_p, i32, C.POINTER(vp), vp]
+    L.bbq_index_export.argtypes = [vp, vp, vp]
     _lib = L
     return L
 
@@ -180,6 +185,31 @@ class Index:
         self._h, self.dim, self.n = h, dim, n
         return self, codes, corr, cen
 
+    def save(self, path_prefix, centroid, sim):
+        """<prefix>.veb (the device tiles, byte for byte) + <prefix>.vemb (MetadataFormat + geometry + centroid)"""
+        cen = np.ascontiguousarray(centroid, np.float32)
+        if cen.shape != (self.dim,):
+            raise BBQError(ERR_DIM_MISMATCH, "centroid must be [dim]")
+        _chk(lib().bbq_index_save(self._h, os.fsencode(path_prefix), _ptr(cen), sim))
+
+    @classmethod
+    def load(cls, path_prefix, device=0):
+        """returns (index, centroid, info): a straight file -> HBM copy, no re-tiling"""
+        info = file_info(path_prefix)
+        cen = np.zeros(info["dim"], np.float32)
+        h = C.c_void_p()
+        _chk(lib().bbq_index_load(os.fsencode(path_prefix), device, C.byref(h), _ptr(cen)))
+        self = cls.__new__(cls)
+        self._h, self.dim, self.n = h, info["dim"], info["n_rows"]
+        return self, cen, info
+
+    def export(self):
+        """(codes [n, ceil(dim/8)], corr [n, 4]) as vectorValue / getCorrectiveTerms would return them"""
+        codes = np.zeros((self.n, (self.dim + 7) // 8), np.uint8)
+        corr = np.zeros((self.n, 4), np.float64)
+        _chk(lib().bbq_index_export(self._h, _ptr(codes), _ptr(corr)))
+        return codes, corr
+
     def close(self):
         if self._h:
             lib().bbq_index_destroy(self._h)
@@ -245,6 +275,12 @@ class Index:
         _chk(lib().bbq_shard_scan(self._h, qq.shape[0], _ptr(qq), _ptr(qc), query_bits, sim, k, dev_packed_ptr, packed_cap,
                                  dev_offsets_ptr, dev_flags_ptr, C.byref(total)))
         return total.value
+
+
+def file_info(path_prefix):
+    n, dim, sim, cdp, rb = C.c_int64(0), C.c_int32(0), C.c_int32(0), C.c_double(0), C.c_int64(0)
+    _chk(lib().bbq_index_file_info(os.fsencode(path_prefix), C.byref(n), C.byref(dim), C.byref(sim), C.byref(cdp), C.byref(rb)))
+    return {"n_rows": n.value, "dim": dim.value, "sim": sim.value, "centroid_dp": cdp.value, "row_base": rb.value}
 
 
 class Vectors:

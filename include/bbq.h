@@ -168,6 +168,29 @@ int bbq_replay_batch(int32_t n_sources, const bbq_cand *const *packed, const int
                      float *out_score, int64_t *out_n);
 
 /* ------------------------------------------------------------------------------------------
+ * On-disk format.  The reference declares a vector-data file ("veb") and a metadata file ("vemb",
+ * src/constants.ts:52-57) with the fields of VectorDataFormat / MetadataFormat (src/types.ts:78-113) but only ever
+ * builds them in memory (serializeVectorData, src/binaryQuantizationFormat.ts:483-530).  Here they are real files whose
+ * payload IS the device layout, so loading is a straight file -> HBM copy with no re-tiling:
+ *   <prefix>.vemb  "BVEC", version, MetadataFormat {fieldNumber, vectorEncodingOrdinal, vectorSimilarityOrdinal,
+ *                  dimensions, vectorDataOffset, vectorDataLength, vectorCount, centroidSquareMagnitude}, the tile
+ *                  geometry, centroid f32[dimensions], checksums            (DESIGN.md "On-disk format")
+ *   <prefix>.veb   the 64-row tile records (packed 1-bit codes + corrections per row = VectorDataFormat's
+ *                  binaryValues, lowerInterval, upperInterval, additionalCorrection, quantizedComponentSum),
+ *                  then the exact-corrections side array of the compact layout
+ * Little-endian.  A shard with a pilot replica cannot be saved (save the whole index, or the shard's own rows).
+ */
+int bbq_index_save(bbq_index *idx, const char *path_prefix, const float *centroid, int32_t similarity_ordinal);
+/* header of <prefix>.vemb; any output pointer may be NULL */
+int bbq_index_file_info(const char *path_prefix, int64_t *n_rows, int32_t *dim, int32_t *similarity_ordinal,
+                        double *centroid_dp, int64_t *row_base);
+/* centroid_out [dim] (may be NULL).  Fails with BBQ_ERR_INVALID_ARG on a malformed, truncated or corrupted file. */
+int bbq_index_load(const char *path_prefix, int32_t device, bbq_index **out, float *centroid_out);
+/* the rows back in the reference's shape: codes [n*ceil(dim/8)], corr [n*4] (either may be NULL) - what
+ * vectorValue(ord) / getCorrectiveTerms(ord) return (src/binaryQuantizationFormat.ts:52-76) */
+int bbq_index_export(bbq_index *idx, uint8_t *codes, double *corr);
+
+/* ------------------------------------------------------------------------------------------
  * Oversample + exact rerank (the reference's recall recipe: src/topKSelector.ts:29-115,
  * tests/recall-common.ts:188-213).  The ORIGINAL fp32 vectors stay resident in HBM next to the 1-bit
  * index; true scores are computeSimilarity (src/vectorSimilarity.ts:14-126): f64, accumulated in index

@@ -73,4 +73,54 @@ T.goldenNames().filter(function (n) { return !/^(intdot_|api_|rerank_|big_)/.tes
 const packed = new Uint8Array(1);
 bbq.OptimizedScalarQuantizer.packAsBinary(new Uint8Array([1, 0, 1, 0, 1, 0, 1, 0]), packed);
 T.check(packed[0] === 0xAA, 'packAsBinary');
+// serializeVectorData / deserializeVectorData (src/binaryQuantizationFormat.ts:483-566) with the double-pack bug fixed:
+// records carry the packed row + four corrections, the metadata the MetadataFormat fields; the round trip keeps every byte
+(function () {
+  const g = T.loadGolden('m_100d_cos_qb4'), io = T.inputs(g);
+  const fmt = new bbq.BinaryQuantizationFormat({ queryBits: 4, indexBits: 1, quantizer: { similarityFunction: 'COSINE', lambda: g.lambda, iters: g.iters } });
+  const ser = fmt.serializeVectorData(io.base);
+  T.check(ser.vectorData.length === g.n && ser.metadata.vectorCount === g.n && ser.metadata.dimensions === g.dim, 'serialize: counts');
+  T.check(ser.vectorData[0].binaryValues.length === g.row_bytes, 'serialize: binaryValues is the packed row');
+  T.check(T.sameBits(ser.metadata.centroid, T.dec(g.centroid_f32, Float32Array)), 'serialize: centroid');
+  T.check(T.sameBits(new Float64Array([ser.metadata.centroidSquareMagnitude]), T.dec(g.centroid_dp_f64, Float64Array)), 'serialize: centroidSquareMagnitude');
+  const flat = new Uint8Array(g.n * g.row_bytes);
+  ser.vectorData.forEach(function (d, i) { flat.set(d.binaryValues, i * g.row_bytes); });
+  T.check(T.sha(flat) === g.codes_sha256, 'serialize: rows equal the reference codes');
+  const back = fmt.deserializeVectorData(ser.vectorData, ser.metadata);
+  T.check(back.size() === g.n && back.dimension() === g.dim && T.sha(back._codes) === g.codes_sha256, 'deserialize: rows');
+  const hc = T.dec(g.head_corr_f64, Float64Array), t = back.getCorrectiveTerms(1);
+  T.check(T.sameBits(new Float64Array([t.lowerInterval, t.upperInterval, t.additionalCorrection, t.quantizedComponentSum]), hc.subarray(4, 8)), 'deserialize: corrections');
+  let threw = false;
+  try { fmt.deserializeVectorData(ser.vectorData, Object.assign({}, ser.metadata, { dimensions: g.dim + 8 })); } catch (e) { threw = true; }
+  T.check(threw, 'deserialize: dimension mismatch throws');
+})();
+// .fvecs / .ivecs loaders (tests/benchmarks/siftDataLoader.ts:27-127)
+(function () {
+  const fs = require('fs'), os = require('os'), path = require('path');
+  const dir = fs.mkdtempSync(path.join(os.tmpdir(), 'bbq_sift_'));
+  const dim = 7, n = 5, k = 3;
+  const wf = function (name, rows) {
+    const buf = Buffer.alloc(rows.length * (dim + 1) * 4);
+    rows.forEach(function (r, i) { buf.writeUInt32LE(dim, i * (dim + 1) * 4); r.forEach(function (v, j) { buf.writeFloatLE(v, i * (dim + 1) * 4 + 4 + j * 4); }); });
+    fs.writeFileSync(path.join(dir, name), buf);
+  };
+  const rows = []; for (let i = 0; i < n; i++) { const r = []; for (let j = 0; j < dim; j++) r.push(i * 10 + j / 4); rows.push(r); }
+  wf('sift_base.fvecs', rows); wf('sift_query.fvecs', rows.slice(0, 2));
+  const gt = Buffer.alloc(2 * (k + 1) * 4);
+  [[4, 2, 0], [1, 3, 2]].forEach(function (r, i) { gt.writeUInt32LE(k, i * (k + 1) * 4); r.forEach(function (v, j) { gt.writeUInt32LE(v, i * (k + 1) * 4 + 4 + j * 4); }); });
+  fs.writeFileSync(path.join(dir, 'sift_groundtruth.ivecs'), gt);
+  const d = bbq.loadSiftDataset(dir, 'base', 4);
+  T.check(d.count === 4 && d.dimension === dim && d.vectors[3].values[2] === 30.5 && d.vectors[3].dimension === dim, 'loadSiftDataset');
+  T.check(bbq.loadSiftVectors(path.join(dir, 'sift_base.fvecs')).count === n, 'loadSiftVectors default cap');
+  const q = bbq.loadSiftQueries(dir, 10);
+  T.check(q.queries.length === 2 && JSON.stringify(q.groundtruth) === '[[4,2,0],[1,3,2]]', 'loadSiftQueries');
+  let msg = '';
+  try { bbq.loadSiftVectors(path.join(dir, 'nope.fvecs')); } catch (e) { msg = e.message; }
+  T.check(/^读取SIFT数据失败: /.test(msg), 'loadSiftVectors error prefix');
+  const bad = Buffer.from(fs.readFileSync(path.join(dir, 'sift_base.fvecs'))); bad.writeUInt32LE(dim + 1, (dim + 1) * 4);
+  fs.writeFileSync(path.join(dir, 'bad.fvecs'), bad);
+  msg = '';
+  try { bbq.loadSiftVectors(path.join(dir, 'bad.fvecs')); } catch (e) { msg = e.message; }
+  T.check(msg.indexOf('向量维度不一致') >= 0, 'inconsistent record dimension');
+})();
 T.finish('js cpu_checks');

@@ -107,4 +107,36 @@ T.goldenNames().filter(function (n) { return /^rerank_/.test(n); }).forEach(func
   index.dispose();
 });
 
+// on-disk format: saveIndex -> loadIndex keeps every answer and every row; deserialized indexes are searchable
+(function () {
+  const fs = require('fs'), os = require('os'), path = require('path');
+  const dir = fs.mkdtempSync(path.join(os.tmpdir(), 'bbq_idx_'));
+  const g = T.loadGolden('m_768d_cos_qb4'), io = T.inputs(g);
+  const fmt = new bbq.BinaryQuantizationFormat({ queryBits: 4, indexBits: 1, quantizer: { similarityFunction: 'COSINE', lambda: g.lambda, iters: g.iters } });
+  const index = fmt.quantizeVectors(io.base).quantizedVectors;
+  const prefix = path.join(dir, 'm768');
+  fmt.saveIndex(index, prefix);
+  T.check(fs.existsSync(prefix + '.veb') && fs.existsSync(prefix + '.vemb'), 'saveIndex writes .veb + .vemb');
+  const loaded = fmt.loadIndex(prefix);
+  T.check(loaded.size() === g.n && loaded.dimension() === g.dim, 'loadIndex: size/dimension');
+  let ok = true;
+  for (let qi = 0; qi < g.nq; qi++) {
+    const a = fmt.searchNearestNeighbors(io.queries[qi], index, g.k), b = fmt.searchNearestNeighbors(io.queries[qi], loaded, g.k);
+    ok = ok && JSON.stringify(a) === JSON.stringify(b) && T.sameBits(Int32Array.from(b.map(function (r) { return r.index; })), T.dec(g.queries[qi].topk[0].idx_i32, Int32Array));
+  }
+  T.check(ok, 'loadIndex: same top-k as the index that was saved and as the reference');
+  T.check(T.sha(loaded.vectorValue(0)) === T.sha(index.vectorValue(0)) && loaded._codes && T.sha(loaded._codes) === g.codes_sha256, 'loadIndex: rows come back from the device');
+  T.check(JSON.stringify(loaded.getCorrectiveTerms(5)) === JSON.stringify(index.getCorrectiveTerms(5)), 'loadIndex: corrections');
+  const euc = new bbq.BinaryQuantizationFormat({ quantizer: { similarityFunction: 'EUCLIDEAN' } });
+  let threw = false;
+  try { euc.loadIndex(prefix); } catch (e) { threw = true; }
+  T.check(threw, 'loadIndex refuses a file written for another similarity');
+  threw = false;
+  try { fmt.loadIndex(path.join(dir, 'absent')); } catch (e) { threw = /cannot open/.test(e.message); }
+  T.check(threw, 'loadIndex: missing file');
+  const ser = fmt.serializeVectorData(io.base), back = fmt.deserializeVectorData(ser.vectorData, ser.metadata);
+  T.check(JSON.stringify(fmt.searchNearestNeighbors(io.queries[0], back, g.k)) === JSON.stringify(fmt.searchNearestNeighbors(io.queries[0], index, g.k)), 'deserialized index searches like the original');
+  loaded.dispose(); back.dispose(); index.dispose();
+})();
+
 T.finish('js gpu_parity');

@@ -721,3 +721,120 @@ def test_rerank_errors():
     short.close()
     dv.close()
     ix.close()
+
+
+# ---------------------------------------------------------------- on-disk format
+
+def _search_all(ix, g, cen, sim, qb, k):
+    _, queries = O.golden_inputs(g)
+    qs = [B.quantize_query(q, cen, sim, qb, g["lambda"], g["iters"]) for q in queries]
+    return ix.search_batch(np.stack([a for a, _ in qs]), np.stack([b for _, b in qs]), qb, sim, k)
+
+
+@pytest.mark.parametrize("compact", [True, False])
+@pytest.mark.parametrize("name", ["m_768d_cos_qb4", "m_100d_euc_qb4", "big_20000x128_cos", "edge_zero_const"])
+def test_save_load_roundtrip(tmp_path, name, compact):
+    """save -> load is a byte-for-byte copy of the device buffers: same geometry, same answers, same exported rows"""
+    import os
+    g = O.load_golden(name)
+    sim, base, queries, codes, corr, cen, cdp = _index_from_case(g)
+    ix = _make_index(codes, corr, g["dim"], cdp, compact)
+    k = min(100, g["n"])
+    want = _search_all(ix, g, cen, sim, g["qb"], k)
+    prefix = str(tmp_path / "idx")
+    ix.save(prefix, cen, sim)
+    n_tiles = (g["n"] + 63) // 64
+    stride = ix.bytes_per_row * 64
+    assert os.path.getsize(prefix + ".veb") == n_tiles * stride + (n_tiles * 64 * 32 if compact else 0)
+    assert os.path.getsize(prefix + ".vemb") == 104 + 4 * g["dim"] + 16
+    info = B.file_info(prefix)
+    assert info == {"n_rows": g["n"], "dim": g["dim"], "sim": sim, "centroid_dp": cdp, "row_base": 0}
+    ix2, cen2, _ = B.Index.load(prefix)
+    assert ix2.bytes_per_row == ix.bytes_per_row
+    np.testing.assert_array_equal(cen2.view(np.uint32), cen.view(np.uint32))
+    got = _search_all(ix2, g, cen2, sim, g["qb"], k)
+    for a, b in zip(want, got):
+        np.testing.assert_array_equal(np.asarray(a).view(np.uint32) if a.dtype == np.float32 else a,
+                                      np.asarray(b).view(np.uint32) if b.dtype == np.float32 else b)
+    for src in (ix, ix2):
+        c2, r2 = src.export()
+        np.testing.assert_array_equal(c2, codes)
+        np.testing.assert_array_equal(canon64(r2), canon64(corr))
+    # per-row scores through the loaded copy too
+    qq, qc = B.quantize_query(queries[0], cen, sim, g["qb"], g["lambda"], g["iters"])
+    d1, s1, _ = ix.score_rows(qq, qc, g["qb"], sim)
+    d2, s2, _ = ix2.score_rows(qq, qc, g["qb"], sim)
+    np.testing.assert_array_equal(d1, d2)
+    np.testing.assert_array_equal(canon64(s1), canon64(s2))
+    ix.close()
+    ix2.close()
+
+
+def test_save_load_device_built_and_explicit_sums(tmp_path):
+    rng = np.random.default_rng(8)
+    base = rng.standard_normal((5000, 96)).astype(np.float32)
+    ix, codes, corr, cen = B.Index.build(base, 1)
+    ix.save(str(tmp_path / "built"), cen, 1)
+    ix2, cen2, info = B.Index.load(str(tmp_path / "built"))
+    assert info["n_rows"] == 5000 and info["dim"] == 96
+    c2, r2 = ix2.export()
+    np.testing.assert_array_equal(c2, codes)
+    np.testing.assert_array_equal(canon64(r2), canon64(corr))
+    q = rng.standard_normal(96).astype(np.float32)
+    qq, qc = B.quantize_query(q, cen, 1, 4)
+    a, b = ix.search(qq, qc, 4, 1, 50), ix2.search(qq, qc, 4, 1, 50)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(canon32(a[1]), canon32(b[1]))
+    ix.close()
+    ix2.close()
+    # quantizedComponentSum that is NOT the popcount: explicit sums travel in the tile records (inline layout + x1)
+    corr3 = corr.copy()
+    corr3[::7, 3] += 2.0
+    ix3 = B.Index(codes, corr3, 96, B.centroid_dp(cen))
+    ix3.save(str(tmp_path / "x1"), cen, 1)
+    ix4, _, _ = B.Index.load(str(tmp_path / "x1"))
+    assert ix4.bytes_per_row == ix3.bytes_per_row
+    _, r4 = ix4.export()
+    np.testing.assert_array_equal(canon64(r4), canon64(corr3))
+    a, b = ix3.search(qq, qc, 4, 1, 50), ix4.search(qq, qc, 4, 1, 50)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(canon32(a[1]), canon32(b[1]))
+    ix3.close()
+    ix4.close()
+
+
+def test_load_rejects_damaged_files(tmp_path):
+    rng = np.random.default_rng(9)
+    base = rng.standard_normal((700, 64)).astype(np.float32)
+    codes, corr, cen = B.quantize_vectors(base, 1, 1)
+    ix = B.Index(codes, corr, 64, B.centroid_dp(cen))
+    prefix = str(tmp_path / "d")
+    ix.save(prefix, cen, 1)
+    veb, vemb = open(prefix + ".veb", "rb").read(), open(prefix + ".vemb", "rb").read()
+
+    def variant(name, veb_bytes, vemb_bytes):
+        p = str(tmp_path / name)
+        open(p + ".veb", "wb").write(veb_bytes)
+        open(p + ".vemb", "wb").write(vemb_bytes)
+        return p
+
+    flipped = bytearray(veb)
+    flipped[len(veb) // 2] ^= 0x10
+    bad_meta = bytearray(vemb)
+    bad_meta[110] ^= 1   # a centroid byte
+    for p in (variant("flip", bytes(flipped), vemb), variant("short", veb[:-8], vemb), variant("meta", veb, bytes(bad_meta)),
+              variant("magic", veb, b"XVEC" + vemb[4:]), variant("trunc", veb, vemb[:50]), str(tmp_path / "missing")):
+        with pytest.raises(B.BBQError):
+            B.Index.load(p)
+    ok, _, _ = B.Index.load(variant("good", veb, vemb))
+    ok.close()
+    with pytest.raises(B.BBQError):
+        ix.save(str(tmp_path / "nodir" / "x"), cen, 1)
+    with pytest.raises(B.BBQError):
+        ix.save(prefix, cen[:10], 1)
+    # a shard with a pilot replica is refused
+    sh = B.Index(codes[512:], corr[512:], 64, B.centroid_dp(cen), row_base=512, pilot_codes=codes[:512], pilot_corr=corr[:512])
+    with pytest.raises(B.BBQError):
+        sh.save(prefix + "_shard", cen, 1)
+    sh.close()
+    ix.close()

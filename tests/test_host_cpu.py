@@ -123,3 +123,39 @@ def test_replay_edge_cases():
     idx, sc = B.replay([_entries(np.arange(6), s)], 6, 3)
     oi, osc = O.heap_topk(s, 3)
     np.testing.assert_array_equal(idx, oi)
+
+
+def test_vemb_header_spec(tmp_path):
+    """the metadata file layout as DESIGN.md documents it, parsed by bbq_index_file_info (no device needed):
+    104-byte little-endian header, centroid f32[dim], data checksum, metadata checksum (FNV-1a over 64-bit words)"""
+    import struct
+    from bbqlib import bbq_amd as B
+
+    def fnv(data, h):
+        data = data + b"\0" * (-len(data) % 8)
+        for (w,) in struct.iter_unpack("<Q", data):
+            h = ((h ^ w) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+        return h
+
+    dim, n = 100, 1000
+    pb, w16 = (dim + 7) // 8, ((dim + 7) // 8 + 15) // 16
+    n_tiles = (n + 63) // 64
+    stride = w16 * 1024 + 512                                        # compact layout
+    tiles, exact = n_tiles * stride, n_tiles * 64 * 32
+    hdr = struct.pack("<4sI4i3qd6i3q", b"BVEC", 1, 0, 0, 1, dim, 0, tiles + exact, n, 0.125, 1, 1, w16, stride, 0, 64, tiles, exact, 0)
+    assert len(hdr) == 104
+    cen = np.arange(dim, dtype=np.float32).tobytes()
+    dsum = struct.pack("<Q", 0x1234)
+    msum = fnv(dsum, fnv(cen, fnv(hdr, 0xcbf29ce484222325)))
+    p = str(tmp_path / "h")
+    open(p + ".vemb", "wb").write(hdr + cen + dsum + struct.pack("<Q", msum))
+    assert B.file_info(p) == {"n_rows": n, "dim": dim, "sim": 1, "centroid_dp": 0.125, "row_base": 0}
+    open(p + ".vemb", "wb").write(hdr + cen + dsum + struct.pack("<Q", msum ^ 1))
+    with pytest.raises(B.BBQError):
+        B.file_info(p)
+    bad = struct.pack("<4sI4i3qd6i3q", b"BVEC", 1, 0, 0, 1, dim, 0, tiles + exact, n, 0.125, 1, 1, w16, stride + 16, 0, 64, tiles, exact, 0)
+    open(p + ".vemb", "wb").write(bad + cen + dsum + struct.pack("<Q", fnv(dsum, fnv(cen, fnv(bad, 0xcbf29ce484222325)))))
+    with pytest.raises(B.BBQError):
+        B.file_info(p)
+    with pytest.raises(B.BBQError):
+        B.file_info(str(tmp_path / "absent"))
