@@ -122,7 +122,7 @@ T.goldenNames().filter(function (n) { return /^rerank_/.test(n); }).forEach(func
   let ok = true;
   for (let qi = 0; qi < g.nq; qi++) {
     const a = fmt.searchNearestNeighbors(io.queries[qi], index, g.k), b = fmt.searchNearestNeighbors(io.queries[qi], loaded, g.k);
-    ok = ok && JSON.stringify(a) === JSON.stringify(b) && T.sameBits(Int32Array.from(b.map(function (r) { return r.index; })), T.dec(g.queries[qi].topk[0].idx_i32, Int32Array));
+    ok = ok && JSON.stringify(a) === JSON.stringify(b) && T.sameBits(Int32Array.from(b.map(function (r) { return r.index; })), T.dec(g.queries[qi].topk.filter(function (t) { return t.k === g.k; })[0].idx_i32, Int32Array));
   }
   T.check(ok, 'loadIndex: same top-k as the index that was saved and as the reference');
   T.check(T.sha(loaded.vectorValue(0)) === T.sha(index.vectorValue(0)) && loaded._codes && T.sha(loaded._codes) === g.codes_sha256, 'loadIndex: rows come back from the device');
