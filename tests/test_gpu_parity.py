@@ -838,3 +838,68 @@ def test_load_rejects_damaged_files(tmp_path):
         sh.save(prefix + "_shard", cen, 1)
     sh.close()
     ix.close()
+
+
+# ---------------------------------------------------------------- randomized sweep of shapes and options
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_shapes_options_vs_oracle(seed):
+    """random (n, dim, k, queryBits, similarity, layout, segment plan, sweep sharing, data flavour) against the oracle:
+    index bytes, per-row integers and f64 scores, and the replayed top-k incl. order"""
+    rng = np.random.default_rng(1000 + seed)
+    dim = int(rng.choice([1, 2, 7, 8, 9, 63, 64, 65, 96, 127, 128, 129, 200, 256, 384, 500, 768, 1000]))
+    n = int(rng.choice([1, 2, 63, 64, 65, 511, 512, 513, 1500, 4097, 9000]))
+    sim = int(rng.integers(0, 3))
+    qb = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 7, 8]))
+    k = int(rng.choice([1, 2, 10, 100, n, n + 3, max(1, n // 2)]))
+    flavour = int(rng.integers(0, 4))
+    if flavour == 0:
+        base = rng.standard_normal((n, dim)).astype(np.float32)
+    elif flavour == 1:   # few distinct rows: masses of exactly equal scores
+        pool = rng.standard_normal((max(2, min(12, n)), dim)).astype(np.float32)
+        base = pool[rng.integers(0, pool.shape[0], n)]
+    elif flavour == 2:   # wildly different magnitudes per row, some zero / constant rows
+        base = (rng.standard_normal((n, dim)) * 10.0 ** rng.integers(-6, 7, (n, 1))).astype(np.float32)
+        base[rng.integers(0, n, max(1, n // 50))] = 0
+        base[rng.integers(0, n, max(1, n // 50))] = 3.5
+    else:                # scores rising with the row number: the worst case for the thresholds
+        base = rng.standard_normal((n, dim)).astype(np.float32) * 0.05 + np.linspace(-1, 1, n, dtype=np.float32)[:, None] * rng.standard_normal(dim).astype(np.float32)
+    nq = int(rng.integers(1, 40))
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    if flavour == 3:
+        queries[0] = base[-1]
+    codes, corr, cen = O.build_index(base, sim)
+    pcodes, pcorr, pcen = B.quantize_vectors(base, sim)
+    np.testing.assert_array_equal(pcodes, codes)
+    np.testing.assert_array_equal(canon64(pcorr), canon64(corr))
+    np.testing.assert_array_equal(pcen.view(np.uint32), cen.view(np.uint32))
+    cdp = B.centroid_dp(cen)
+    compact = bool(rng.integers(0, 2))
+    ix = _make_index(codes, corr, dim, cdp, compact)
+    try:
+        ix.set_option("first_segment_rows", int(rng.choice([1024, 2048, 4096])))
+        ix.set_option("segment_growth", int(rng.choice([2, 3, 8, 64])))
+        ix.set_option("batch_queries", int(rng.choice([1, 5, 32])))
+        ix.set_option("pipeline_slots", int(rng.choice([1, 2, 3])))
+        ix.set_option("replay_threads", int(rng.choice([1, 4])))
+        ix.set_option("sweep_share", int(rng.choice([1, 1, 4, 8, 32])))
+        qs = [B.quantize_query(q, cen, sim, qb) for q in queries]
+        qq, qc = np.stack([a for a, _ in qs]), np.stack([b for _, b in qs])
+        for i in range(nq):
+            oq, oc = O.quantize_query(queries[i], cen, sim, qb)
+            np.testing.assert_array_equal(qq[i], oq)
+            np.testing.assert_array_equal(canon64(qc[i]), canon64(oc))
+        idx, sc, cnt = ix.search_batch(qq, qc, qb, sim, k)
+        for i in range(nq):
+            d, s64, s32 = O.score_all(codes, corr, dim, qq[i], qc[i], qb, sim, cdp)
+            oi, osc = O.heap_topk(s32, k)
+            assert cnt[i] == len(oi) == min(k, n)
+            np.testing.assert_array_equal(idx[i, :cnt[i]], oi)
+            np.testing.assert_array_equal(canon32(sc[i, :cnt[i]]), canon32(osc))
+        gd, g64, g32 = ix.score_rows(qq[0], qc[0], qb, sim)
+        d, s64, s32 = O.score_all(codes, corr, dim, qq[0], qc[0], qb, sim, cdp)
+        np.testing.assert_array_equal(gd, d)
+        np.testing.assert_array_equal(canon64(g64), canon64(s64))
+        np.testing.assert_array_equal(canon32(g32), canon32(s32))
+    finally:
+        ix.close()
