@@ -15,12 +15,16 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 dim, k = 768, 100
 codes, corr = bench.synth_rows(1, 0, n, dim // 8)
 ix = B.Index(codes, corr, dim, 0.01)
+sizes = (1, 2, 4, 8, 32)
 for o in sys.argv[2:]:
     a, b = o.split("=")
-    ix.set_option(a, int(b))
+    if a == "only":
+        sizes = (int(b),)
+    else:
+        ix.set_option(a, int(b))
 qq, qc = bench.synth_queries(2, 64, dim, 4)
 out = {}
-for nb in (1, 2, 4, 8, 32):
+for nb in sizes:
     ix.search_batch(qq[:nb], qc[:nb], 4, 1, k)
     ts = []
     for r in range(30):
