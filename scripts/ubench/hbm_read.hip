@@ -1,0 +1,106 @@
+// hbm_read.hip - what a pure streaming read reaches on this MI355X: the practical ceiling the scan kernel is held
+// against ("confirm with a hipMemcpy / stream probe on the box").  Reads `bytes` once with 16-byte
+// non-temporal (or plain) loads per lane, XOR-reduces so the loads cannot be dropped, several block sizes / unrolls.
+//   hipcc --offload-arch=gfx950 -O3 -o hbm_read hbm_read.hip && ./hbm_read
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <vector>
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int UNROLL, bool NT>
+__global__ void read_kernel(const u32x4 *__restrict__ p, size_t n_vec, uint32_t *out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  u32x4 acc = {0, 0, 0, 0};
+  for (; i + (UNROLL - 1) * stride < n_vec; i += UNROLL * stride) {
+    u32x4 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) v[u] = NT ? __builtin_nontemporal_load(p + i + u * stride) : p[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc ^= v[u];
+  }
+  for (; i < n_vec; i += stride) acc ^= p[i];
+  const uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+  if (r == 0x12345678u) atomicAdd(out, 1u);  // practically never: keeps the loads alive
+}
+
+// the scan kernel's shape: one workgroup per contiguous 52 KB piece (512 rows x 104 B), each lane 6 loads 1 KB apart
+__global__ __launch_bounds__(512) void tile_kernel(const u32x4 *__restrict__ p, size_t n_chunks, uint32_t *out) {
+  const size_t c = blockIdx.x;
+  if (c >= n_chunks) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const u32x4 *tp = p + (c * 8 + wave) * (6656 / 16) + lane;
+  u32x4 v[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) v[j] = __builtin_nontemporal_load(tp + j * 64);
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 *cp = reinterpret_cast<const u32x2 *>(tp - lane + 6 * 64) + lane;
+  const u32x2 cc = __builtin_nontemporal_load(cp);
+  u32x4 acc = v[0] ^ v[1] ^ v[2] ^ v[3] ^ v[4] ^ v[5];
+  const uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w ^ cc.x ^ cc.y;
+  if (r == 0x12345678u) atomicAdd(out, 1u);
+}
+
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <int UNROLL, bool NT>
+static int run(const u32x4 *d, size_t bytes, uint32_t *d_out, int block, int blocks_per_cu) {
+  hipEvent_t e0, e1;
+  CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+  const int grid = 256 * blocks_per_cu;
+  float best = 1e9f, sum = 0;
+  for (int it = 0; it < 12; ++it) {
+    CHK(hipEventRecord(e0));
+    hipLaunchKernelGGL((read_kernel<UNROLL, NT>), dim3(grid), dim3(block), 0, 0, d, bytes / 16, d_out);
+    CHK(hipEventRecord(e1));
+    CHK(hipEventSynchronize(e1));
+    float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+    if (it >= 2) { sum += ms; if (ms < best) best = ms; }
+  }
+  printf("grid-stride  %s unroll %d block %4d x %2d/CU : avg %.1f GB/s  best %.1f GB/s\n", NT ? "nontemporal" : "plain      ", UNROLL, block, blocks_per_cu,
+         bytes / (sum / 10 * 1e-3) / 1e9, bytes / (best * 1e-3) / 1e9);
+  return 0;
+}
+
+int main() {
+  const size_t n_chunks = 15434;                  // the bench's dominant segment: 7.9 M rows
+  const size_t tile_bytes = n_chunks * 8 * 6656;  // 822 MB
+  const size_t bytes = (size_t)4 << 30;
+  u32x4 *d; uint32_t *d_out;
+  CHK(hipMalloc((void **)&d, bytes));
+  CHK(hipMalloc((void **)&d_out, 4));
+  CHK(hipMemset(d, 0x5a, bytes));
+  CHK(hipMemset(d_out, 0, 4));
+  if (run<4, true>(d, bytes, d_out, 256, 8)) return 1;
+  if (run<4, false>(d, bytes, d_out, 256, 8)) return 1;
+  if (run<8, true>(d, bytes, d_out, 256, 8)) return 1;
+  if (run<4, true>(d, bytes, d_out, 512, 4)) return 1;
+  if (run<4, true>(d, bytes, d_out, 1024, 2)) return 1;
+  if (run<2, true>(d, bytes, d_out, 256, 16)) return 1;
+  hipEvent_t e0, e1;
+  CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+  float best = 1e9f, sum = 0;
+  for (int it = 0; it < 12; ++it) {
+    CHK(hipEventRecord(e0));
+    hipLaunchKernelGGL(tile_kernel, dim3((unsigned)n_chunks), dim3(512), 0, 0, d, n_chunks, d_out);
+    CHK(hipEventRecord(e1));
+    CHK(hipEventSynchronize(e1));
+    float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+    if (it >= 2) { sum += ms; if (ms < best) best = ms; }
+  }
+  printf("scan-shaped read (512-row workgroups, 6 x 16 B + 8 B per lane, 822 MB): avg %.1f GB/s  best %.1f GB/s\n",
+         tile_bytes / (sum / 10 * 1e-3) / 1e9, tile_bytes / (best * 1e-3) / 1e9);
+  // hipMemcpy device-to-device for reference (reads + writes: bytes moved = 2 x size)
+  u32x4 *d2; CHK(hipMalloc((void **)&d2, bytes / 2));
+  for (int it = 0; it < 4; ++it) {
+    CHK(hipEventRecord(e0));
+    CHK(hipMemcpyAsync(d2, d, bytes / 2, hipMemcpyDeviceToDevice, 0));
+    CHK(hipEventRecord(e1));
+    CHK(hipEventSynchronize(e1));
+    float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+    if (it == 3) printf("hipMemcpy D2D 2 GiB: %.1f GB/s copied = %.1f GB/s read+write\n", bytes / 2 / (ms * 1e-3) / 1e9, bytes / (ms * 1e-3) / 1e9);
+  }
+  return 0;
+}
