@@ -38,6 +38,17 @@ using namespace bbq;
 
 namespace {
 
+// device scratch that is released on every exit path
+struct DevMem {
+  void *p = nullptr;
+  DevMem() = default;
+  DevMem(const DevMem &) = delete;
+  DevMem &operator=(const DevMem &) = delete;
+  ~DevMem() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
 constexpr int kMaxSlots = 4;
 constexpr int64_t kMaxFastK = 2048;  // beyond this the dense path is used (finalize LDS key buffer)
 
@@ -219,26 +230,26 @@ int make_storage(bbq_index *ix, Storage &st, const uint8_t *codes, const double 
                  bool check_x1) {
   const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
   const int64_t pb = ix->pb;
-  uint8_t *d_codes = nullptr;
-  double *d_corr = nullptr;
-  uint32_t *d_mis = nullptr;
+  DevMem m_codes, m_corr, m_mis;
   hipStream_t s = ix->aux_stream;
   if (n_rows > 0) {
-    HIPCHK(hipMalloc((void **)&d_codes, (size_t)(n_rows * pb)));
-    HIPCHK(hipMalloc((void **)&d_corr, (size_t)n_rows * 32));
-    HIPCHK(hipMemcpyAsync(d_codes, codes, (size_t)(n_rows * pb), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_corr, corr, (size_t)n_rows * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(m_codes.alloc((size_t)(n_rows * pb)));
+    HIPCHK(m_corr.alloc((size_t)n_rows * 32));
+    HIPCHK(hipMemcpyAsync(m_codes.p, codes, (size_t)(n_rows * pb), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m_corr.p, corr, (size_t)n_rows * 32, hipMemcpyHostToDevice, s));
   }
+  uint8_t *d_codes = m_codes.as<uint8_t>();
+  double *d_corr = m_corr.as<double>();
   if (check_x1) {
     // quantizedComponentSum of a 1-bit row is its popcount (src/optimizedScalarQuantizer.ts:204-209); if that
     // holds for every row the 8 bytes need not be stored or read.  Decided once per index, over all storages.
     uint32_t mis = 0;
-    HIPCHK(hipMalloc((void **)&d_mis, 4));
+    HIPCHK(m_mis.alloc(4));
+    uint32_t *d_mis = m_mis.as<uint32_t>();
     HIPCHK(hipMemsetAsync(d_mis, 0, 4, s));
     HIPCHK(launch_check_x1(d_codes, d_corr, n_rows, (int32_t)pb, d_mis, s));
     HIPCHK(hipMemcpyAsync(&mis, d_mis, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipFree(d_mis));
     if (mis) ix->has_x1 = 1;
   }
   // compact corrections (8 B/row streamed + exact side array) need the implicit component sum; otherwise inline
@@ -260,8 +271,7 @@ int make_storage(bbq_index *ix, Storage &st, const uint8_t *codes, const double 
   }
   st.view.exact = st.d_exact;
   st.view.tiles = st.d_tiles;
-  if (d_codes) HIPCHK(hipFree(d_codes));
-  if (d_corr) HIPCHK(hipFree(d_corr));
+  HIPCHK(hipStreamSynchronize(s));  // the scratch rows are released on return
   return BBQ_OK;
 }
 
@@ -1093,13 +1103,14 @@ int bbq_score_rows(bbq_index *ix, const uint8_t *qquant, const double *qcorr, in
   HIPCHK(hipStreamSynchronize(st));
   const int64_t piece_chunks = 1024;  // 1M rows per piece
   const int64_t c_first = row_begin / kChunkRows, c_last = (row_begin + row_count + kChunkRows - 1) / kChunkRows;
-  float *d32 = nullptr;
-  int32_t *dqc = nullptr;
-  double *d64 = nullptr;
-  const int64_t piece_rows = piece_chunks * kChunkRows;
-  HIPCHK(hipMalloc((void **)&d32, (size_t)piece_rows * 4));
-  HIPCHK(hipMalloc((void **)&dqc, (size_t)piece_rows * 4));
-  HIPCHK(hipMalloc((void **)&d64, (size_t)piece_rows * 8));
+  const int64_t piece_rows = std::min(piece_chunks, c_last - c_first) * kChunkRows;
+  DevMem m32, mqc, m64;
+  HIPCHK(m32.alloc((size_t)piece_rows * 4));
+  HIPCHK(mqc.alloc((size_t)piece_rows * 4));
+  HIPCHK(m64.alloc((size_t)piece_rows * 8));
+  float *d32 = m32.as<float>();
+  int32_t *dqc = mqc.as<int32_t>();
+  double *d64 = m64.as<double>();
   std::vector<float> h32((size_t)piece_rows);
   std::vector<int32_t> hqc((size_t)piece_rows);
   std::vector<double> h64((size_t)piece_rows);
@@ -1131,9 +1142,6 @@ int bbq_score_rows(bbq_index *ix, const uint8_t *qquant, const double *qcorr, in
       if (out_score64) out_score64[r - row_begin] = h64[(size_t)(r - r0)];
     }
   }
-  (void)hipFree(d32);
-  (void)hipFree(dqc);
-  (void)hipFree(d64);
   return rc;
 }
 
