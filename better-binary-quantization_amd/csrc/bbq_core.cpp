@@ -73,6 +73,7 @@ struct Plan {
   std::vector<Segment> segs;
   int64_t s0 = 0;
   int64_t list_cap = 0;
+  int64_t flood_cap = 0;  // per-query entries of the flood tier (overflow area + list headroom); 0: none
   int64_t max_slots = 0;  // max over sparse segments of n_chunks*cap
   int64_t max_chunks = 0;
 };
@@ -82,11 +83,12 @@ struct Slot {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr, ev_big = nullptr;
   // capacities the buffers below were allocated for
   int q_cap = 0;
-  int64_t qbuf_bytes = 0, chunks_cap = 0, slots_cap = 0, dense_cap = 0, list_cap = 0, k_cap = 0, hprefix = 0;
+  int64_t qbuf_bytes = 0, chunks_cap = 0, slots_cap = 0, dense_cap = 0, list_cap = 0, k_cap = 0, hprefix = 0, flood_cap = 0;
   uint8_t *d_qbuf = nullptr, *h_qbuf = nullptr;
   uint32_t *d_theta = nullptr, *d_flags = nullptr, *d_counts = nullptr, *d_topk = nullptr;
   int32_t *d_topk_counts = nullptr, *d_list_counts = nullptr, *h_list_counts = nullptr;
-  uint64_t *d_entries = nullptr, *d_lists = nullptr, *h_lists = nullptr;
+  uint64_t *d_entries = nullptr, *d_lists = nullptr, *h_lists = nullptr, *d_ovf = nullptr;
+  uint32_t *d_ovf_counts = nullptr;
   float *d_dense0 = nullptr;
   // in-flight sub-batch: busy = device work enqueued and not yet collected; replaying = host replay jobs outstanding
   bool busy = false;
@@ -141,6 +143,9 @@ struct bbq_index {
   // host threads replaying the heaps of one sub-batch: half the cores, at most 8 (a batch of 32 answers 1.4x sooner than with 1)
   int opt_replay_threads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
   int64_t opt_s0 = 4096;
+  // flood tier: candidates one query may pile up beyond the planned list (rows stored cluster by cluster make the
+  // query's own cluster beat a threshold that was derived from other clusters) before it has to take the dense path
+  int64_t opt_flood = 262144;
   bbq_stats stats{};
 };
 
@@ -349,6 +354,7 @@ void build_plan(bbq_index *ix, int64_t k) {
   if (sparse < 0) sparse = 0;
   p.list_cap = dense_rows + (int64_t)(4.0 * sparse) + 4096;
   p.list_cap = (p.list_cap + 1023) / 1024 * 1024;
+  p.flood_cap = std::min<int64_t>(ix->opt_flood, (ix->main.view.n_rows + 1023) / 1024 * 1024);
 }
 
 // ------------------------------------------------------------------------------------------------ slots
@@ -364,6 +370,9 @@ void free_slot_buffers(Slot &s) {
   if (s.d_lists) (void)hipFree(s.d_lists);
   if (s.h_lists) (void)hipHostFree(s.h_lists);
   if (s.d_dense0) (void)hipFree(s.d_dense0);
+  if (s.d_ovf) (void)hipFree(s.d_ovf);
+  s.d_ovf = nullptr;
+  s.d_ovf_counts = nullptr;
   s.d_qbuf = s.h_qbuf = nullptr;
   s.d_theta = s.d_flags = s.d_counts = s.d_topk = nullptr;
   s.d_topk_counts = s.d_list_counts = s.h_list_counts = nullptr;
@@ -379,7 +388,8 @@ int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
   const int64_t qb = qbuf_bytes_per_query(ix);
   const int64_t hprefix = std::min<int64_t>(p.list_cap, 16384);
   const bool ok = s.q_cap >= nq && s.qbuf_bytes >= qb && s.chunks_cap >= p.max_chunks && s.slots_cap >= p.max_slots &&
-                  s.dense_cap >= p.s0 && s.list_cap >= p.list_cap && s.k_cap >= p.k && s.hprefix >= hprefix &&
+                  s.dense_cap >= p.s0 && s.list_cap >= p.list_cap + (own_lists ? p.flood_cap : 0) && s.k_cap >= p.k && s.hprefix >= hprefix &&
+                  s.flood_cap >= p.flood_cap &&
                   (!own_lists || s.d_lists != nullptr);
   if (ok) return BBQ_OK;
   free_slot_buffers(s);
@@ -388,16 +398,19 @@ int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
   s.chunks_cap = std::max<int64_t>(p.max_chunks, 1);
   s.slots_cap = std::max<int64_t>(p.max_slots, 1);
   s.dense_cap = p.s0;
-  s.list_cap = p.list_cap;
+  s.list_cap = p.list_cap + (own_lists ? p.flood_cap : 0);  // own lists can take a flood; external ones are the caller's size
+  s.flood_cap = p.flood_cap;
   s.k_cap = std::max<int64_t>(p.k, 1);
   s.hprefix = hprefix;
   HIPCHK(hipMalloc((void **)&s.d_qbuf, (size_t)(Q * qb)));
   HIPCHK(hipHostMalloc((void **)&s.h_qbuf, (size_t)(Q * qb), hipHostMallocDefault));
-  // theta | flags | topk_counts | list_counts live in one control block so that one memset resets a sub-batch
-  HIPCHK(hipMalloc((void **)&s.d_theta, (size_t)Q * 20));
+  // theta | flags | topk_counts | list_counts | ovf_counts live in one control block so that one memset resets a sub-batch
+  HIPCHK(hipMalloc((void **)&s.d_theta, (size_t)Q * 24));
   s.d_flags = s.d_theta + Q;
   s.d_topk_counts = reinterpret_cast<int32_t *>(s.d_theta + 2 * (size_t)Q);
   s.d_list_counts = reinterpret_cast<int32_t *>(s.d_theta + 3 * (size_t)Q);
+  s.d_ovf_counts = s.d_theta + 5 * (size_t)Q;
+  if (s.flood_cap > 0) HIPCHK(hipMalloc((void **)&s.d_ovf, (size_t)(Q * s.flood_cap) * 8));
   HIPCHK(hipMalloc((void **)&s.d_counts, (size_t)(Q * s.chunks_cap) * 4));
   HIPCHK(hipMalloc((void **)&s.d_topk, (size_t)(Q * s.k_cap) * 4));
   HIPCHK(hipHostMalloc((void **)&s.h_list_counts, (size_t)Q * 8, hipHostMallocDefault));
@@ -539,7 +552,7 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
   uint64_t *d_lists = d_lists_ext ? d_lists_ext : s.d_lists;
   const int64_t list_cap = d_lists_ext ? list_cap_ext : s.list_cap;
   int32_t *d_list_counts = d_counts_ext ? d_counts_ext : s.d_list_counts;
-  HIPCHK(hipMemsetAsync(s.d_theta, 0, (size_t)s.q_cap * 20, st));
+  HIPCHK(hipMemsetAsync(s.d_theta, 0, (size_t)s.q_cap * 24, st));
   if (d_counts_ext) HIPCHK(hipMemsetAsync(d_counts_ext, 0, (size_t)nq * 8, st));
 
   s.timed = false;
@@ -557,6 +570,9 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
     a.flags = s.d_flags;
     a.cap = g.cap;
     a.n_chunks = (int32_t)g.n_chunks;
+    a.ovf = s.d_ovf;
+    a.ovf_counts = s.d_ovf_counts;
+    a.ovf_cap = (int32_t)s.flood_cap;
     a.dense_score32 = g.dense ? s.d_dense0 : nullptr;
     a.dense_stride = s.dense_cap;
     const int my_slot = (int)(&s - ix->slots);
@@ -591,6 +607,8 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
     f.dense_row_id_base = sto.row_id_base + g.chunk_begin * kChunkRows;
     f.n_chunks = (int32_t)g.n_chunks;
     f.cap = g.cap;
+    f.ovf = s.d_ovf;
+    f.ovf_cap = (int32_t)s.flood_cap;
     f.lists = d_lists;
     f.list_counts = d_list_counts;
     f.list_cap = list_cap;
@@ -1234,6 +1252,7 @@ int bbq_set_option(bbq_index *ix, const char *name, int64_t v) {
   else if (n == "replay_threads" && v >= 1 && v <= 256) ix->opt_replay_threads = (int)v;
   else if (n == "force_dense" && (v == 0 || v == 1)) ix->opt_force_dense = (int)v;
   else if (n == "sweep_share" && (v == 1 || v == 4 || v == 8 || v == 32)) ix->opt_share = (int)v;
+  else if (n == "flood_rows" && v >= 0 && v <= (1 << 24)) ix->opt_flood = (v + 1023) / 1024 * 1024;
   else return fail(BBQ_ERR_INVALID_ARG, "bbq_set_option: unknown option or value out of range: %s=%lld", name, (long long)v);
   ix->plan.k = -1;  // workspace is grow-only and re-checked by ensure_slot on the next call
   return BBQ_OK;

@@ -10,6 +10,7 @@ constexpr int kTileRows = 64;        // one wavefront = one tile: lane r owns ro
 #endif
 constexpr int kChunkRows = BBQ_CHUNK_ROWS;  // rows per workgroup (one 64-row tile per wave); candidate slots are per chunk
 constexpr int kTilesPerChunk = kChunkRows / kTileRows;
+constexpr uint32_t kCountRedirect = 0x80000000u;  // chunk count: the entries live in the overflow area
 constexpr uint32_t kFlagOverflow = 1u;   // a candidate slot / list / key buffer overflowed
 constexpr uint32_t kFlagNaN = 2u;        // a NaN score was produced: order statistics are meaningless
 
@@ -62,6 +63,11 @@ struct ScanArgs {
   uint32_t *flags;             // [Q]
   int32_t cap;
   int32_t n_chunks;            // chunks in this launch (= gridDim.x)
+  // flood tier (may be null): a chunk with more than `cap` candidates parks ALL of them, row-ordered, in a block of the
+  // query's overflow area and leaves counts = kCountRedirect | n, entries[0] = block offset (bbq_scan_kernel only)
+  uint64_t *ovf;               // [Q][ovf_cap]
+  uint32_t *ovf_counts;        // [Q] entries handed out so far
+  int32_t ovf_cap;
   // dense output (every row), indexed by row - chunk_begin*1024
   float *dense_score32;        // [Q][dense_stride] or null
   int32_t *dense_qcdist;       // or null
@@ -79,6 +85,8 @@ struct FinalizeArgs {
   int64_t dense_row_id_base;
   int32_t n_chunks;
   int32_t cap;
+  const uint64_t *ovf;         // flood tier of the scan launch (null: none)
+  int32_t ovf_cap;
   // candidate list being built, ascending by global row
   uint64_t *lists;             // [Q][list_cap]
   int32_t *list_counts;        // [Q][2] {count, flags}

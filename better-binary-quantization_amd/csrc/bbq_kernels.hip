@@ -147,7 +147,9 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) 
   const int w16 = W > 0 ? W : a.idx.w16;
   u32x4 *s_planes = reinterpret_cast<u32x4 *>(smem);
   uint64_t *s_ent = reinterpret_cast<uint64_t *>(smem + (size_t)w16 * QB * 16);
-  uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_ent + (DENSE ? 0 : a.cap));
+  // with a flood tier every passing row of the chunk is staged (it may have to move to the overflow area as a whole)
+  const uint32_t stage_cap = DENSE ? 0u : (a.ovf ? (uint32_t)kChunkRows : (uint32_t)a.cap);
+  uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_ent + stage_cap);
 
   const int q = blockIdx.y;
   const int tid = threadIdx.x;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) 
       } else {
         if (valid && (s32 == s32) && key_of_bits(bits) > theta) {
           const uint32_t slot = atomicAdd(s_cnt, 1u);
-          if (slot < (uint32_t)a.cap) s_ent[slot] = ((uint64_t)(uint32_t)(a.row_id_base + row) << 32) | bits;
+          if (slot < stage_cap) s_ent[slot] = ((uint64_t)(uint32_t)(a.row_id_base + row) << 32) | bits;
         }
       }
     }
@@ -240,18 +242,38 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) 
   if constexpr (!DENSE) {
     __syncthreads();
     uint32_t cnt = *s_cnt;
-    if (cnt > (uint32_t)a.cap) {
-      if (tid == 0) atomicOr(a.flags + q, kFlagOverflow);
-      cnt = (uint32_t)a.cap;
+    uint64_t *__restrict__ slot0 = a.entries + ((size_t)q * a.n_chunks + blockIdx.x) * (size_t)a.cap;
+    uint64_t *__restrict__ out = slot0;
+    uint32_t count_word = cnt;
+    if (cnt > (uint32_t)a.cap) {  // workgroup-uniform
+      bool parked = false;
+      if (a.ovf) {
+        // flood (e.g. rows stored cluster by cluster and this is the query's cluster): one block of the query's overflow
+        // area takes the whole chunk, so the list stays row-ordered and the query stays on the sparse path
+        __syncthreads();  // everyone has read *s_cnt
+        if (tid == 0) *s_cnt = atomicAdd(a.ovf_counts + q, cnt);
+        __syncthreads();
+        const uint32_t off = *s_cnt;
+        if ((uint64_t)off + cnt <= (uint64_t)a.ovf_cap) {
+          out = a.ovf + (size_t)q * a.ovf_cap + off;
+          count_word = kCountRedirect | cnt;
+          if (tid == 0) slot0[0] = off;
+          parked = true;
+        }
+      }
+      if (!parked) {
+        if (tid == 0) atomicOr(a.flags + q, kFlagOverflow);
+        cnt = min(cnt, (uint32_t)a.cap);
+        count_word = cnt;
+      }
     }
-    uint64_t *__restrict__ out = a.entries + ((size_t)q * a.n_chunks + blockIdx.x) * (size_t)a.cap;
     for (uint32_t i = tid; i < cnt; i += NT) {  // rows are distinct: rank by counting puts them in row order
       const uint64_t e = s_ent[i];
       uint32_t rank = 0;
       for (uint32_t j = 0; j < cnt; ++j) rank += (s_ent[j] < e) ? 1u : 0u;
       out[rank] = e;
     }
-    if (tid == 0) a.counts[(size_t)q * a.n_chunks + blockIdx.x] = cnt;
+    if (tid == 0) a.counts[(size_t)q * a.n_chunks + blockIdx.x] = count_word;
   }
 }
 
@@ -433,13 +455,14 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
     const int c0 = min(tid * cpt, a.n_chunks), c1 = min(c0 + cpt, a.n_chunks);
     const uint32_t *__restrict__ cnts = a.counts + (size_t)q * a.n_chunks;
     uint32_t sum = 0;
-    for (int c = c0; c < c1; ++c) sum += cnts[c];
+    for (int c = c0; c < c1; ++c) sum += cnts[c] & ~kCountRedirect;
     uint32_t total;
     uint32_t off = block_exclusive_scan_1024(sum, s_wave, total);
     m_new = total;
     for (int c = c0; c < c1; ++c) {
-      const uint32_t n = cnts[c];
+      const uint32_t cw = cnts[c], n = cw & ~kCountRedirect;
       const uint64_t *__restrict__ e = a.entries + ((size_t)q * a.n_chunks + c) * (size_t)a.cap;
+      if (cw & kCountRedirect) e = a.ovf + (size_t)q * a.ovf_cap + (size_t)e[0];  // the chunk's block in the flood tier
       for (uint32_t i = 0; i < n; ++i, ++off) {
         const uint64_t ent = e[i];
         if (a.emit && base + off < a.list_cap) list[base + off] = ent;
@@ -455,11 +478,13 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
   if (a.need_theta) {
     const uint32_t tcount = (uint32_t)a.topk_counts[q];
     uint32_t *__restrict__ tk = a.topk_keys + (size_t)q * a.k;
-    if (m_new + tcount > (uint32_t)kFinalizeKeyCap) {
-      flags |= kFlagOverflow;  // theta stays as it is: still a valid (weaker) bound
-    } else {
-      for (uint32_t i = tid; i < tcount; i += kFinalizeThreads) s_keys[m_new + i] = tk[i];
-      const uint32_t M = m_new + tcount;
+    {
+      // more new keys than the LDS buffer holds (a flood): select among the ones that fit.  The k-th largest of any
+      // SUBSET of the rows seen so far is a valid (weaker) lower bound of the reference heap's minimum, so the
+      // query stays exact and on the sparse path
+      const uint32_t m_use = min(m_new, (uint32_t)kFinalizeKeyCap - tcount);
+      for (uint32_t i = tid; i < tcount; i += kFinalizeThreads) s_keys[m_use + i] = tk[i];
+      const uint32_t M = m_use + tcount;
       __syncthreads();
       if (M < (uint32_t)a.k) {
         // fewer than k rows seen so far: the reference heap is still filling, everything stays a candidate
@@ -631,7 +656,7 @@ __global__ __launch_bounds__(256) void bbq_pack_copy_kernel(const uint64_t *__re
 template <int QB, int W, int MODE>
 static hipError_t launch_scan_t(const ScanArgs &a, int n_queries, int n_chunks, hipStream_t s) {
   const int w16 = W > 0 ? W : a.idx.w16;
-  const size_t smem = (size_t)w16 * QB * 16 + ((MODE & 1) ? 0 : (size_t)a.cap * 8) + 16;
+  const size_t smem = (size_t)w16 * QB * 16 + ((MODE & 1) ? 0 : (size_t)(a.ovf ? kChunkRows : a.cap) * 8) + 16;
   dim3 grid((unsigned)n_chunks, (unsigned)n_queries, 1), block(kChunkRows, 1, 1);
   hipLaunchKernelGGL((bbq_scan_kernel<QB, W, MODE>), grid, block, smem, s, a);
   return hipGetLastError();

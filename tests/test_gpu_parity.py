@@ -903,3 +903,48 @@ def test_fuzz_shapes_options_vs_oracle(seed):
         np.testing.assert_array_equal(canon32(g32), canon32(s32))
     finally:
         ix.close()
+
+
+# ---------------------------------------------------------------- rows stored cluster by cluster (flood tier)
+
+@pytest.mark.parametrize("compact", [True, False])
+@pytest.mark.parametrize("flood_rows,expect_dense", [(262144, False), (1024, True), (0, True)])
+def test_cluster_ordered_rows_stay_exact_and_sparse(compact, flood_rows, expect_dense):
+    """topic/time-ordered ingestion: the query's own cluster sits in one contiguous run of rows and beats a threshold that was
+    derived from other clusters, so whole chunks pass.  The flood tier keeps such queries on the sparse path (no dense
+    fallback) and the answers stay bit-identical; with the tier disabled or too small they fall back and are still exact."""
+    rng = np.random.default_rng(77)
+    n, dim, ncl, nq, k = 120000, 64, 40, 12, 50
+    centres = rng.standard_normal((ncl, dim)).astype(np.float32)
+    cid = np.sort(rng.integers(0, ncl, n))
+    base = centres[cid] + 0.4 * rng.standard_normal((n, dim)).astype(np.float32)
+    qcl = np.array([0, 1, 5, 13, 20, 27, 33, 38, 39, 39, 17, 9])
+    queries = centres[qcl] + 0.4 * rng.standard_normal((nq, dim)).astype(np.float32)
+    sim = 1
+    codes, corr, cen = B.quantize_vectors(base, sim)
+    cdp = B.centroid_dp(cen)
+    ix = _make_index(codes, corr, dim, cdp, compact)
+    try:
+        ix.set_option("flood_rows", flood_rows)
+        ix.set_option("replay_threads", 4)
+        qs = [B.quantize_query(q, cen, sim, 4) for q in queries]
+        qq, qc = np.stack([a for a, _ in qs]), np.stack([b for _, b in qs])
+        idx, sc, cnt = ix.search_batch(qq, qc, 4, sim, k)
+        st = ix.stats()
+        for i in range(nq):
+            d, s64, s32 = O.score_all(codes, corr, dim, qq[i], qc[i], 4, sim, cdp)
+            oi, osc = O.heap_topk(s32, k)
+            np.testing.assert_array_equal(idx[i], oi)
+            np.testing.assert_array_equal(canon32(sc[i]), canon32(osc))
+        if expect_dense:
+            assert st["dense_fallbacks"] > 0
+        else:
+            assert st["dense_fallbacks"] == 0
+            assert st["candidates"] > nq * 1000   # the floods were replayed, not dropped
+        # the same data through the shared sweeps (no flood tier there: those queries take the dense path) is exact too
+        ix.set_option("sweep_share", 8)
+        idx8, sc8, _ = ix.search_batch(qq, qc, 4, sim, k)
+        np.testing.assert_array_equal(idx8, idx)
+        np.testing.assert_array_equal(canon32(sc8), canon32(sc))
+    finally:
+        ix.close()
