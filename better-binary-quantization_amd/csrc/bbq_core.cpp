@@ -570,9 +570,10 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
     a.flags = s.d_flags;
     a.cap = g.cap;
     a.n_chunks = (int32_t)g.n_chunks;
-    a.ovf = s.d_ovf;
+    // the slot's area may be larger than this plan asks for (slots are shared and grow-only): the plan's size governs
+    a.ovf = p.flood_cap > 0 ? s.d_ovf : nullptr;
     a.ovf_counts = s.d_ovf_counts;
-    a.ovf_cap = (int32_t)s.flood_cap;
+    a.ovf_cap = (int32_t)p.flood_cap;
     a.dense_score32 = g.dense ? s.d_dense0 : nullptr;
     a.dense_stride = s.dense_cap;
     const int my_slot = (int)(&s - ix->slots);
@@ -607,8 +608,8 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
     f.dense_row_id_base = sto.row_id_base + g.chunk_begin * kChunkRows;
     f.n_chunks = (int32_t)g.n_chunks;
     f.cap = g.cap;
-    f.ovf = s.d_ovf;
-    f.ovf_cap = (int32_t)s.flood_cap;
+    f.ovf = a.ovf;
+    f.ovf_cap = a.ovf_cap;
     f.lists = d_lists;
     f.list_counts = d_list_counts;
     f.list_cap = list_cap;
