@@ -166,8 +166,8 @@ def test_k_edge_cases(k):
 
 
 def test_adversarial_increasing_scores_falls_back_and_stays_exact():
-    """rows sorted by ascending score: every row enters the reference heap, candidate lists overflow, the
-    dense path takes over - result must still be exact"""
+    """rows sorted by ascending score: every row enters the reference heap.  The flood tier carries all of them to the
+    host replay; without it the candidate slots overflow and the dense path takes over - exact either way"""
     rng = np.random.default_rng(7)
     n, dim, k = 40000, 64, 50
     base = rng.standard_normal((n, dim)).astype(np.float32)
@@ -180,11 +180,13 @@ def test_adversarial_increasing_scores_falls_back_and_stays_exact():
     codes, corr = codes[order].copy(), corr[order].copy()
     ix = B.Index(codes, corr, dim, cdp)
     try:
-        idx, sc = ix.search(qq, qc, 4, sim, k)
         oi, os_ = _oracle_topk(codes, corr, dim, qq, qc, 4, sim, cdp, k)
-        np.testing.assert_array_equal(idx, oi)
-        np.testing.assert_array_equal(sc.view(np.uint32), os_.view(np.uint32))
-        assert ix.stats()["dense_fallbacks"] == 1
+        for flood_rows, dense in ((262144, 0), (0, 1)):
+            ix.set_option("flood_rows", flood_rows)
+            idx, sc = ix.search(qq, qc, 4, sim, k)
+            np.testing.assert_array_equal(idx, oi)
+            np.testing.assert_array_equal(sc.view(np.uint32), os_.view(np.uint32))
+            assert ix.stats()["dense_fallbacks"] == dense
     finally:
         ix.close()
 
