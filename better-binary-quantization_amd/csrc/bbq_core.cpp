@@ -761,12 +761,37 @@ int finish_replay(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score
   const int64_t k = c.k;
   for (int i = 0; i < s.nq; ++i)
     if (s.h_list_counts[2 * i + 1] == 0) ix->stats.candidates += s.h_list_counts[2 * i];
-  for (int i : s.dense_q) {
-    const int64_t qi = s.q_first + i;
+  if (s.dense_q.empty()) return BBQ_OK;
+  // queries the device could not bound.  The shared sweeps have no flood tier: a query whose candidate slots overflowed
+  // there first gets one sweep of its own (slot s is free again at this point) before it pays for the dense path.
+  const std::vector<int> flagged = s.dense_q;
+  std::vector<uint32_t> why;
+  for (int i : flagged) why.push_back((uint32_t)s.h_list_counts[2 * i + 1]);
+  const int64_t first = s.q_first;
+  s.dense_q.clear();
+  for (size_t j = 0; j < flagged.size(); ++j) {
+    const int64_t qi = first + flagged[j];
+    if (ix->opt_share > 1 && ix->plan.flood_cap > 0 && why[j] == kFlagOverflow) {
+      BatchCtx cs = c;
+      cs.k = std::min<int64_t>(c.k, ix->n_rows);
+      const int share = ix->opt_share;
+      ix->opt_share = 1;
+      int rc = enqueue_subbatch(cs, s, qi, 1, nullptr, 0, nullptr);
+      ix->opt_share = share;
+      if (rc == BBQ_OK) rc = begin_replay(c, s, out_idx, out_score, out_n);
+      if (rc != BBQ_OK) return rc;
+      while (s.pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+      s.replaying = false;
+      const bool solved = s.dense_q.empty();
+      s.dense_q.clear();
+      if (solved) {
+        ix->stats.candidates += s.h_list_counts[0];
+        continue;
+      }
+    }
     int rc = dense_search_one(c, qi, out_idx + qi * k, out_score + qi * k, out_n + qi);
     if (rc != BBQ_OK) return rc;
   }
-  s.dense_q.clear();
   return BBQ_OK;
 }
 

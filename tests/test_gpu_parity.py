@@ -943,10 +943,12 @@ def test_cluster_ordered_rows_stay_exact_and_sparse(compact, flood_rows, expect_
         else:
             assert st["dense_fallbacks"] == 0
             assert st["candidates"] > nq * 1000   # the floods were replayed, not dropped
-        # the same data through the shared sweeps (no flood tier there: those queries take the dense path) is exact too
-        ix.set_option("sweep_share", 8)
-        idx8, sc8, _ = ix.search_batch(qq, qc, 4, sim, k)
-        np.testing.assert_array_equal(idx8, idx)
-        np.testing.assert_array_equal(canon32(sc8), canon32(sc))
+        # the shared sweeps have no flood tier of their own: an overflowing query gets one sweep of its own before the dense path
+        for share in (8, 32):
+            ix.set_option("sweep_share", share)
+            idx8, sc8, _ = ix.search_batch(qq, qc, 4, sim, k)
+            np.testing.assert_array_equal(idx8, idx)
+            np.testing.assert_array_equal(canon32(sc8), canon32(sc))
+            assert (ix.stats()["dense_fallbacks"] > 0) == expect_dense
     finally:
         ix.close()
