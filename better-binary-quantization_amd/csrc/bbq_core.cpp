@@ -1213,7 +1213,9 @@ int bbq_shard_scan(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, cons
   BatchCtx c{ix, qquant, qcorr, planes_for(qquant, (int64_t)n_queries * ix->dim), query_bits == 1 ? 1 : 0, sim, k};
   if (c.one_bit) c.planes = 1;
   build_plan(ix, k);
-  const int64_t list_cap = ix->plan.list_cap;
+  // per-query lists with room for a flood (rows stored cluster by cluster); what travels is packed, so the headroom costs
+  // device memory only
+  const int64_t list_cap = ix->plan.list_cap + std::min<int64_t>(ix->plan.flood_cap, 65536);
   if (ix->shard_q_cap < n_queries || ix->shard_list_cap < list_cap) {  // per-query lists the finalize kernels build
     if (ix->d_shard_lists) HIPCHK(hipFree(ix->d_shard_lists));
     if (ix->d_shard_counts) HIPCHK(hipFree(ix->d_shard_counts));
@@ -1247,7 +1249,7 @@ int bbq_shard_scan(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, cons
   // pack: [nq][list_cap] -> contiguous entries + offsets, what the host framework sends over RCCL
   int64_t *d_total = reinterpret_cast<int64_t *>(ix->d_shard_counts + (size_t)n_queries * 2);
   d_total = reinterpret_cast<int64_t *>(((uintptr_t)d_total + 7) & ~(uintptr_t)7);
-  HIPCHK(launch_pack(ix->d_shard_counts, ix->d_shard_lists, list_cap, n_queries, reinterpret_cast<int64_t *>(dev_offsets),
+  HIPCHK(launch_pack(ix->d_shard_counts, ix->d_shard_lists, list_cap, ix->plan.list_cap, n_queries, reinterpret_cast<int64_t *>(dev_offsets),
                      reinterpret_cast<int32_t *>(dev_flags), d_total, reinterpret_cast<uint64_t *>(dev_packed), packed_cap, ix->aux_stream));
   int64_t total = 0;
   HIPCHK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, ix->aux_stream));

