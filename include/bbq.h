@@ -89,9 +89,12 @@ int bbq_index_build(const float *vectors, int64_t n, int32_t dim, int32_t sim, d
 /* Row-sharded variant for one-process-per-GPU deployments (new; the reference has no distribution).
  *   row_base     global row id of this shard's row 0 (shards are contiguous, ascending)
  *   pilot_codes / pilot_corr / n_pilot
- *                optional replica of GLOBAL rows [0, n_pilot) (n_pilot a multiple of 1024, or the
- *                whole index): lets every shard derive valid top-k thresholds without waiting for the
- *                shards before it.  Pass NULL/0 on the shard that owns row 0 (row_base == 0).
+ *                optional replica of n_pilot DISTINCT global rows that all precede this shard (global id <
+ *                row_base; n_pilot a multiple of 1024, or all row_base of them): lets every shard derive valid
+ *                top-k thresholds without waiting for the shards before it.  The prefix [0, n_pilot) works; an
+ *                evenly strided sample of [0, row_base) gives tighter thresholds when rows are stored cluster by
+ *                cluster.  Only thresholds are taken from these rows (their ids never appear in a result).
+ *                Pass NULL/0 on the shard that owns row 0 (row_base == 0).
  */
 int bbq_index_create_shard(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim,
                            int32_t index_bits, double centroid_dp, int64_t row_base,

@@ -978,11 +978,12 @@ def test_sharded_scan_cluster_ordered_rows(squeeze):
     packed, offsets, flagged = [], [], np.zeros(nq, bool)
     for r in range(shards):
         r0, r1 = r * per, min((r + 1) * per, n)
-        P = 4096 if r > 0 else 0
+        # pilot replica = an evenly strided sample of the rows before the shard (a prefix would only know the first clusters)
+        pick = np.linspace(0, r0 - 1, 4096).astype(np.int64) if r > 0 else None
         ix = B.Index(codes[r0:r1], corr[r0:r1], dim, cdp, row_base=r0,
-                     pilot_codes=codes[:P] if P else None, pilot_corr=corr[:P] if P else None)
+                     pilot_codes=codes[pick] if r > 0 else None, pilot_corr=corr[pick] if r > 0 else None)
         adv = int(ix.shard_list_cap(k))
-        cap = adv * nq
+        cap = adv * nq * (1 if squeeze else 8)
         d_packed = torch.zeros(cap, dtype=torch.int64, device="cuda")
         d_off = torch.zeros(nq + 1, dtype=torch.int64, device="cuda")
         d_flags = torch.zeros(nq, dtype=torch.int32, device="cuda")
@@ -995,7 +996,6 @@ def test_sharded_scan_cluster_ordered_rows(squeeze):
             assert (np.diff(off)[fl == 0] <= adv).all() and fl.any()
         elif not squeeze:
             assert not fl.any()
-            assert np.diff(off).max() > adv or r != shards - 1 or True
         flagged |= fl != 0
         packed.append(d_packed[:total].cpu().numpy().view(np.uint64))
         offsets.append(off)
