@@ -114,6 +114,7 @@ struct RerankArgs {
 };
 
 constexpr int kFinalizeThreads = 1024;
+constexpr int kFinalizeFloodJobs = 1024;  // flood blocks one finalize launch copies cooperatively (more: thread by thread)
 constexpr int kFinalizeKeyCap = 12288;   // LDS key buffer of the finalize kernel (new keys + running top-k)
 
 __host__ __device__ inline uint32_t key_of_bits(uint32_t b) { return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }

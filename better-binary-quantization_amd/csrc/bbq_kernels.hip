@@ -434,6 +434,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
   __shared__ uint32_t s_hist[256];
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_misc[4];
+  __shared__ uint32_t s_jobs[3 * kFinalizeFloodJobs];  // flood blocks of this launch: {source offset, list offset, entries}
   const int q = blockIdx.x;
   const int tid = threadIdx.x;
   uint32_t flags = 0;
@@ -459,14 +460,37 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
     uint32_t total;
     uint32_t off = block_exclusive_scan_1024(sum, s_wave, total);
     m_new = total;
+    if (tid == 0) s_misc[3] = 0;
+    __syncthreads();
     for (int c = c0; c < c1; ++c) {
       const uint32_t cw = cnts[c], n = cw & ~kCountRedirect;
       const uint64_t *__restrict__ e = a.entries + ((size_t)q * a.n_chunks + c) * (size_t)a.cap;
-      if (cw & kCountRedirect) e = a.ovf + (size_t)q * a.ovf_cap + (size_t)e[0];  // the chunk's block in the flood tier
+      if (cw & kCountRedirect) {
+        // the chunk's block in the flood tier (up to 512 entries): queued for a cooperative copy below
+        const uint32_t src = (uint32_t)e[0];
+        const uint32_t w = atomicAdd(&s_misc[3], 1u);
+        if (w < (uint32_t)kFinalizeFloodJobs) {
+          s_jobs[3 * w] = src; s_jobs[3 * w + 1] = off; s_jobs[3 * w + 2] = n;
+          off += n;
+          continue;
+        }
+        e = a.ovf + (size_t)q * a.ovf_cap + src;  // job table full: this thread copies the block itself
+      }
       for (uint32_t i = 0; i < n; ++i, ++off) {
         const uint64_t ent = e[i];
         if (a.emit && base + off < a.list_cap) list[base + off] = ent;
         if (off < (uint32_t)kFinalizeKeyCap) s_keys[off] = key_of_bits((uint32_t)ent);
+      }
+    }
+    __syncthreads();
+    const uint32_t n_jobs = min(s_misc[3], (uint32_t)kFinalizeFloodJobs);
+    for (uint32_t j = 0; j < n_jobs; ++j) {
+      const uint64_t *__restrict__ e = a.ovf + (size_t)q * a.ovf_cap + s_jobs[3 * j];
+      const uint32_t o0 = s_jobs[3 * j + 1], n = s_jobs[3 * j + 2];
+      for (uint32_t i = tid; i < n; i += kFinalizeThreads) {
+        const uint64_t ent = e[i];
+        if (a.emit && base + o0 + i < a.list_cap) list[base + o0 + i] = ent;
+        if (o0 + i < (uint32_t)kFinalizeKeyCap) s_keys[o0 + i] = key_of_bits((uint32_t)ent);
       }
     }
   }
