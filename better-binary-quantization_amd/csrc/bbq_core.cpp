@@ -25,134 +25,18 @@
 #include <string>
 #include <thread>
 #include <vector>
-#include "bbq_internal.h"
-#include "bbq_launch.h"
+#include "bbq_host.h"
 
 using namespace bbq;
 
-#define HIPCHK(expr)                                                                          \
-  do {                                                                                        \
-    hipError_t e_ = (expr);                                                                   \
-    if (e_ != hipSuccess) return fail(BBQ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-  } while (0)
-
-namespace {
-
-// device scratch that is released on every exit path
-struct DevMem {
-  void *p = nullptr;
-  DevMem() = default;
-  DevMem(const DevMem &) = delete;
-  DevMem &operator=(const DevMem &) = delete;
-  ~DevMem() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
-  template <class T> T *as() const { return static_cast<T *>(p); }
-};
-
-constexpr int kMaxSlots = 4;
-constexpr int64_t kMaxFastK = 2048;  // beyond this the dense path is used (finalize LDS key buffer)
-
-struct Storage {
-  uint8_t *d_tiles = nullptr;
-  double *d_exact = nullptr;  // kLayoutCompact: exact corrections, gathered for the rows whose bound passes
-  IndexView view{};
-  int64_t row_id_base = 0;
-  int64_t n_chunks() const { return (view.n_rows + kChunkRows - 1) / kChunkRows; }
-};
-
-struct Segment {
-  int storage;  // 0 = pilot replica, 1 = main
-  int64_t chunk_begin, n_chunks, rows;
-  bool dense, emit, need_theta, dominant;
-  int cap;
-  bool big = false;  // large sweeps of different sub-batches are serialised through an event chain
-};
-
-struct Plan {
-  int64_t k = -1;
-  std::vector<Segment> segs;
-  int64_t s0 = 0;
-  int64_t list_cap = 0;
-  int64_t flood_cap = 0;  // per-query entries of the flood tier (overflow area + list headroom); 0: none
-  int64_t max_slots = 0;  // max over sparse segments of n_chunks*cap
-  int64_t max_chunks = 0;
-};
-
-struct Slot {
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr, ev_big = nullptr;
-  // capacities the buffers below were allocated for
-  int q_cap = 0;
-  int64_t qbuf_bytes = 0, chunks_cap = 0, slots_cap = 0, dense_cap = 0, list_cap = 0, k_cap = 0, hprefix = 0, flood_cap = 0;
-  uint8_t *d_qbuf = nullptr, *h_qbuf = nullptr;
-  uint32_t *d_theta = nullptr, *d_flags = nullptr, *d_counts = nullptr, *d_topk = nullptr;
-  int32_t *d_topk_counts = nullptr, *d_list_counts = nullptr, *h_list_counts = nullptr;
-  uint64_t *d_entries = nullptr, *d_lists = nullptr, *h_lists = nullptr, *d_ovf = nullptr;
-  uint32_t *d_ovf_counts = nullptr;
-  float *d_dense0 = nullptr;
-  // in-flight sub-batch: busy = device work enqueued and not yet collected; replaying = host replay jobs outstanding
-  bool busy = false;
-  bool replaying = false;
-  std::atomic<int> pending{0};
-  std::vector<std::vector<uint64_t>> tails;
-  std::vector<int> dense_q;
-  int nq = 0;
-  int64_t q_first = 0;
-  bool timed = false;
-  int64_t timed_rows = 0, timed_bytes = 0;
-};
-
-}  // namespace
-
-// Per-device context shared by every index on that device: streams, events and the per-slot workspace are expensive
-// to create (~10 ms per index with hipStreamCreate/Destroy) and quickSearch builds a fresh index on every call
-// (src/index.ts:109), so they live for the process.  One API call at a time per device (mutex).
-struct DeviceCtx {
-  int device = 0;
-  std::mutex mu;
-  bool ready = false;
-  Slot slots[kMaxSlots];
-  hipStream_t aux_stream = nullptr;   // dense path / bbq_score_rows / index build: never touches an in-flight slot
-  uint8_t *d_aux_qbuf = nullptr;
-  int64_t aux_qbuf_bytes = 0;
-  uint32_t *d_aux_flags = nullptr;
-  int last_big_slot = -1;             // slot whose ev_big marks the end of the most recently enqueued big sweep
-};
-
-struct bbq_index {
-  int device = 0;
-  DeviceCtx *ctx = nullptr;
-  Slot *slots = nullptr;  // = ctx->slots
-  int32_t dim = 0, pb = 0, w16 = 0, tile_stride = 0, has_x1 = 0, bytes_per_row = 0, layout = 0, want_compact = 1;
-  int64_t n_rows = 0, row_base = 0;
-  double centroid_dp = 0;
-  bool has_pilot = false;
-  Storage pilot, main;
-  Plan plan;
-  hipStream_t aux_stream = nullptr;  // = ctx->aux_stream
-  uint8_t *d_aux_qbuf = nullptr;     // = ctx->d_aux_qbuf
-  uint32_t *d_aux_flags = nullptr;
-  float *d_dense_all = nullptr;
-  int64_t dense_all_cap = 0;
-  // bbq_shard_scan: per-query lists before packing
-  uint64_t *d_shard_lists = nullptr;
-  int32_t *d_shard_counts = nullptr;
-  int64_t shard_q_cap = 0, shard_list_cap = 0;
-  // options
-  int opt_batch = 32, opt_slots = 2, opt_growth = 8, opt_force_dense = 0, opt_share = 1;
-  // host threads replaying the heaps of one sub-batch: half the cores, at most 8 (a batch of 32 answers 1.4x sooner than with 1)
-  int opt_replay_threads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
-  int64_t opt_s0 = 4096;
-  // flood tier: candidates one query may pile up beyond the planned list (rows stored cluster by cluster make the
-  // query's own cluster beat a threshold that was derived from other clusters) before it has to take the dense path
-  int64_t opt_flood = 262144;
-  bbq_stats stats{};
-};
-
-namespace {
+namespace bbq {
 
 // per query: bit-planes (up to 8) + int8 values in MFMA fragment order + score uniforms + group maxima
 int64_t qbuf_bytes_per_query_w(int w16) { return (int64_t)w16 * 8 * 16 + (int64_t)w16 * 128 + (int64_t)sizeof(QueryParams) + 16; }
+
+}  // namespace bbq
+
+namespace {
 
 // Host worker pool for the heap replays: persistent threads (spawning per sub-batch cost more than the replay itself
 // once sweeps are shared), fed while the device already works on the next sub-batches.
@@ -193,6 +77,10 @@ class ReplayPool {
   std::vector<std::thread> th_;
 };
 
+}  // namespace
+
+namespace bbq {
+
 std::mutex g_ctx_mu;
 DeviceCtx *g_ctx[64] = {nullptr};
 
@@ -228,6 +116,10 @@ int ensure_aux_qbuf(DeviceCtx *c, int64_t bytes) {
   c->aux_qbuf_bytes = bytes;
   return BBQ_OK;
 }
+
+}  // namespace bbq
+
+namespace {
 
 // ------------------------------------------------------------------------------------------------ storage
 
@@ -809,6 +701,10 @@ int drain(bbq_index *ix) {
   return BBQ_OK;
 }
 
+}  // namespace
+
+namespace bbq {
+
 // frees what the index owns; the device context (streams, workspace) stays
 void destroy_unlocked(bbq_index *ix) {
   if (!ix) return;
@@ -823,7 +719,7 @@ void destroy_unlocked(bbq_index *ix) {
   delete ix;
 }
 
-}  // namespace
+}  // namespace bbq
 
 // ================================================================================================ C ABI
 
@@ -902,132 +798,6 @@ int bbq_index_create_shard(const uint8_t *codes, const double *corr, int64_t n_r
     rc = make_storage(ix.get(), ix->main, codes, corr, n_rows, row_base, true);
     if (rc != BBQ_OK) { destroy_unlocked(ix.release()); return rc; }
   }
-  *out = ix.release();
-  return BBQ_OK;
-}
-
-// quantizeVectors on the device + index in place (bbq_build_kernels.hip)
-int bbq_index_build(const float *vectors, int64_t n, int32_t dim, int32_t sim, double lambda, int32_t iters, int32_t device,
-                    bbq_index **out, float *centroid, uint8_t *codes, double *corr, int64_t *bad_row, int32_t *bad_col) {
-  clear_error();
-  if (!out) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_build: out is null");
-  *out = nullptr;
-  if (n == 0) return fail(BBQ_ERR_EMPTY, "向量集合不能为空");
-  if (n < 0 || dim <= 0 || !vectors || !centroid) return fail(BBQ_ERR_INVALID_ARG, "输入向量不能为空");
-  if (sim < 0 || sim > 2) return fail(BBQ_ERR_INVALID_ARG, "不支持的相似性函数: %d", sim);
-  if (iters < 0 || lambda != lambda) return fail(BBQ_ERR_INVALID_ARG, "bad lambda/iters");
-  if (n > 0xFFFFFFFFll) return fail(BBQ_ERR_UNSUPPORTED, "more than 2^32 rows");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(BBQ_ERR_NO_DEVICE, "no HIP device available: libbbq has no CPU fallback (hipGetDeviceCount found %d)", ndev);
-  if (device < 0 || device >= ndev) return fail(BBQ_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, ndev - 1);
-  HIPCHK(hipSetDevice(device));
-  DeviceCtx *ctx = nullptr;
-  int rc = get_ctx(device, &ctx);
-  if (rc != BBQ_OK) return rc;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  hipStream_t st = ctx->aux_stream;
-
-  const int64_t npad = (n + kTileRows - 1) / kTileRows * kTileRows;
-  const int dim4 = (dim + 3) / 4;
-  float *d_in = nullptr, *d_vT4 = nullptr, *d_cen = nullptr;
-  unsigned long long *d_bad = nullptr;
-  double *d_corr = nullptr;
-  uint8_t *d_codes = nullptr;
-  std::unique_ptr<bbq_index> ix(new bbq_index());
-  auto cleanup = [&]() {
-    if (d_in) (void)hipFree(d_in);
-    if (d_vT4) (void)hipFree(d_vT4);
-    if (d_cen) (void)hipFree(d_cen);
-    if (d_bad) (void)hipFree(d_bad);
-    if (d_corr) (void)hipFree(d_corr);
-    if (d_codes) (void)hipFree(d_codes);
-  };
-#define BCHK(expr)                                                                                   \
-  do {                                                                                               \
-    hipError_t e_ = (expr);                                                                          \
-    if (e_ != hipSuccess) {                                                                          \
-      cleanup();                                                                                     \
-      destroy_unlocked(ix.release());                                                                \
-      return fail(BBQ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));                      \
-    }                                                                                                \
-  } while (0)
-  BCHK(hipMalloc((void **)&d_in, (size_t)n * dim * 4));
-  BCHK(hipMalloc((void **)&d_vT4, (size_t)dim4 * npad * 16));
-  BCHK(hipMemcpyAsync(d_in, vectors, (size_t)n * dim * 4, hipMemcpyHostToDevice, st));
-  BCHK(launch_build_transpose(d_in, n, dim, npad, d_vT4, st));
-  BCHK(hipStreamSynchronize(st));
-  BCHK(hipFree(d_in));
-  d_in = nullptr;
-  if (sim == BBQ_COSINE) BCHK(launch_build_normalize(d_vT4, n, dim, npad, st));  // src/binaryQuantizationFormat.ts:174-176
-  // :196-211 NaN / Infinity validation on the processed vectors, first offender in row-major order
-  unsigned long long bad = ~0ull;
-  BCHK(hipMalloc((void **)&d_bad, 8));
-  BCHK(hipMemcpyAsync(d_bad, &bad, 8, hipMemcpyHostToDevice, st));
-  BCHK(launch_build_validate(d_vT4, n, dim, npad, d_bad, st));
-  BCHK(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, st));
-  BCHK(hipStreamSynchronize(st));
-  if (bad != ~0ull) {
-    const int64_t r = (int64_t)(bad / (unsigned long long)dim);
-    const int c = (int)(bad % (unsigned long long)dim);
-    float v = 0;
-    BCHK(hipMemcpy(&v, d_vT4 + ((size_t)(c / 4) * npad + r) * 4 + (c & 3), 4, hipMemcpyDeviceToHost));
-    cleanup();
-    if (bad_row) *bad_row = r;
-    if (bad_col) *bad_col = c;
-    if (v != v) return fail(BBQ_ERR_NAN_INPUT, "向量 %lld 位置 %d 包含NaN值", (long long)r, c);
-    return fail(BBQ_ERR_INF_INPUT, "向量 %lld 位置 %d 包含Infinity值", (long long)r, c);
-  }
-  BCHK(hipMalloc((void **)&d_cen, (size_t)dim4 * 16));
-  BCHK(launch_build_centroid(d_vT4, n, dim, npad, d_cen, st));  // :214
-  BCHK(hipMemcpyAsync(centroid, d_cen, (size_t)dim * 4, hipMemcpyDeviceToHost, st));
-
-  ix->device = device;
-  ix->ctx = ctx;
-  ix->slots = ctx->slots;
-  ix->aux_stream = ctx->aux_stream;
-  ix->d_aux_flags = ctx->d_aux_flags;
-  ix->dim = dim;
-  ix->pb = (dim + 7) / 8;
-  ix->w16 = (ix->pb + 15) / 16;
-  ix->n_rows = n;
-  ix->row_base = 0;
-  {
-    const char *e = getenv("BBQ_COMPACT_CORRECTIONS");
-    ix->want_compact = (e && e[0] == '0') ? 0 : 1;
-  }
-  ix->has_x1 = 0;  // a freshly quantized 1-bit row's component sum IS its popcount
-  ix->layout = ix->want_compact ? kLayoutCompact : kLayoutInline;
-  ix->tile_stride = ix->w16 * 1024 + (ix->layout == kLayoutCompact ? 512 : 1536);
-  ix->bytes_per_row = ix->tile_stride / kTileRows;
-  Storage &sto = ix->main;
-  const int64_t n_tiles = npad / kTileRows;
-  BCHK(hipMalloc((void **)&sto.d_tiles, (size_t)n_tiles * ix->tile_stride));
-  if (ix->layout == kLayoutCompact) BCHK(hipMalloc((void **)&sto.d_exact, (size_t)npad * 32));
-  if (corr) BCHK(hipMalloc((void **)&d_corr, (size_t)n * 32));
-  BCHK(launch_build_quantize1(d_vT4, n, dim, npad, d_cen, sim, lambda, iters, sto.d_tiles, sto.d_exact, d_corr, ix->w16, ix->tile_stride,
-                              ix->layout, st));  // :221-249
-  if (corr) BCHK(hipMemcpyAsync(corr, d_corr, (size_t)n * 32, hipMemcpyDeviceToHost, st));
-  if (codes) {
-    BCHK(hipMalloc((void **)&d_codes, (size_t)n * ix->pb));
-    BCHK(launch_build_untile(sto.d_tiles, n, ix->pb, ix->w16, ix->tile_stride, d_codes, st));
-    BCHK(hipMemcpyAsync(codes, d_codes, (size_t)n * ix->pb, hipMemcpyDeviceToHost, st));
-  }
-  BCHK(hipStreamSynchronize(st));
-#undef BCHK
-  cleanup();
-  sto.row_id_base = 0;
-  sto.view.tiles = sto.d_tiles;
-  sto.view.exact = sto.d_exact;
-  sto.view.n_rows = n;
-  sto.view.w16 = ix->w16;
-  sto.view.tile_stride = ix->tile_stride;
-  sto.view.has_x1 = 0;
-  sto.view.dim = dim;
-  sto.view.layout = ix->layout;
-  ix->centroid_dp = bbq_centroid_dp(centroid, dim);  // getCentroidDP(undefined), :113-121
-  rc = ensure_aux_qbuf(ctx, qbuf_bytes_per_query_w(ix->w16));
-  if (rc != BBQ_OK) { destroy_unlocked(ix.release()); return rc; }
   *out = ix.release();
   return BBQ_OK;
 }
@@ -1283,510 +1053,6 @@ int bbq_set_option(bbq_index *ix, const char *name, int64_t v) {
   else if (n == "flood_rows" && v >= 0 && v <= (1 << 24)) ix->opt_flood = (v + 1023) / 1024 * 1024;
   else return fail(BBQ_ERR_INVALID_ARG, "bbq_set_option: unknown option or value out of range: %s=%lld", name, (long long)v);
   ix->plan.k = -1;  // workspace is grow-only and re-checked by ensure_slot on the next call
-  return BBQ_OK;
-}
-
-}  // extern "C"
-
-/* ------------------------------------------------------------------ oversample + exact rerank */
-
-struct bbq_vectors {
-  int device = 0;
-  DeviceCtx *ctx = nullptr;
-  float *d = nullptr;
-  int64_t n = 0;
-  int32_t dim = 0;
-  // grow-only staging for bbq_rerank_scores
-  float *d_q = nullptr;
-  int64_t q_cap = 0;
-  int64_t *d_off = nullptr;
-  int64_t off_cap = 0;
-  int32_t *d_rows = nullptr;
-  double *d_out = nullptr;
-  int64_t cand_cap = 0;
-};
-
-namespace {
-
-template <class T>
-int grow(T **p, int64_t *cap, int64_t need) {
-  if (need <= *cap) return BBQ_OK;
-  if (*p) (void)hipFree(*p);
-  *p = nullptr;
-  *cap = 0;
-  const int64_t c = need + need / 2 + 64;
-  HIPCHK(hipMalloc((void **)p, (size_t)c * sizeof(T)));
-  *cap = c;
-  return BBQ_OK;
-}
-
-struct Ranked { double score; int32_t pos; };
-
-// Array.prototype.sort((a, b) => b.trueScore - a.trueScore), src/topKSelector.ts:75,112: stable; an element of the right
-// run overtakes one of the left run only when the comparator says so (> 0), whatever it says for NaN
-void sort_desc_stable(std::vector<Ranked> &v) {
-  const size_t n = v.size();
-  std::vector<Ranked> tmp(n);
-  for (size_t w = 1; w < n; w *= 2) {
-    for (size_t lo = 0; lo < n; lo += 2 * w) {
-      const size_t mid = std::min(lo + w, n), hi = std::min(lo + 2 * w, n);
-      size_t i = lo, j = mid, o = lo;
-      while (i < mid && j < hi) tmp[o++] = (v[j].score - v[i].score) > 0 ? v[j++] : v[i++];
-      while (i < mid) tmp[o++] = v[i++];
-      while (j < hi) tmp[o++] = v[j++];
-    }
-    v.swap(tmp);
-  }
-}
-
-}  // namespace
-
-extern "C" {
-
-int bbq_vectors_create(const float *vectors, int64_t n, int32_t dim, int32_t device, bbq_vectors **out) {
-  clear_error();
-  if (!out) return fail(BBQ_ERR_INVALID_ARG, "bbq_vectors_create: out is null");
-  *out = nullptr;
-  if (n < 0 || dim <= 0 || (n > 0 && !vectors)) return fail(BBQ_ERR_INVALID_ARG, "bbq_vectors_create: bad arguments");
-  if (n > 0x7fffffffLL) return fail(BBQ_ERR_INVALID_ARG, "bbq_vectors_create: more than 2^31-1 rows");
-  DeviceCtx *ctx = nullptr;
-  int rc = get_ctx(device, &ctx);
-  if (rc != BBQ_OK) return rc;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIPCHK(hipSetDevice(device));
-  bbq_vectors *v = new bbq_vectors();
-  v->device = device;
-  v->ctx = ctx;
-  v->n = n;
-  v->dim = dim;
-  if (n > 0) {
-    hipError_t e = hipMalloc((void **)&v->d, (size_t)n * dim * sizeof(float));
-    if (e != hipSuccess) {
-      delete v;
-      return fail(BBQ_ERR_OOM, "bbq_vectors_create: %lld x %d fp32: %s", (long long)n, dim, hipGetErrorString(e));
-    }
-    const int64_t total = n * dim, piece = 64LL << 20;  // 256 MB pieces keep the runtime's pinned staging bounded
-    for (int64_t o = 0; o < total; o += piece) {
-      e = hipMemcpy(v->d + o, vectors + o, (size_t)std::min(piece, total - o) * sizeof(float), hipMemcpyHostToDevice);
-      if (e != hipSuccess) {
-        (void)hipFree(v->d);
-        delete v;
-        return fail(BBQ_ERR_HIP, "bbq_vectors_create: copy: %s", hipGetErrorString(e));
-      }
-    }
-  }
-  *out = v;
-  return BBQ_OK;
-}
-
-void bbq_vectors_destroy(bbq_vectors *v) {
-  if (!v) return;
-  std::lock_guard<std::mutex> lk(v->ctx->mu);
-  (void)hipSetDevice(v->device);
-  if (v->d) (void)hipFree(v->d);
-  if (v->d_q) (void)hipFree(v->d_q);
-  if (v->d_off) (void)hipFree(v->d_off);
-  if (v->d_rows) (void)hipFree(v->d_rows);
-  if (v->d_out) (void)hipFree(v->d_out);
-  delete v;
-}
-
-int64_t bbq_vectors_size(const bbq_vectors *v) { return v ? v->n : 0; }
-int32_t bbq_vectors_dimension(const bbq_vectors *v) { return v ? v->dim : 0; }
-
-int bbq_rerank_scores(bbq_vectors *v, int32_t n_queries, const float *queries, const int64_t *offsets, const int32_t *rows,
-                      int32_t true_sim, double *out_true) {
-  clear_error();
-  if (!v) return fail(BBQ_ERR_INVALID_ARG, "bbq_rerank_scores: vectors handle is null");
-  if (n_queries < 0 || n_queries > 65535) return fail(BBQ_ERR_INVALID_ARG, "bbq_rerank_scores: n_queries out of range");
-  if (true_sim < 0 || true_sim > 2) return fail(BBQ_ERR_INVALID_ARG, "不支持的相似性函数: %d", true_sim);
-  if (n_queries == 0) return BBQ_OK;
-  if (!queries || !offsets) return fail(BBQ_ERR_INVALID_ARG, "bbq_rerank_scores: null argument");
-  if (offsets[0] != 0) return fail(BBQ_ERR_INVALID_ARG, "bbq_rerank_scores: offsets[0] must be 0");
-  int64_t max_count = 0;
-  for (int32_t q = 0; q < n_queries; ++q) {
-    const int64_t c = offsets[q + 1] - offsets[q];
-    if (c < 0) return fail(BBQ_ERR_INVALID_ARG, "bbq_rerank_scores: offsets must ascend");
-    max_count = std::max(max_count, c);
-  }
-  const int64_t total = offsets[n_queries];
-  if (total == 0) return BBQ_OK;
-  if (!rows || !out_true) return fail(BBQ_ERR_INVALID_ARG, "bbq_rerank_scores: null argument");
-  for (int64_t i = 0; i < total; ++i)
-    if (rows[i] < 0 || rows[i] >= v->n) return fail(BBQ_ERR_INVALID_ARG, "基础向量%d不存在", rows[i]);
-  std::lock_guard<std::mutex> lk(v->ctx->mu);
-  HIPCHK(hipSetDevice(v->device));
-  int rc = grow(&v->d_q, &v->q_cap, (int64_t)n_queries * v->dim);
-  if (rc == BBQ_OK) rc = grow(&v->d_off, &v->off_cap, (int64_t)n_queries + 1);
-  if (rc == BBQ_OK && total > v->cand_cap) {
-    int64_t c1 = v->cand_cap, c2 = v->cand_cap;
-    rc = grow(&v->d_rows, &c1, total);
-    if (rc == BBQ_OK) rc = grow(&v->d_out, &c2, total);
-    v->cand_cap = rc == BBQ_OK ? std::min(c1, c2) : 0;
-  }
-  if (rc != BBQ_OK) return rc;
-  hipStream_t st = v->ctx->aux_stream;
-  HIPCHK(hipMemcpyAsync(v->d_q, queries, (size_t)n_queries * v->dim * sizeof(float), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(v->d_off, offsets, (size_t)(n_queries + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(v->d_rows, rows, (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  RerankArgs a{};
-  a.vecs = v->d;
-  a.n = v->n;
-  a.dim = v->dim;
-  a.sim = true_sim;
-  a.queries = v->d_q;
-  a.offsets = v->d_off;
-  a.rows = v->d_rows;
-  a.out = v->d_out;
-  HIPCHK(launch_rerank(a, n_queries, max_count, st));
-  HIPCHK(hipMemcpyAsync(out_true, v->d_out, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  return BBQ_OK;
-}
-
-int bbq_search_rerank_batch(bbq_index *ix, bbq_vectors *v, int32_t n_queries, const float *queries, const uint8_t *qquant,
-                            const double *qcorr, int32_t query_bits, int32_t sim, int64_t k, int32_t factor, int32_t selector,
-                            int32_t true_sim, int32_t *out_idx, float *out_quantized, double *out_true, int64_t *out_n) {
-  clear_error();
-  if (!ix || !v) return fail(BBQ_ERR_INVALID_ARG, "bbq_search_rerank_batch: null handle");
-  if (k < 0) return fail(BBQ_ERR_INVALID_ARG, "k必须是非负数");
-  if (factor < 1) return fail(BBQ_ERR_INVALID_ARG, "bbq_search_rerank_batch: factor must be >= 1");
-  if (selector != 0 && selector != 1) return fail(BBQ_ERR_INVALID_ARG, "bbq_search_rerank_batch: selector must be 0 (heap) or 1 (sort)");
-  if (v->dim != ix->dim) return fail(BBQ_ERR_DIM_MISMATCH, "bbq_search_rerank_batch: vectors are %d-d, index is %d-d", v->dim, ix->dim);
-  if (v->n < ix->n_rows) return fail(BBQ_ERR_INVALID_ARG, "bbq_search_rerank_batch: %lld vectors for %lld index rows", (long long)v->n, (long long)ix->n_rows);
-  if (n_queries > 0 && (!out_n || !queries)) return fail(BBQ_ERR_INVALID_ARG, "bbq_search_rerank_batch: null argument");
-  if (k > 0 && k * (int64_t)factor / factor != k) return fail(BBQ_ERR_INVALID_ARG, "bbq_search_rerank_batch: k*factor overflows");
-  const int64_t kk = k * (int64_t)factor;
-  const int64_t kq = std::min<int64_t>(kk, ix->n_rows);  // candidates a query can return
-  std::vector<int32_t> cidx((size_t)n_queries * (size_t)std::max<int64_t>(kk, 1));
-  std::vector<float> csc(cidx.size());
-  std::vector<int64_t> cn((size_t)std::max(n_queries, 1));
-  // the search strides its outputs by its k; ask for kk but only kq entries per query can be filled
-  int rc = bbq_search_batch(ix, n_queries, qquant, qcorr, query_bits, sim, kk, cidx.data(), csc.data(), cn.data());
-  if (rc != BBQ_OK) return rc;
-  (void)kq;
-  for (int32_t q = 0; q < n_queries; ++q) out_n[q] = 0;
-  if (n_queries == 0 || k == 0) return BBQ_OK;
-  if (!out_idx || !out_quantized || !out_true) return fail(BBQ_ERR_INVALID_ARG, "output arrays are null");
-  std::vector<int64_t> off((size_t)n_queries + 1, 0);
-  for (int32_t q = 0; q < n_queries; ++q) off[q + 1] = off[q] + cn[q];
-  std::vector<int32_t> rows((size_t)off[n_queries]);
-  for (int32_t q = 0; q < n_queries; ++q)
-    std::copy(cidx.begin() + (int64_t)q * kk, cidx.begin() + (int64_t)q * kk + cn[q], rows.begin() + off[q]);
-  std::vector<double> ts(rows.size());
-  rc = bbq_rerank_scores(v, n_queries, queries, off.data(), rows.data(), true_sim, ts.data());
-  if (rc != BBQ_OK) return rc;
-  std::vector<Ranked> r;
-  std::vector<int32_t> tag((size_t)k + 1);
-  std::vector<double> tsc((size_t)k + 1);
-  for (int32_t q = 0; q < n_queries; ++q) {
-    const int64_t cnt = cn[q];
-    const double *t = ts.data() + off[q];
-    r.clear();
-    if (selector == 0) {  // src/topKSelector.ts:40-76
-      HeapReplay h(k, INT64_MAX);
-      for (int64_t i = 0; i < cnt; ++i) h.offer64(t[i], (int32_t)i);
-      const int64_t m = h.drain_ascending(tag.data(), tsc.data());
-      for (int64_t j = 0; j < m; ++j) r.push_back(Ranked{tsc[j], tag[j]});
-      sort_desc_stable(r);
-    } else {  // :102-114
-      for (int64_t i = 0; i < cnt; ++i) r.push_back(Ranked{t[i], (int32_t)i});
-      sort_desc_stable(r);
-      if ((int64_t)r.size() > k) r.resize((size_t)k);
-    }
-    for (size_t j = 0; j < r.size(); ++j) {
-      out_idx[(int64_t)q * k + j] = cidx[(int64_t)q * kk + r[j].pos];
-      out_quantized[(int64_t)q * k + j] = csc[(int64_t)q * kk + r[j].pos];
-      out_true[(int64_t)q * k + j] = r[j].score;
-    }
-    out_n[q] = (int64_t)r.size();
-  }
-  return BBQ_OK;
-}
-
-}  // extern "C"
-
-/* ------------------------------------------------------------------ on-disk format (veb / vemb) */
-
-namespace {
-
-#pragma pack(push, 1)
-struct MetaHeader {
-  char magic[4];  // "BVEC" (COMPONENT_NAMES.BINARIZED_VECTOR, src/constants.ts:62-65)
-  uint32_t version;
-  // MetadataFormat, src/types.ts:92-113
-  int32_t fieldNumber, vectorEncodingOrdinal, vectorSimilarityOrdinal, dimensions;
-  int64_t vectorDataOffset, vectorDataLength, vectorCount;
-  double centroidSquareMagnitude;
-  // geometry of the tile records in the vector-data file (= the device layout, bbq_device.h)
-  int32_t indexBits, layout, w16, tileStride, hasX1, tileRows;
-  int64_t tilesBytes, exactBytes, rowBase;
-};
-#pragma pack(pop)
-static_assert(sizeof(MetaHeader) == 104, "vemb header layout");
-constexpr uint32_t kFileVersion = 1;
-
-// FNV-1a over little-endian 64-bit words (tail zero-padded): one multiply per 8 bytes keeps up with the disk
-uint64_t fnv64_words(const void *data, size_t n, uint64_t h) {
-  const uint8_t *p = (const uint8_t *)data;
-  size_t i = 0;
-  for (; i + 8 <= n; i += 8) {
-    uint64_t w;
-    memcpy(&w, p + i, 8);
-    h = (h ^ w) * 0x100000001b3ull;
-  }
-  if (i < n) {
-    uint64_t w = 0;
-    memcpy(&w, p + i, n - i);
-    h = (h ^ w) * 0x100000001b3ull;
-  }
-  return h;
-}
-constexpr uint64_t kFnvSeed = 0xcbf29ce484222325ull;
-
-int32_t expected_tile_stride(int32_t w16, int32_t layout, int32_t has_x1) {
-  return w16 * 1024 + (layout == kLayoutCompact ? 512 : 1536 + (has_x1 ? 512 : 0));
-}
-
-struct FileCloser {
-  FILE *f;
-  ~FileCloser() { if (f) fclose(f); }
-};
-
-int read_meta(const char *prefix, MetaHeader *h, std::vector<float> *centroid, uint64_t *data_sum) {
-  const std::string path = std::string(prefix) + ".vemb";
-  FileCloser fc{fopen(path.c_str(), "rb")};
-  if (!fc.f) return fail(BBQ_ERR_INVALID_ARG, "cannot open %s", path.c_str());
-  if (fread(h, sizeof *h, 1, fc.f) != 1) return fail(BBQ_ERR_INVALID_ARG, "%s: truncated header", path.c_str());
-  if (memcmp(h->magic, "BVEC", 4) != 0) return fail(BBQ_ERR_INVALID_ARG, "%s: not a BVEC metadata file", path.c_str());
-  if (h->version != kFileVersion) return fail(BBQ_ERR_UNSUPPORTED, "%s: format version %u (this build reads %u)", path.c_str(), h->version, kFileVersion);
-  if (h->dimensions <= 0 || h->dimensions > (1 << 24) || h->vectorCount < 0 || h->rowBase < 0 || h->indexBits != 1 || h->tileRows != kTileRows ||
-      (h->layout != kLayoutCompact && h->layout != kLayoutInline) || (h->hasX1 != 0 && h->hasX1 != 1) ||
-      h->vectorSimilarityOrdinal < 0 || h->vectorSimilarityOrdinal > 2)
-    return fail(BBQ_ERR_INVALID_ARG, "%s: header fields out of range", path.c_str());
-  const int32_t pb = (h->dimensions + 7) / 8;
-  const int64_t n_tiles = (h->vectorCount + kTileRows - 1) / kTileRows;
-  if (h->w16 != (pb + 15) / 16 || h->tileStride != expected_tile_stride(h->w16, h->layout, h->hasX1) ||
-      (h->layout == kLayoutCompact && h->hasX1) || h->tilesBytes != n_tiles * h->tileStride ||
-      h->exactBytes != (h->layout == kLayoutCompact ? n_tiles * kTileRows * 32 : 0) ||
-      h->vectorDataLength != h->tilesBytes + h->exactBytes || h->vectorDataOffset < 0)
-    return fail(BBQ_ERR_INVALID_ARG, "%s: tile geometry does not match dimensions/vectorCount", path.c_str());
-  std::vector<float> cen((size_t)h->dimensions);
-  uint64_t sums[2];
-  if (fread(cen.data(), 4, cen.size(), fc.f) != cen.size() || fread(sums, 8, 2, fc.f) != 2)
-    return fail(BBQ_ERR_INVALID_ARG, "%s: truncated", path.c_str());
-  uint64_t m = fnv64_words(h, sizeof *h, kFnvSeed);
-  m = fnv64_words(cen.data(), cen.size() * 4, m);
-  m = fnv64_words(&sums[0], 8, m);
-  if (m != sums[1]) return fail(BBQ_ERR_INVALID_ARG, "%s: metadata checksum mismatch", path.c_str());
-  if (centroid) centroid->swap(cen);
-  if (data_sum) *data_sum = sums[0];
-  return BBQ_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-int bbq_index_save(bbq_index *ix, const char *prefix, const float *centroid, int32_t sim) {
-  clear_error();
-  if (!ix || !prefix || !centroid) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_save: null argument");
-  if (sim < 0 || sim > 2) return fail(BBQ_ERR_INVALID_ARG, "不支持的相似性函数: %d", sim);
-  if (ix->has_pilot) return fail(BBQ_ERR_UNSUPPORTED, "bbq_index_save: a shard with a pilot replica cannot be saved");
-  std::lock_guard<std::mutex> lk(ix->ctx->mu);
-  HIPCHK(hipSetDevice(ix->device));
-  const int64_t n_tiles = (ix->n_rows + kTileRows - 1) / kTileRows;
-  MetaHeader h{};
-  memcpy(h.magic, "BVEC", 4);
-  h.version = kFileVersion;
-  h.vectorSimilarityOrdinal = sim;
-  h.dimensions = ix->dim;
-  h.vectorCount = ix->n_rows;
-  h.centroidSquareMagnitude = ix->centroid_dp;
-  h.indexBits = 1;
-  h.layout = ix->layout;
-  h.w16 = ix->w16;
-  h.tileStride = ix->tile_stride;
-  h.hasX1 = ix->has_x1;
-  h.tileRows = kTileRows;
-  h.tilesBytes = n_tiles * ix->tile_stride;
-  h.exactBytes = ix->layout == kLayoutCompact ? n_tiles * kTileRows * 32 : 0;
-  h.rowBase = ix->row_base;
-  h.vectorDataOffset = 0;
-  h.vectorDataLength = h.tilesBytes + h.exactBytes;
-  const std::string dpath = std::string(prefix) + ".veb", mpath = std::string(prefix) + ".vemb";
-  uint64_t dsum = kFnvSeed;
-  {
-    FileCloser fc{fopen(dpath.c_str(), "wb")};
-    if (!fc.f) return fail(BBQ_ERR_INVALID_ARG, "cannot create %s", dpath.c_str());
-    const size_t piece = 64u << 20;  // multiple of 8: the checksum words never straddle pieces
-    std::vector<uint8_t> buf(piece);
-    const uint8_t *src[2] = {ix->main.d_tiles, (const uint8_t *)ix->main.d_exact};
-    const int64_t len[2] = {h.tilesBytes, h.exactBytes};
-    for (int part = 0; part < 2; ++part) {
-      for (int64_t o = 0; o < len[part]; o += (int64_t)piece) {
-        const size_t m = (size_t)std::min<int64_t>((int64_t)piece, len[part] - o);
-        HIPCHK(hipMemcpy(buf.data(), src[part] + o, m, hipMemcpyDeviceToHost));
-        dsum = fnv64_words(buf.data(), m, dsum);
-        if (fwrite(buf.data(), 1, m, fc.f) != m) return fail(BBQ_ERR_INVALID_ARG, "%s: write failed", dpath.c_str());
-      }
-    }
-    if (fflush(fc.f) != 0) return fail(BBQ_ERR_INVALID_ARG, "%s: write failed", dpath.c_str());
-  }
-  FileCloser fc{fopen(mpath.c_str(), "wb")};
-  if (!fc.f) return fail(BBQ_ERR_INVALID_ARG, "cannot create %s", mpath.c_str());
-  uint64_t m = fnv64_words(&h, sizeof h, kFnvSeed);
-  m = fnv64_words(centroid, (size_t)ix->dim * 4, m);
-  m = fnv64_words(&dsum, 8, m);
-  const uint64_t sums[2] = {dsum, m};
-  if (fwrite(&h, sizeof h, 1, fc.f) != 1 || fwrite(centroid, 4, (size_t)ix->dim, fc.f) != (size_t)ix->dim || fwrite(sums, 8, 2, fc.f) != 2 ||
-      fflush(fc.f) != 0)
-    return fail(BBQ_ERR_INVALID_ARG, "%s: write failed", mpath.c_str());
-  return BBQ_OK;
-}
-
-int bbq_index_file_info(const char *prefix, int64_t *n_rows, int32_t *dim, int32_t *sim, double *cdp, int64_t *row_base) {
-  clear_error();
-  if (!prefix) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_file_info: null path");
-  MetaHeader h;
-  int rc = read_meta(prefix, &h, nullptr, nullptr);
-  if (rc != BBQ_OK) return rc;
-  if (n_rows) *n_rows = h.vectorCount;
-  if (dim) *dim = h.dimensions;
-  if (sim) *sim = h.vectorSimilarityOrdinal;
-  if (cdp) *cdp = h.centroidSquareMagnitude;
-  if (row_base) *row_base = h.rowBase;
-  return BBQ_OK;
-}
-
-int bbq_index_load(const char *prefix, int32_t device, bbq_index **out, float *centroid_out) {
-  clear_error();
-  if (!out) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_load: out is null");
-  *out = nullptr;
-  if (!prefix) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_load: null path");
-  MetaHeader h;
-  std::vector<float> cen;
-  uint64_t want_sum = 0;
-  int rc = read_meta(prefix, &h, &cen, &want_sum);
-  if (rc != BBQ_OK) return rc;
-  if (h.rowBase + h.vectorCount > 0xFFFFFFFFll) return fail(BBQ_ERR_UNSUPPORTED, "more than 2^32 rows");
-  const std::string dpath = std::string(prefix) + ".veb";
-  FileCloser fc{fopen(dpath.c_str(), "rb")};
-  if (!fc.f) return fail(BBQ_ERR_INVALID_ARG, "cannot open %s", dpath.c_str());
-  if (fseeko(fc.f, 0, SEEK_END) != 0 || ftello(fc.f) < h.vectorDataOffset + h.vectorDataLength)
-    return fail(BBQ_ERR_INVALID_ARG, "%s: shorter than vectorDataOffset + vectorDataLength", dpath.c_str());
-  if (fseeko(fc.f, h.vectorDataOffset, SEEK_SET) != 0) return fail(BBQ_ERR_INVALID_ARG, "%s: seek failed", dpath.c_str());
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(BBQ_ERR_NO_DEVICE, "no HIP device available: libbbq has no CPU fallback (hipGetDeviceCount found %d)", ndev);
-  if (device < 0 || device >= ndev) return fail(BBQ_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, ndev - 1);
-  HIPCHK(hipSetDevice(device));
-  DeviceCtx *ctx = nullptr;
-  rc = get_ctx(device, &ctx);
-  if (rc != BBQ_OK) return rc;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  std::unique_ptr<bbq_index> ix(new bbq_index());
-  ix->device = device;
-  ix->dim = h.dimensions;
-  ix->pb = (h.dimensions + 7) / 8;
-  ix->w16 = h.w16;
-  ix->n_rows = h.vectorCount;
-  ix->row_base = h.rowBase;
-  ix->centroid_dp = h.centroidSquareMagnitude;
-  ix->has_pilot = false;
-  ix->want_compact = h.layout == kLayoutCompact;
-  ix->layout = h.layout;
-  ix->has_x1 = h.hasX1;
-  ix->tile_stride = h.tileStride;
-  ix->bytes_per_row = h.tileStride / kTileRows;
-  ix->ctx = ctx;
-  ix->slots = ctx->slots;
-  ix->aux_stream = ctx->aux_stream;
-  ix->d_aux_flags = ctx->d_aux_flags;
-  rc = ensure_aux_qbuf(ctx, qbuf_bytes_per_query_w(ix->w16));
-  if (rc != BBQ_OK) return rc;
-  Storage &st = ix->main;
-  auto bail = [&](int code) {
-    destroy_unlocked(ix.release());
-    return code;
-  };
-  if (h.tilesBytes > 0 && hipMalloc((void **)&st.d_tiles, (size_t)h.tilesBytes) != hipSuccess)
-    return bail(fail(BBQ_ERR_OOM, "bbq_index_load: %lld bytes of tiles", (long long)h.tilesBytes));
-  if (h.exactBytes > 0 && hipMalloc((void **)&st.d_exact, (size_t)h.exactBytes) != hipSuccess)
-    return bail(fail(BBQ_ERR_OOM, "bbq_index_load: %lld bytes of exact corrections", (long long)h.exactBytes));
-  const size_t piece = 64u << 20;
-  std::vector<uint8_t> buf(piece);
-  uint8_t *dst[2] = {st.d_tiles, (uint8_t *)st.d_exact};
-  const int64_t len[2] = {h.tilesBytes, h.exactBytes};
-  uint64_t dsum = kFnvSeed;
-  for (int part = 0; part < 2; ++part) {
-    for (int64_t o = 0; o < len[part]; o += (int64_t)piece) {
-      const size_t m = (size_t)std::min<int64_t>((int64_t)piece, len[part] - o);
-      if (fread(buf.data(), 1, m, fc.f) != m) return bail(fail(BBQ_ERR_INVALID_ARG, "%s: read failed", dpath.c_str()));
-      dsum = fnv64_words(buf.data(), m, dsum);
-      if (hipMemcpy(dst[part] + o, buf.data(), m, hipMemcpyHostToDevice) != hipSuccess)
-        return bail(fail(BBQ_ERR_HIP, "bbq_index_load: copy to the device failed"));
-    }
-  }
-  if (dsum != want_sum) return bail(fail(BBQ_ERR_INVALID_ARG, "%s: vector data checksum mismatch", dpath.c_str()));
-  st.row_id_base = h.rowBase;
-  st.view.n_rows = h.vectorCount;
-  st.view.w16 = h.w16;
-  st.view.tile_stride = h.tileStride;
-  st.view.has_x1 = h.hasX1;
-  st.view.dim = h.dimensions;
-  st.view.layout = h.layout;
-  st.view.tiles = st.d_tiles;
-  st.view.exact = st.d_exact;
-  if (centroid_out) memcpy(centroid_out, cen.data(), cen.size() * 4);
-  *out = ix.release();
-  return BBQ_OK;
-}
-
-int bbq_index_export(bbq_index *ix, uint8_t *codes, double *corr) {
-  clear_error();
-  if (!ix) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_export: null handle");
-  if (ix->n_rows == 0 || (!codes && !corr)) return BBQ_OK;
-  std::lock_guard<std::mutex> lk(ix->ctx->mu);
-  HIPCHK(hipSetDevice(ix->device));
-  const int64_t n_tiles = (ix->n_rows + kTileRows - 1) / kTileRows;
-  const int64_t group = std::max<int64_t>(1, (64ll << 20) / ix->tile_stride);  // tiles per piece
-  std::vector<uint8_t> buf((size_t)(group * ix->tile_stride));
-  std::vector<double> ex;
-  if (corr && ix->layout == kLayoutCompact) ex.resize((size_t)(group * kTileRows * 4));
-  const int pb = ix->pb, w16 = ix->w16;
-  for (int64_t t0 = 0; t0 < n_tiles; t0 += group) {
-    const int64_t nt = std::min(group, n_tiles - t0);
-    HIPCHK(hipMemcpy(buf.data(), ix->main.d_tiles + t0 * ix->tile_stride, (size_t)(nt * ix->tile_stride), hipMemcpyDeviceToHost));
-    if (!ex.empty())
-      HIPCHK(hipMemcpy(ex.data(), ix->main.d_exact + t0 * kTileRows * 4, (size_t)(nt * kTileRows) * 32, hipMemcpyDeviceToHost));
-    for (int64_t t = 0; t < nt; ++t) {
-      const uint8_t *tp = buf.data() + t * ix->tile_stride;
-      const uint8_t *cr = tp + (size_t)w16 * (kTileRows * 16);
-      for (int r = 0; r < kTileRows; ++r) {
-        const int64_t row = (t0 + t) * kTileRows + r;
-        if (row >= ix->n_rows) break;
-        int ones = 0;
-        for (int b = 0; b < pb; ++b) {
-          const uint8_t v = tp[((size_t)(b >> 4) * kTileRows + r) * 16 + (b & 15)];
-          if (codes) codes[row * pb + b] = v;
-          ones += __builtin_popcount(v);
-        }
-        if (!corr) continue;
-        double *c = corr + row * 4;
-        if (ix->layout == kLayoutCompact) {
-          const double *e = ex.data() + ((size_t)t * kTileRows + r) * 4;
-          c[0] = e[0]; c[1] = e[1]; c[2] = e[2];
-          c[3] = (double)ones;  // compact layout is only chosen when every sum equals the popcount
-        } else {
-          memcpy(c, cr + r * 16, 16);
-          memcpy(c + 2, cr + 1024 + r * 8, 8);
-          if (ix->has_x1) memcpy(c + 3, cr + 1536 + r * 8, 8);
-          else c[3] = (double)ones;
-        }
-      }
-    }
-  }
   return BBQ_OK;
 }
 

@@ -1,0 +1,146 @@
+// bbq_host.h - host-side internals of libbbq shared by its translation units: the device-resident index object, the
+// per-device context (streams, events, per-slot workspace) and the helpers every entry point needs.
+//   bbq_core.cpp     index creation from rows, segment plan, pipelined search, sharded scan, options
+//   bbq_build.cpp    quantizeVectors on the device (bbq_index_build)
+//   bbq_rerank.cpp   oversample + exact rerank (bbq_vectors_*, bbq_rerank_scores, bbq_search_rerank_batch)
+//   bbq_persist.cpp  on-disk format (bbq_index_save / load / file_info / export)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <atomic>
+#include <algorithm>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include "bbq_internal.h"
+#include "bbq_launch.h"
+
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail(BBQ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+namespace bbq {
+
+// device scratch that is released on every exit path
+struct DevMem {
+  void *p = nullptr;
+  DevMem() = default;
+  DevMem(const DevMem &) = delete;
+  DevMem &operator=(const DevMem &) = delete;
+  ~DevMem() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+constexpr int kMaxSlots = 4;
+constexpr int64_t kMaxFastK = 2048;  // beyond this the dense path is used (finalize LDS key buffer)
+
+struct Storage {
+  uint8_t *d_tiles = nullptr;
+  double *d_exact = nullptr;  // kLayoutCompact: exact corrections, gathered for the rows whose bound passes
+  IndexView view{};
+  int64_t row_id_base = 0;
+  int64_t n_chunks() const { return (view.n_rows + kChunkRows - 1) / kChunkRows; }
+};
+
+struct Segment {
+  int storage;  // 0 = pilot replica, 1 = main
+  int64_t chunk_begin, n_chunks, rows;
+  bool dense, emit, need_theta, dominant;
+  int cap;
+  bool big = false;  // large sweeps of different sub-batches are serialised through an event chain
+};
+
+struct Plan {
+  int64_t k = -1;
+  std::vector<Segment> segs;
+  int64_t s0 = 0;
+  int64_t list_cap = 0;
+  int64_t flood_cap = 0;  // per-query entries of the flood tier (overflow area + list headroom); 0: none
+  int64_t max_slots = 0;  // max over sparse segments of n_chunks*cap
+  int64_t max_chunks = 0;
+};
+
+struct Slot {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr, ev_big = nullptr;
+  // capacities the buffers below were allocated for
+  int q_cap = 0;
+  int64_t qbuf_bytes = 0, chunks_cap = 0, slots_cap = 0, dense_cap = 0, list_cap = 0, k_cap = 0, hprefix = 0, flood_cap = 0;
+  uint8_t *d_qbuf = nullptr, *h_qbuf = nullptr;
+  uint32_t *d_theta = nullptr, *d_flags = nullptr, *d_counts = nullptr, *d_topk = nullptr;
+  int32_t *d_topk_counts = nullptr, *d_list_counts = nullptr, *h_list_counts = nullptr;
+  uint64_t *d_entries = nullptr, *d_lists = nullptr, *h_lists = nullptr, *d_ovf = nullptr;
+  uint32_t *d_ovf_counts = nullptr;
+  float *d_dense0 = nullptr;
+  // in-flight sub-batch: busy = device work enqueued and not yet collected; replaying = host replay jobs outstanding
+  bool busy = false;
+  bool replaying = false;
+  std::atomic<int> pending{0};
+  std::vector<std::vector<uint64_t>> tails;
+  std::vector<int> dense_q;
+  int nq = 0;
+  int64_t q_first = 0;
+  bool timed = false;
+  int64_t timed_rows = 0, timed_bytes = 0;
+};
+
+// Per-device context shared by every index on that device: streams, events and the per-slot workspace are expensive
+// to create (~10 ms per index with hipStreamCreate/Destroy) and quickSearch builds a fresh index on every call
+// (src/index.ts:109), so they live for the process.  One API call at a time per device (mutex).
+struct DeviceCtx {
+  int device = 0;
+  std::mutex mu;
+  bool ready = false;
+  Slot slots[kMaxSlots];
+  hipStream_t aux_stream = nullptr;   // dense path / bbq_score_rows / index build: never touches an in-flight slot
+  uint8_t *d_aux_qbuf = nullptr;
+  int64_t aux_qbuf_bytes = 0;
+  uint32_t *d_aux_flags = nullptr;
+  int last_big_slot = -1;             // slot whose ev_big marks the end of the most recently enqueued big sweep
+};
+
+// per query: bit-planes (up to 8) + int8 values in MFMA fragment order + score uniforms + group maxima
+int64_t qbuf_bytes_per_query_w(int w16);
+// returns the (lazily created, never destroyed) context of a device; call with hipSetDevice(device) done
+int get_ctx(int device, DeviceCtx **out);
+int ensure_aux_qbuf(DeviceCtx *c, int64_t bytes);
+
+}  // namespace bbq
+
+struct bbq_index {
+  int device = 0;
+  bbq::DeviceCtx *ctx = nullptr;
+  bbq::Slot *slots = nullptr;  // = ctx->slots
+  int32_t dim = 0, pb = 0, w16 = 0, tile_stride = 0, has_x1 = 0, bytes_per_row = 0, layout = 0, want_compact = 1;
+  int64_t n_rows = 0, row_base = 0;
+  double centroid_dp = 0;
+  bool has_pilot = false;
+  bbq::Storage pilot, main;
+  bbq::Plan plan;
+  hipStream_t aux_stream = nullptr;  // = ctx->aux_stream
+  uint8_t *d_aux_qbuf = nullptr;     // = ctx->d_aux_qbuf
+  uint32_t *d_aux_flags = nullptr;
+  float *d_dense_all = nullptr;
+  int64_t dense_all_cap = 0;
+  // bbq_shard_scan: per-query lists before packing
+  uint64_t *d_shard_lists = nullptr;
+  int32_t *d_shard_counts = nullptr;
+  int64_t shard_q_cap = 0, shard_list_cap = 0;
+  // options
+  int opt_batch = 32, opt_slots = 2, opt_growth = 8, opt_force_dense = 0, opt_share = 1;
+  // host threads replaying the heaps of one sub-batch: half the cores, at most 8 (a batch of 32 answers 1.4x sooner than with 1)
+  int opt_replay_threads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
+  int64_t opt_s0 = 4096;
+  // flood tier: candidates one query may pile up beyond the planned list (rows stored cluster by cluster make the
+  // query's own cluster beat a threshold that was derived from other clusters) before it has to take the dense path
+  int64_t opt_flood = 262144;
+  bbq_stats stats{};
+};
+
+namespace bbq {
+// frees what the index owns; the device context (streams, workspace) stays.  Call with the context mutex held.
+void destroy_unlocked(bbq_index *ix);
+}  // namespace bbq

@@ -1,0 +1,294 @@
+// bbq_persist.cpp - on-disk format: <prefix>.vemb (metadata) + <prefix>.veb (the device tile records, byte for byte)
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <memory>
+#include <string>
+#include "bbq_host.h"
+
+using namespace bbq;
+
+namespace {
+
+#pragma pack(push, 1)
+struct MetaHeader {
+  char magic[4];  // "BVEC" (COMPONENT_NAMES.BINARIZED_VECTOR, src/constants.ts:62-65)
+  uint32_t version;
+  // MetadataFormat, src/types.ts:92-113
+  int32_t fieldNumber, vectorEncodingOrdinal, vectorSimilarityOrdinal, dimensions;
+  int64_t vectorDataOffset, vectorDataLength, vectorCount;
+  double centroidSquareMagnitude;
+  // geometry of the tile records in the vector-data file (= the device layout, bbq_device.h)
+  int32_t indexBits, layout, w16, tileStride, hasX1, tileRows;
+  int64_t tilesBytes, exactBytes, rowBase;
+};
+#pragma pack(pop)
+static_assert(sizeof(MetaHeader) == 104, "vemb header layout");
+constexpr uint32_t kFileVersion = 1;
+
+// FNV-1a over little-endian 64-bit words (tail zero-padded): one multiply per 8 bytes keeps up with the disk
+uint64_t fnv64_words(const void *data, size_t n, uint64_t h) {
+  const uint8_t *p = (const uint8_t *)data;
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w;
+    memcpy(&w, p + i, 8);
+    h = (h ^ w) * 0x100000001b3ull;
+  }
+  if (i < n) {
+    uint64_t w = 0;
+    memcpy(&w, p + i, n - i);
+    h = (h ^ w) * 0x100000001b3ull;
+  }
+  return h;
+}
+constexpr uint64_t kFnvSeed = 0xcbf29ce484222325ull;
+
+int32_t expected_tile_stride(int32_t w16, int32_t layout, int32_t has_x1) {
+  return w16 * 1024 + (layout == kLayoutCompact ? 512 : 1536 + (has_x1 ? 512 : 0));
+}
+
+struct FileCloser {
+  FILE *f;
+  ~FileCloser() { if (f) fclose(f); }
+};
+
+int read_meta(const char *prefix, MetaHeader *h, std::vector<float> *centroid, uint64_t *data_sum) {
+  const std::string path = std::string(prefix) + ".vemb";
+  FileCloser fc{fopen(path.c_str(), "rb")};
+  if (!fc.f) return fail(BBQ_ERR_INVALID_ARG, "cannot open %s", path.c_str());
+  if (fread(h, sizeof *h, 1, fc.f) != 1) return fail(BBQ_ERR_INVALID_ARG, "%s: truncated header", path.c_str());
+  if (memcmp(h->magic, "BVEC", 4) != 0) return fail(BBQ_ERR_INVALID_ARG, "%s: not a BVEC metadata file", path.c_str());
+  if (h->version != kFileVersion) return fail(BBQ_ERR_UNSUPPORTED, "%s: format version %u (this build reads %u)", path.c_str(), h->version, kFileVersion);
+  if (h->dimensions <= 0 || h->dimensions > (1 << 24) || h->vectorCount < 0 || h->rowBase < 0 || h->indexBits != 1 || h->tileRows != kTileRows ||
+      (h->layout != kLayoutCompact && h->layout != kLayoutInline) || (h->hasX1 != 0 && h->hasX1 != 1) ||
+      h->vectorSimilarityOrdinal < 0 || h->vectorSimilarityOrdinal > 2)
+    return fail(BBQ_ERR_INVALID_ARG, "%s: header fields out of range", path.c_str());
+  const int32_t pb = (h->dimensions + 7) / 8;
+  const int64_t n_tiles = (h->vectorCount + kTileRows - 1) / kTileRows;
+  if (h->w16 != (pb + 15) / 16 || h->tileStride != expected_tile_stride(h->w16, h->layout, h->hasX1) ||
+      (h->layout == kLayoutCompact && h->hasX1) || h->tilesBytes != n_tiles * h->tileStride ||
+      h->exactBytes != (h->layout == kLayoutCompact ? n_tiles * kTileRows * 32 : 0) ||
+      h->vectorDataLength != h->tilesBytes + h->exactBytes || h->vectorDataOffset < 0)
+    return fail(BBQ_ERR_INVALID_ARG, "%s: tile geometry does not match dimensions/vectorCount", path.c_str());
+  std::vector<float> cen((size_t)h->dimensions);
+  uint64_t sums[2];
+  if (fread(cen.data(), 4, cen.size(), fc.f) != cen.size() || fread(sums, 8, 2, fc.f) != 2)
+    return fail(BBQ_ERR_INVALID_ARG, "%s: truncated", path.c_str());
+  uint64_t m = fnv64_words(h, sizeof *h, kFnvSeed);
+  m = fnv64_words(cen.data(), cen.size() * 4, m);
+  m = fnv64_words(&sums[0], 8, m);
+  if (m != sums[1]) return fail(BBQ_ERR_INVALID_ARG, "%s: metadata checksum mismatch", path.c_str());
+  if (centroid) centroid->swap(cen);
+  if (data_sum) *data_sum = sums[0];
+  return BBQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bbq_index_save(bbq_index *ix, const char *prefix, const float *centroid, int32_t sim) {
+  clear_error();
+  if (!ix || !prefix || !centroid) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_save: null argument");
+  if (sim < 0 || sim > 2) return fail(BBQ_ERR_INVALID_ARG, "不支持的相似性函数: %d", sim);
+  if (ix->has_pilot) return fail(BBQ_ERR_UNSUPPORTED, "bbq_index_save: a shard with a pilot replica cannot be saved");
+  std::lock_guard<std::mutex> lk(ix->ctx->mu);
+  HIPCHK(hipSetDevice(ix->device));
+  const int64_t n_tiles = (ix->n_rows + kTileRows - 1) / kTileRows;
+  MetaHeader h{};
+  memcpy(h.magic, "BVEC", 4);
+  h.version = kFileVersion;
+  h.vectorSimilarityOrdinal = sim;
+  h.dimensions = ix->dim;
+  h.vectorCount = ix->n_rows;
+  h.centroidSquareMagnitude = ix->centroid_dp;
+  h.indexBits = 1;
+  h.layout = ix->layout;
+  h.w16 = ix->w16;
+  h.tileStride = ix->tile_stride;
+  h.hasX1 = ix->has_x1;
+  h.tileRows = kTileRows;
+  h.tilesBytes = n_tiles * ix->tile_stride;
+  h.exactBytes = ix->layout == kLayoutCompact ? n_tiles * kTileRows * 32 : 0;
+  h.rowBase = ix->row_base;
+  h.vectorDataOffset = 0;
+  h.vectorDataLength = h.tilesBytes + h.exactBytes;
+  const std::string dpath = std::string(prefix) + ".veb", mpath = std::string(prefix) + ".vemb";
+  uint64_t dsum = kFnvSeed;
+  {
+    FileCloser fc{fopen(dpath.c_str(), "wb")};
+    if (!fc.f) return fail(BBQ_ERR_INVALID_ARG, "cannot create %s", dpath.c_str());
+    const size_t piece = 64u << 20;  // multiple of 8: the checksum words never straddle pieces
+    std::vector<uint8_t> buf(piece);
+    const uint8_t *src[2] = {ix->main.d_tiles, (const uint8_t *)ix->main.d_exact};
+    const int64_t len[2] = {h.tilesBytes, h.exactBytes};
+    for (int part = 0; part < 2; ++part) {
+      for (int64_t o = 0; o < len[part]; o += (int64_t)piece) {
+        const size_t m = (size_t)std::min<int64_t>((int64_t)piece, len[part] - o);
+        HIPCHK(hipMemcpy(buf.data(), src[part] + o, m, hipMemcpyDeviceToHost));
+        dsum = fnv64_words(buf.data(), m, dsum);
+        if (fwrite(buf.data(), 1, m, fc.f) != m) return fail(BBQ_ERR_INVALID_ARG, "%s: write failed", dpath.c_str());
+      }
+    }
+    if (fflush(fc.f) != 0) return fail(BBQ_ERR_INVALID_ARG, "%s: write failed", dpath.c_str());
+  }
+  FileCloser fc{fopen(mpath.c_str(), "wb")};
+  if (!fc.f) return fail(BBQ_ERR_INVALID_ARG, "cannot create %s", mpath.c_str());
+  uint64_t m = fnv64_words(&h, sizeof h, kFnvSeed);
+  m = fnv64_words(centroid, (size_t)ix->dim * 4, m);
+  m = fnv64_words(&dsum, 8, m);
+  const uint64_t sums[2] = {dsum, m};
+  if (fwrite(&h, sizeof h, 1, fc.f) != 1 || fwrite(centroid, 4, (size_t)ix->dim, fc.f) != (size_t)ix->dim || fwrite(sums, 8, 2, fc.f) != 2 ||
+      fflush(fc.f) != 0)
+    return fail(BBQ_ERR_INVALID_ARG, "%s: write failed", mpath.c_str());
+  return BBQ_OK;
+}
+
+int bbq_index_file_info(const char *prefix, int64_t *n_rows, int32_t *dim, int32_t *sim, double *cdp, int64_t *row_base) {
+  clear_error();
+  if (!prefix) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_file_info: null path");
+  MetaHeader h;
+  int rc = read_meta(prefix, &h, nullptr, nullptr);
+  if (rc != BBQ_OK) return rc;
+  if (n_rows) *n_rows = h.vectorCount;
+  if (dim) *dim = h.dimensions;
+  if (sim) *sim = h.vectorSimilarityOrdinal;
+  if (cdp) *cdp = h.centroidSquareMagnitude;
+  if (row_base) *row_base = h.rowBase;
+  return BBQ_OK;
+}
+
+int bbq_index_load(const char *prefix, int32_t device, bbq_index **out, float *centroid_out) {
+  clear_error();
+  if (!out) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_load: out is null");
+  *out = nullptr;
+  if (!prefix) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_load: null path");
+  MetaHeader h;
+  std::vector<float> cen;
+  uint64_t want_sum = 0;
+  int rc = read_meta(prefix, &h, &cen, &want_sum);
+  if (rc != BBQ_OK) return rc;
+  if (h.rowBase + h.vectorCount > 0xFFFFFFFFll) return fail(BBQ_ERR_UNSUPPORTED, "more than 2^32 rows");
+  const std::string dpath = std::string(prefix) + ".veb";
+  FileCloser fc{fopen(dpath.c_str(), "rb")};
+  if (!fc.f) return fail(BBQ_ERR_INVALID_ARG, "cannot open %s", dpath.c_str());
+  if (fseeko(fc.f, 0, SEEK_END) != 0 || ftello(fc.f) < h.vectorDataOffset + h.vectorDataLength)
+    return fail(BBQ_ERR_INVALID_ARG, "%s: shorter than vectorDataOffset + vectorDataLength", dpath.c_str());
+  if (fseeko(fc.f, h.vectorDataOffset, SEEK_SET) != 0) return fail(BBQ_ERR_INVALID_ARG, "%s: seek failed", dpath.c_str());
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(BBQ_ERR_NO_DEVICE, "no HIP device available: libbbq has no CPU fallback (hipGetDeviceCount found %d)", ndev);
+  if (device < 0 || device >= ndev) return fail(BBQ_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+  HIPCHK(hipSetDevice(device));
+  DeviceCtx *ctx = nullptr;
+  rc = get_ctx(device, &ctx);
+  if (rc != BBQ_OK) return rc;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::unique_ptr<bbq_index> ix(new bbq_index());
+  ix->device = device;
+  ix->dim = h.dimensions;
+  ix->pb = (h.dimensions + 7) / 8;
+  ix->w16 = h.w16;
+  ix->n_rows = h.vectorCount;
+  ix->row_base = h.rowBase;
+  ix->centroid_dp = h.centroidSquareMagnitude;
+  ix->has_pilot = false;
+  ix->want_compact = h.layout == kLayoutCompact;
+  ix->layout = h.layout;
+  ix->has_x1 = h.hasX1;
+  ix->tile_stride = h.tileStride;
+  ix->bytes_per_row = h.tileStride / kTileRows;
+  ix->ctx = ctx;
+  ix->slots = ctx->slots;
+  ix->aux_stream = ctx->aux_stream;
+  ix->d_aux_flags = ctx->d_aux_flags;
+  rc = ensure_aux_qbuf(ctx, qbuf_bytes_per_query_w(ix->w16));
+  if (rc != BBQ_OK) return rc;
+  Storage &st = ix->main;
+  auto bail = [&](int code) {
+    destroy_unlocked(ix.release());
+    return code;
+  };
+  if (h.tilesBytes > 0 && hipMalloc((void **)&st.d_tiles, (size_t)h.tilesBytes) != hipSuccess)
+    return bail(fail(BBQ_ERR_OOM, "bbq_index_load: %lld bytes of tiles", (long long)h.tilesBytes));
+  if (h.exactBytes > 0 && hipMalloc((void **)&st.d_exact, (size_t)h.exactBytes) != hipSuccess)
+    return bail(fail(BBQ_ERR_OOM, "bbq_index_load: %lld bytes of exact corrections", (long long)h.exactBytes));
+  const size_t piece = 64u << 20;
+  std::vector<uint8_t> buf(piece);
+  uint8_t *dst[2] = {st.d_tiles, (uint8_t *)st.d_exact};
+  const int64_t len[2] = {h.tilesBytes, h.exactBytes};
+  uint64_t dsum = kFnvSeed;
+  for (int part = 0; part < 2; ++part) {
+    for (int64_t o = 0; o < len[part]; o += (int64_t)piece) {
+      const size_t m = (size_t)std::min<int64_t>((int64_t)piece, len[part] - o);
+      if (fread(buf.data(), 1, m, fc.f) != m) return bail(fail(BBQ_ERR_INVALID_ARG, "%s: read failed", dpath.c_str()));
+      dsum = fnv64_words(buf.data(), m, dsum);
+      if (hipMemcpy(dst[part] + o, buf.data(), m, hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(BBQ_ERR_HIP, "bbq_index_load: copy to the device failed"));
+    }
+  }
+  if (dsum != want_sum) return bail(fail(BBQ_ERR_INVALID_ARG, "%s: vector data checksum mismatch", dpath.c_str()));
+  st.row_id_base = h.rowBase;
+  st.view.n_rows = h.vectorCount;
+  st.view.w16 = h.w16;
+  st.view.tile_stride = h.tileStride;
+  st.view.has_x1 = h.hasX1;
+  st.view.dim = h.dimensions;
+  st.view.layout = h.layout;
+  st.view.tiles = st.d_tiles;
+  st.view.exact = st.d_exact;
+  if (centroid_out) memcpy(centroid_out, cen.data(), cen.size() * 4);
+  *out = ix.release();
+  return BBQ_OK;
+}
+
+int bbq_index_export(bbq_index *ix, uint8_t *codes, double *corr) {
+  clear_error();
+  if (!ix) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_export: null handle");
+  if (ix->n_rows == 0 || (!codes && !corr)) return BBQ_OK;
+  std::lock_guard<std::mutex> lk(ix->ctx->mu);
+  HIPCHK(hipSetDevice(ix->device));
+  const int64_t n_tiles = (ix->n_rows + kTileRows - 1) / kTileRows;
+  const int64_t group = std::max<int64_t>(1, (64ll << 20) / ix->tile_stride);  // tiles per piece
+  std::vector<uint8_t> buf((size_t)(group * ix->tile_stride));
+  std::vector<double> ex;
+  if (corr && ix->layout == kLayoutCompact) ex.resize((size_t)(group * kTileRows * 4));
+  const int pb = ix->pb, w16 = ix->w16;
+  for (int64_t t0 = 0; t0 < n_tiles; t0 += group) {
+    const int64_t nt = std::min(group, n_tiles - t0);
+    HIPCHK(hipMemcpy(buf.data(), ix->main.d_tiles + t0 * ix->tile_stride, (size_t)(nt * ix->tile_stride), hipMemcpyDeviceToHost));
+    if (!ex.empty())
+      HIPCHK(hipMemcpy(ex.data(), ix->main.d_exact + t0 * kTileRows * 4, (size_t)(nt * kTileRows) * 32, hipMemcpyDeviceToHost));
+    for (int64_t t = 0; t < nt; ++t) {
+      const uint8_t *tp = buf.data() + t * ix->tile_stride;
+      const uint8_t *cr = tp + (size_t)w16 * (kTileRows * 16);
+      for (int r = 0; r < kTileRows; ++r) {
+        const int64_t row = (t0 + t) * kTileRows + r;
+        if (row >= ix->n_rows) break;
+        int ones = 0;
+        for (int b = 0; b < pb; ++b) {
+          const uint8_t v = tp[((size_t)(b >> 4) * kTileRows + r) * 16 + (b & 15)];
+          if (codes) codes[row * pb + b] = v;
+          ones += __builtin_popcount(v);
+        }
+        if (!corr) continue;
+        double *c = corr + row * 4;
+        if (ix->layout == kLayoutCompact) {
+          const double *e = ex.data() + ((size_t)t * kTileRows + r) * 4;
+          c[0] = e[0]; c[1] = e[1]; c[2] = e[2];
+          c[3] = (double)ones;  // compact layout is only chosen when every sum equals the popcount
+        } else {
+          memcpy(c, cr + r * 16, 16);
+          memcpy(c + 2, cr + 1024 + r * 8, 8);
+          if (ix->has_x1) memcpy(c + 3, cr + 1536 + r * 8, 8);
+          else c[3] = (double)ones;
+        }
+      }
+    }
+  }
+  return BBQ_OK;
+}
+
+}  // extern "C"
