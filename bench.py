@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--pilot", type=int, default=32768, help="replicated pilot rows per non-root shard (multi-GPU)")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the full-size oracle check of one timed query")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value")
     ap.add_argument("--shared-sweep", type=int, default=32, help="also time the batched mode (queries per shared sweep; 0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1: nccl (= RCCL) or gloo (rehearsal)")
@@ -289,21 +290,11 @@ def main():
         }
         if batched is not None:
             out["batched"] = batched
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed at N=1 only
             us_row, done, rows, secs = cpu_baseline(dim, k, codes, corr, qq_all, qc_all, cdp, QB, SIM)
             out["cpu_baseline"] = {"value": 1e6 / (us_row * N), "unit": "queries/s", "cores": 1, "kind": "port",
                                    "sample": "%d queries x %d rows of the same synthetic index in %.1fs (%.3f us/row), linearly extrapolated to %d rows"
                                              % (done, rows, secs, us_row, N)}
-            # the sample doubles as a parity check of the timed configuration: one full-size query against the oracle
-            import orclib as O
-            if world == 1:
-                fc, fr = codes, corr
-            else:
-                fc, fr = synth_rows(1, 0, N, pb)  # rank 0 rebuilds the whole index for the checker only
-            _, _, s32 = O.score_all(fc, fr, dim, qq_all[args.warmup * Q], qc_all[args.warmup * Q], QB, SIM, cdp)
-            oi, osc = O.heap_topk(s32, k)
-            gi, gs, _ = results[args.warmup]
-            out["parity_full_size"] = bool((gi[0] == oi).all() and (gs[0].view(np.uint32) == osc.view(np.uint32)).all())
             # the same loops restated in JS, under node on this box's host, 1 core
             import shutil
             import subprocess
@@ -318,6 +309,17 @@ def main():
                                                         % (js["queries"], js["rows"], js["seconds"], js["us_per_row"], N)}
                 except Exception as e:  # the baseline is informational: never fail the bench for it
                     out["cpu_baseline_js"] = {"error": str(e)[:200]}
+        if not args.no_parity:
+            # parity check of the timed configuration (any N): one full-size query of the timed region against the oracle
+            import orclib as O
+            if world == 1:
+                fc, fr = codes, corr
+            else:
+                fc, fr = synth_rows(1, 0, N, pb)  # rank 0 rebuilds the whole index for the checker only
+            _, _, s32 = O.score_all(fc, fr, dim, qq_all[args.warmup * Q], qc_all[args.warmup * Q], QB, SIM, cdp)
+            oi, osc = O.heap_topk(s32, k)
+            gi, gs, _ = results[args.warmup]
+            out["parity_full_size"] = bool((gi[0] == oi).all() and (gs[0].view(np.uint32) == osc.view(np.uint32)).all())
         if not args.no_recall:
             rec, desc = recall_probe(B, device)
             out["recall_at_100"] = rec
