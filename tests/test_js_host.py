@@ -16,3 +16,15 @@ def test_js_host_gpu_parity():
     print(r.stdout[-2000:])
     assert r.returncode == 0, r.stdout[-4000:]
     assert "0 failures" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_js_reference_suite():
+    """the reference's own test expectations (recall thresholds on its closed-form datasets, batch == single, known answers)
+    through the drop-in JavaScript API"""
+    r = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "reference_suite.js")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=900)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-4000:]
+    assert "0 failures" in r.stdout
