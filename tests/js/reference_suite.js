@@ -101,9 +101,8 @@ function avgRecall(fmt, base, queries, k, oversample) {
       const one = fmt.getScorer().computeBatchQuantizedScores(qq.quantizedQuery, qq.queryCorrections, index, [i], qb)[0];
       same = same && Math.abs(one.score - batch[i].score) <= 1e-10 && one.bitDotProduct === batch[i].bitDotProduct;
       const row = index.getUnpackedVector(i);
-      let dot = 0;
-      if (qb === 1) { const qrow = qq.quantizedQuery; for (let d = 0; d < 1024; d++) dot += ((qrow[d >> 3] >> (7 - (d & 7))) & 1) * row[d]; }
-      else for (let d = 0; d < 1024; d++) dot += qq.quantizedQuery[d] * row[d];
+      let dot = 0;   // the scorer packs a 1-bit query itself (src/binaryQuantizedScorer.ts:333-335): a plain dot in both cases
+      for (let d = 0; d < 1024; d++) dot += qq.quantizedQuery[d] * row[d];
       naive = naive && dot === batch[i].bitDotProduct;
     }
     T.check(same, 'batch-quantized-scores.test.ts:' + (qb === 1 ? '130-145' : '281-294') + ' batch == single-row within 1e-10 (queryBits ' + qb + ')');
