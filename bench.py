@@ -69,17 +69,20 @@ def synth_queries(seed, nq, dim, qb=4):
     return qq, qc
 
 
-def recall_probe(B, device, n=200000, dim=768, nq=32, k=100):
-    """real fp32 vectors -> product quantizer -> GPU search, recall@k against an fp32 brute force (torch, same GPU)"""
+def recall_probe(B, device, n=1_000_000, dim=768, nq=32, k=100):
+    """real fp32 vectors -> quantizeVectors on the device -> GPU search, recall@k against an fp32 brute force (torch, same GPU).
+    SURVEY 8(d): a 1 M x 768 fp32 run; --recall-rows 10000000 repeats it at the headline size (30.7 GB of fp32)."""
     import torch
     rng = np.random.default_rng(99)
     # clustered data (random vectors have no neighbour structure to recall): 2000 centres + noise
-    centres = rng.standard_normal((2000, dim)).astype(np.float32)
-    base = centres[rng.integers(0, 2000, n)] + 0.7 * rng.standard_normal((n, dim)).astype(np.float32)
-    queries = centres[rng.integers(0, 2000, nq)] + 0.7 * rng.standard_normal((nq, dim)).astype(np.float32)
+    centres = rng.standard_normal((2000, dim), dtype=np.float32)
+    base = np.empty((n, dim), np.float32)
+    for i in range(0, n, 250000):
+        m = min(250000, n - i)
+        base[i:i + m] = centres[rng.integers(0, 2000, m)] + 0.7 * rng.standard_normal((m, dim), dtype=np.float32)
+    queries = centres[rng.integers(0, 2000, nq)] + 0.7 * rng.standard_normal((nq, dim), dtype=np.float32)
     sim = 1
-    codes, corr, cen = B.quantize_vectors(base, sim)
-    ix = B.Index(codes, corr, dim, B.centroid_dp(cen), device=device)
+    ix, _, _, cen = B.Index.build(base, sim, device=device, want_host_copy=False)
     qs = [B.quantize_query(q, cen, sim, 4) for q in queries]
     qq, qc = np.stack([a for a, _ in qs]), np.stack([b for _, b in qs])
     idx, sc, cnt = ix.search_batch(qq, qc, 4, sim, k)
@@ -91,11 +94,21 @@ def recall_probe(B, device, n=200000, dim=768, nq=32, k=100):
     rerank_ms = (time.perf_counter() - t0) * 1e3 / nq
     dv.close()
     ix.close()
-    tb = torch.from_numpy(base).to("cuda:%d" % device)
-    tb = tb / tb.norm(dim=1, keepdim=True)
-    tq = torch.from_numpy(queries).to("cuda:%d" % device)
+    # fp32 brute force, in row blocks so that the normalised copy never doubles the footprint
+    dev = "cuda:%d" % device
+    tq = torch.from_numpy(queries).to(dev)
     tq = tq / tq.norm(dim=1, keepdim=True)
-    truth = (tq @ tb.T).topk(k, dim=1).indices.cpu().numpy()
+    best_s = torch.full((nq, k), -2.0, device=dev)
+    best_i = torch.zeros((nq, k), dtype=torch.int64, device=dev)
+    for i in range(0, n, 1_000_000):
+        tb = torch.from_numpy(base[i:i + 1_000_000]).to(dev)
+        tb = tb / tb.norm(dim=1, keepdim=True)
+        s_blk, i_blk = (tq @ tb.T).topk(min(k, tb.shape[0]), dim=1)
+        cat_s, cat_i = torch.cat([best_s, s_blk], 1), torch.cat([best_i, i_blk + i], 1)
+        best_s, pick = cat_s.topk(k, dim=1)
+        best_i = torch.gather(cat_i, 1, pick)
+        del tb
+    truth = best_i.cpu().numpy()
     rec = np.mean([len(set(truth[i].tolist()) & set(idx[i].tolist())) / float(k) for i in range(nq)])
     rec3 = np.mean([len(set(truth[i].tolist()) & set(ridx[i].tolist())) / float(k) for i in range(nq)])
     return float(rec), {"n": n, "dim": dim, "queries": nq, "data": "2000 gaussian clusters, sigma 0.7",
@@ -138,6 +151,7 @@ def main():
     ap.add_argument("--replay-threads", type=int, default=16, help="host threads replaying the reference heap")
     ap.add_argument("--pilot", type=int, default=32768, help="replicated pilot rows per non-root shard (multi-GPU)")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--recall-rows", type=int, default=1_000_000, help="rows of the fp32 recall probe (10000000 = the headline size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size oracle check of one timed query")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value")
@@ -321,7 +335,7 @@ def main():
             gi, gs, _ = results[args.warmup]
             out["parity_full_size"] = bool((gi[0] == oi).all() and (gs[0].view(np.uint32) == osc.view(np.uint32)).all())
         if not args.no_recall:
-            rec, desc = recall_probe(B, device)
+            rec, desc = recall_probe(B, device, n=args.recall_rows)
             out["recall_at_100"] = rec
             out["recall_config"] = desc
         print(json.dumps(out), flush=True)
