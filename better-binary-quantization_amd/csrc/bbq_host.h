@@ -35,7 +35,7 @@ struct DevMem {
 };
 
 constexpr int kMaxSlots = 4;
-constexpr int64_t kMaxFastK = 2048;  // beyond this the dense path is used (finalize LDS key buffer)
+constexpr int64_t kMaxFastK = 8192;  // beyond this the dense path is used (the finalize kernel keeps the running top-k keys in its 12288-key LDS buffer)
 
 struct Storage {
   uint8_t *d_tiles = nullptr;
