@@ -20,6 +20,8 @@ for o in sys.argv[2:]:
     a, b = o.split("=")
     if a == "only":
         sizes = (int(b),)
+    elif a == "k":
+        k = int(b)
     else:
         ix.set_option(a, int(b))
 qq, qc = bench.synth_queries(2, 64, dim, 4)
