@@ -144,9 +144,9 @@ def test_batch_pipeline_matches_oracle():
         ix.close()
 
 
-@pytest.mark.parametrize("k", [1, 2048, 2049, 3000, 8192, 8193, 25000, 70000])
+@pytest.mark.parametrize("k", [1, 2048, 2049, 3000, 4096, 4097, 25000, 70000])
 def test_k_edge_cases(k):
-    """large k on the sparse path (up to 8192), k beyond it (dense replay), k > N (clamped like src/binaryQuantizationFormat.ts:385)"""
+    """large k on the sparse path (up to 4096), k beyond it (dense replay), k > N (clamped like src/binaryQuantizationFormat.ts:385)"""
     rng = np.random.default_rng(6)
     n, dim = 50000, 64
     base = rng.standard_normal((n, dim)).astype(np.float32)
@@ -161,8 +161,8 @@ def test_k_edge_cases(k):
         assert len(idx) == min(k, n)
         np.testing.assert_array_equal(idx, oi)
         np.testing.assert_array_equal(sc.view(np.uint32), os_.view(np.uint32))
-        assert ix.stats()["dense_fallbacks"] == (1 if k > 8192 else 0)
-        if 1 < k <= 8192:   # the shared sweeps take the same k
+        assert ix.stats()["dense_fallbacks"] == (1 if k > 4096 else 0)
+        if 1 < k <= 4096:   # the shared sweeps take the same k
             for share in (8, 32):
                 ix.set_option("sweep_share", share)
                 idx2, sc2 = ix.search(qq, qc, 4, sim, k)
