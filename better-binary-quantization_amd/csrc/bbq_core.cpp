@@ -367,7 +367,7 @@ void fill_query(const bbq_index *ix, uint8_t *planes_dst, QueryParams *pp, const
 // g, half h, dword c, byte i the kernel extracts bit p = 4h + c + 8i of the little-endian word ((w >> (4h + c)) &
 // 0x01010101), which is row byte 4g + (p >> 3), bit (p & 7), i.e. dimension 32g + 8*(p >> 3) + 7 - (p & 7)
 // (MSB-first packing, src/optimizedScalarQuantizer.ts:420-446).  Layout: [group][g][h][n][16 B], n = query in its group of 32.
-void fill_query_mfma(const bbq_index *ix, uint8_t *dst, int q_in_batch, const uint8_t *q, bool preshift) {
+void fill_query_mfma(const bbq_index *ix, uint8_t *dst, int q_in_batch, const uint8_t *q) {
   const int words = ix->w16 * 4, group = q_in_batch / 32, n = q_in_batch % 32;
   uint8_t *gb = dst + (size_t)group * words * 2 * 32 * 16;
   for (int g = 0; g < words; ++g)
@@ -377,7 +377,7 @@ void fill_query_mfma(const bbq_index *ix, uint8_t *dst, int q_in_batch, const ui
         for (int i = 0; i < 4; ++i) {
           const int p = 4 * h + cc + 8 * i;
           const int d = 32 * g + 8 * (p >> 3) + 7 - (p & 7);
-          o[4 * cc + i] = d < ix->dim ? (uint8_t)(preshift ? q[d] << (3 - cc) : q[d]) : 0;
+          o[4 * cc + i] = d < ix->dim ? q[d] : 0;
         }
     }
 }
@@ -430,7 +430,7 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
     float *qm = reinterpret_cast<float *>(s.h_qbuf + off_qmax);
     for (int gidx = 0; gidx < groups; ++gidx) qm[4 * gidx] = qm[4 * gidx + 1] = qm[4 * gidx + 2] = qm[4 * gidx + 3] = 0.f;
     for (int i = 0; i < nq; ++i) {
-      fill_query_mfma(ix, s.h_qbuf + off_qbytes, i, c.qquant + (size_t)(q_first + i) * ix->dim, c.maxq <= 15);
+      fill_query_mfma(ix, s.h_qbuf + off_qbytes, i, c.qquant + (size_t)(q_first + i) * ix->dim);
       float *m = qm + 4 * (i / 32);
       // upper bounds (rounded up) of the group's |ay|, |ly|, y1, |qadd - cdp|
       m[0] = std::max(m[0], (float)(fabs(hq[i].ay) * 1.000001));
@@ -474,7 +474,7 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
     if (g.dominant) HIPCHK(hipEventRecord(s.ev0, st));
     const bool mfma_here = use_mfma && !g.dense && mfma_sweep_supported(a);
     if (mfma_here)
-      HIPCHK(launch_scan_mfma(a, s.d_qbuf + off_qbytes, reinterpret_cast<const float *>(s.d_qbuf + off_qmax), c.maxq <= 15, nq, (int)g.n_chunks, st));
+      HIPCHK(launch_scan_mfma(a, s.d_qbuf + off_qbytes, reinterpret_cast<const float *>(s.d_qbuf + off_qmax), nq, (int)g.n_chunks, st));
     else if (!g.dense && ix->opt_share > 1 && shared_sweep_supported(a, ix->opt_share))
       HIPCHK(launch_scan_shared(a, c.planes, ix->opt_share, nq, (int)g.n_chunks, st));
     else

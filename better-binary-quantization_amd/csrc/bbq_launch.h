@@ -12,9 +12,7 @@ bool shared_sweep_supported(const ScanArgs &a, int share);
 hipError_t launch_scan_shared(const ScanArgs &a, int planes, int share, int n_queries, int n_chunks, hipStream_t s);
 // shared sweep on the matrix cores: 32 queries per workgroup (bbq_mfma_kernels.hip); query values must be <= 127
 bool mfma_sweep_supported(const ScanArgs &a);
-// preshift (query values <= 15): qbytes hold q << (3 - dword index); the kernel then expands the code bits without shifts
-hipError_t launch_scan_mfma(const ScanArgs &a, const uint8_t *qbytes, const float *qmax, bool preshift, int n_queries, int n_chunks,
-                            hipStream_t s);
+hipError_t launch_scan_mfma(const ScanArgs &a, const uint8_t *qbytes, const float *qmax, int n_queries, int n_chunks, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, int n_queries, hipStream_t s);
 // lists are [nq][list_stride]; a query may hold more than advertised_cap entries (a flood): such queries are only dropped
 // (flagged) when the packed buffer cannot take the sum

@@ -94,7 +94,7 @@ struct MfmaArgs {
 // scored exactly afterwards by ONE copy of the exact code, 64 pairs at a time.
 constexpr int kMfmaQueueCap = 512;
 constexpr int kMfmaChunksPerBlock = 8;
-template <int W, bool COMPACT, bool PS>
+template <int W, bool COMPACT>
 __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const MfmaArgs a) {  // 4 waves per SIMD = 2 workgroups per CU: caps the allocation at 128 VGPRs
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT = kChunkRows;
@@ -166,7 +166,6 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
     const float cs = sim == 0 ? 2.0f : 1.0f;
     const float ayq = (float)p.ay, lyq = (float)p.ly, y1q = (float)p.y1;
     const float ayz = cs * ayq, lyz = cs * lyq;
-    const float lyq_s = PS ? lyq * 0.125f : lyq, y1q_s = PS ? y1q * 8.0f : y1q;
     const float *__restrict__ gm = a.qmax + (size_t)group * 4;
     const float AYmax = gm[0], LYmax = gm[1], Y1max = gm[2];
 
@@ -223,7 +222,7 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
       // non-finite or huge rows: force a pass (an infinite slack makes every compare below fail to reject)
       const bool weird = !(fabs(R1) + fabs(al) + fabs(lx) + fabs(aadd) < 1e30);
       const float slack32 = weird ? __uint_as_float(0x7f800000u) : (float)slack * 1.001f + 1e-30f;
-      k1.x = PS ? (float)lx * 0.125f : (float)lx; k1.y = (float)(ca_d * aadd) + slack32; k1.z = (float)(cs_d * ea * 1.001); k1.w = (float)(cs_d * eu * 1.001);
+      k1.x = (float)lx; k1.y = (float)(ca_d * aadd) + slack32; k1.z = (float)(cs_d * ea * 1.001); k1.w = (float)(cs_d * eu * 1.001);
       // (float)(ca*aadd) + slack32 rounds once more: one extra ulp of |ca*aadd| is inside the 1.001 factors of slack (eadd part)
       f32x4m *dst = s_row + ((size_t)wave * 64 + lane) * 2;
       dst[0] = k0; dst[1] = k1;
@@ -247,15 +246,8 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
         // this half supplies 16 of the word's 32 dims: bits 4h+c+8i -> byte i of dword c (one shift + one AND per dword;
         // the host lays the query bytes out in the same order, fill_query_mfma)
         i32x4m A;
-        if constexpr (PS) {
-          // pre-shifted queries (values <= 15): bit c of a nibble stays where it is (byte value 2^c) and the host stores
-          // q << (3 - c) in dword c, so every product is 8 * bit * q and the three shifts per word disappear; acc = 8 * qcDist
-          A.x = (int)(aw & 0x01010101u); A.y = (int)(aw & 0x02020202u);
-          A.z = (int)(aw & 0x04040404u); A.w = (int)(aw & 0x08080808u);
-        } else {
-          A.x = (int)(aw & 0x01010101u); A.y = (int)((aw >> 1) & 0x01010101u);
-          A.z = (int)((aw >> 2) & 0x01010101u); A.w = (int)((aw >> 3) & 0x01010101u);
-        }
+        A.x = (int)(aw & 0x01010101u); A.y = (int)((aw >> 1) & 0x01010101u);
+        A.z = (int)((aw >> 2) & 0x01010101u); A.w = (int)((aw >> 3) & 0x01010101u);
         const u32x4m bq = s_B[(g * 2 + h) * 32 + n + lds_off];
         i32x4m Bf;
         Bf.x = (int)bq.x; Bf.y = (int)bq.y; Bf.z = (int)bq.z; Bf.w = (int)bq.w;
@@ -265,16 +257,14 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rit = 32 * rg + (r & 3) + 8 * (r >> 2) + 4 * h;  // row in tile
-        const int qc = PS ? (acc[r] >> 3) : acc[r];
+        const int qc = acc[r];
         const f32x4m *__restrict__ rc = s_row + ((size_t)wave * 64 + rit) * 2;
         const f32x4m k0 = rc[0], k1 = rc[1];
-        // PS: qcf is 8*qc; lx (k1.x) and ly (lyq_s) were divided by 8 and y1 (y1q_s) multiplied by 8 when they were staged -
-        // powers of two, so every product below has exactly the value (and rounding) of the unscaled form
-        const float qcf = (float)acc[r];
+        const float qcf = (float)qc;
         const float u = fmaf(k1.x, qcf, k0.w * y1q);                 // al*y1 + lx*qc
         const float z = fmaf(lyz, u, fmaf(ayz, k0.x, k1.y));         // cs*(ay*R1 + ly*u) + ca*add + slack
-        const float Ae = fmaf(lyq_s, y1q_s - qcf, ayq * k0.y);       // ay*(D-x1) + ly*(y1-qc)
-        const float Be = fmaf(lyq_s, qcf, ayq * k0.z);               // ay*x1 + ly*qc
+        const float Ae = fmaf(lyq, y1q - qcf, ayq * k0.y);           // ay*(D-x1) + ly*(y1-qc)
+        const float Be = fmaf(lyq, qcf, ayq * k0.z);                 // ay*x1 + ly*qc
         const float zu = fmaf(fabsf(Ae), k1.z, fmaf(fabsf(Be), k1.w, z));
         const bool pass = have_q && rit < rows_here && !(zu <= (zth - zth_margin));  // NaN / inf anywhere => pass
         if (pass) {
@@ -339,14 +329,14 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
 
 // ---------------------------------------------------------------------------------------------------------------------
 
-template <int W, bool COMPACT, bool PS>
+template <int W, bool COMPACT>
 static hipError_t launch_mfma_t(const MfmaArgs &a, int nq, int nc, hipStream_t s) {
   constexpr int NW = kChunkRows / 64;
   const size_t smem = (size_t)W * 4 * 2 * 32 * 16 + (size_t)NW * 64 * 2 * 16 + (size_t)NW * kMfmaQueueCap * 4 + 32 +
                       kMfmaQueries * (sizeof(QueryParams) + 8 + 4 + 4) + (size_t)kMfmaQueries * a.s.cap * 8 + 64;
   dim3 grid((unsigned)((nc + kMfmaChunksPerBlock - 1) / kMfmaChunksPerBlock), (unsigned)((nq + kMfmaQueries - 1) / kMfmaQueries), 1),
       block(kChunkRows, 1, 1);
-  auto kern = bbq_scan_mfma_kernel<W, COMPACT, PS>;
+  auto kern = bbq_scan_mfma_kernel<W, COMPACT>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
@@ -362,23 +352,15 @@ bool mfma_sweep_supported(const ScanArgs &a) {
   return smem <= 150 * 1024;
 }
 
-template <int W>
-static hipError_t launch_mfma_w(const MfmaArgs &a, bool compact, bool preshift, int nq, int nc, hipStream_t s) {
-  if (compact) return preshift ? launch_mfma_t<W, true, true>(a, nq, nc, s) : launch_mfma_t<W, true, false>(a, nq, nc, s);
-  return preshift ? launch_mfma_t<W, false, true>(a, nq, nc, s) : launch_mfma_t<W, false, false>(a, nq, nc, s);
-}
-
-// preshift: the query bytes were stored as q << (3 - dword index) (values <= 15 only), see fill_query_mfma
-hipError_t launch_scan_mfma(const ScanArgs &sa, const uint8_t *qbytes, const float *qmax, bool preshift, int n_queries, int n_chunks,
-                            hipStream_t s) {
+hipError_t launch_scan_mfma(const ScanArgs &sa, const uint8_t *qbytes, const float *qmax, int n_queries, int n_chunks, hipStream_t s) {
   if (n_chunks <= 0 || n_queries <= 0) return hipSuccess;
   MfmaArgs a{sa, qbytes, qmax, n_queries};
   const bool compact = sa.idx.layout == kLayoutCompact;
   switch (sa.idx.w16) {
-    case 1: return launch_mfma_w<1>(a, compact, preshift, n_queries, n_chunks, s);
-    case 6: return launch_mfma_w<6>(a, compact, preshift, n_queries, n_chunks, s);
-    case 8: return launch_mfma_w<8>(a, compact, preshift, n_queries, n_chunks, s);
-    case 12: return launch_mfma_w<12>(a, compact, preshift, n_queries, n_chunks, s);
+    case 1: return compact ? launch_mfma_t<1, true>(a, n_queries, n_chunks, s) : launch_mfma_t<1, false>(a, n_queries, n_chunks, s);
+    case 6: return compact ? launch_mfma_t<6, true>(a, n_queries, n_chunks, s) : launch_mfma_t<6, false>(a, n_queries, n_chunks, s);
+    case 8: return compact ? launch_mfma_t<8, true>(a, n_queries, n_chunks, s) : launch_mfma_t<8, false>(a, n_queries, n_chunks, s);
+    case 12: return compact ? launch_mfma_t<12, true>(a, n_queries, n_chunks, s) : launch_mfma_t<12, false>(a, n_queries, n_chunks, s);
     default: return hipErrorInvalidValue;
   }
 }
