@@ -7,7 +7,8 @@ Per batch of queries every rank sweeps its shard and packs its candidates; the r
   3. all_gather  packed[:max total over ranks >= 1]      (the only sizeable message: ~2K entries x 8 B per query and rank)
 and rank 0 replays the reference heap over (own list, rank 1's, rank 2's, ...) in global row order.  Rank 0's own list
 (which carries the dense first segment) never travels.  A scanner thread keeps the GPU sweeping batch i+1 while the
-main thread gathers and replays batch i.
+main thread gathers and replays batch i.  Queries some shard could not bound (flags) are scored densely by every rank, one
+by one; the rest of their batch stays on the sparse path.
 """
 import queue
 import threading
@@ -76,8 +77,12 @@ class ShardedSearcher:
         meta = t.tensor([total, any_flag], dtype=t.int64, device=self.cdev)
         dist.all_gather_into_tensor(self.g_meta, meta)
         m = self.g_meta.cpu().numpy().reshape(self.world, 2)
+        flagged = []
         if m[:, 1].any():
-            return self._merge_dense(nq, qq, qc)
+            # some shard could not bound some query: find out WHICH queries (the rest of the batch stays on the sparse path)
+            gf = t.zeros(self.world * nq, dtype=t.int32, device=self.cdev)
+            dist.all_gather_into_tensor(gf, buf["flags"][:nq].to(self.cdev).contiguous())
+            flagged = np.nonzero(gf.cpu().numpy().reshape(self.world, nq).any(axis=0))[0].tolist()
         go = self.g_offsets[:self.world * (nq + 1)]
         dist.all_gather_into_tensor(go, buf["offsets"][:nq + 1].to(self.cdev).contiguous())
         maxtot = int(m[1:, 0].max()) if self.world > 1 else 0
@@ -85,35 +90,35 @@ class ShardedSearcher:
         if maxtot > 0:
             gp = self.g_packed[:self.world * maxtot]
             dist.all_gather_into_tensor(gp, buf["packed"][:maxtot].to(self.cdev).contiguous())
-        if self.rank != 0:
-            return None
-        h_off = go.cpu().numpy().reshape(self.world, nq + 1)
-        packed = [self._to_host(self.h_own, buf["packed"][:int(m[0, 0])]).view(np.uint64)]
-        offsets = [h_off[0]]
-        if self.world > 1 and maxtot > 0:
-            h_p = self._to_host(self.h_packed, gp).view(np.uint64).reshape(self.world, maxtot)
-            for r in range(1, self.world):
-                packed.append(h_p[r, :int(m[r, 0])])
-                offsets.append(h_off[r])
-        elif self.world > 1:
-            for r in range(1, self.world):
-                packed.append(np.zeros(0, np.uint64))
-                offsets.append(h_off[r])
-        return capi.replay_batch(packed, offsets, nq, self.n_total, self.k, self.threads)
+        res = None
+        if self.rank == 0:
+            h_off = go.cpu().numpy().reshape(self.world, nq + 1)
+            packed = [self._to_host(self.h_own, buf["packed"][:int(m[0, 0])]).view(np.uint64)]
+            offsets = [h_off[0]]
+            if self.world > 1 and maxtot > 0:
+                h_p = self._to_host(self.h_packed, gp).view(np.uint64).reshape(self.world, maxtot)
+                for r in range(1, self.world):
+                    packed.append(h_p[r, :int(m[r, 0])])
+                    offsets.append(h_off[r])
+            elif self.world > 1:
+                for r in range(1, self.world):
+                    packed.append(np.zeros(0, np.uint64))
+                    offsets.append(h_off[r])
+            res = capi.replay_batch(packed, offsets, nq, self.n_total, self.k, self.threads)
+        if flagged:   # collective: every rank takes part; rank 0 overwrites those queries' rows
+            self._merge_dense(flagged, qq, qc, res)
+        return res
 
-    def _merge_dense(self, nq, qq, qc):
-        """a shard could not bound some query (NaN scores / candidate overflow): every rank scores all its rows for
-        the whole batch, rank 0 replays every row - slow, exact, rare"""
+    def _merge_dense(self, which, qq, qc, res):
+        """a shard could not bound these queries (NaN scores / a flood beyond every buffer): every rank scores all its rows
+        for them, rank 0 replays every row into `res` - slow, exact, rare"""
         t, dist = self.torch, self.dist
         rows = t.tensor([self.index.n if self.index is not None else self._dense_rows], dtype=t.int64, device=self.cdev)
         allrows = t.zeros(self.world, dtype=t.int64, device=self.cdev)
         dist.all_gather_into_tensor(allrows, rows)
         allrows = allrows.cpu().numpy()
         mx = int(allrows.max())
-        idx = np.zeros((nq, self.k), np.int32)
-        sc = np.zeros((nq, self.k), np.float32)
-        cnt = np.zeros(nq, np.int64)
-        for q in range(nq):
+        for q in which:
             if self._dense_fn is not None:
                 s32 = self._dense_fn(qq[q], qc[q])
             else:
@@ -123,12 +128,12 @@ class ShardedSearcher:
             everyone = t.zeros(self.world * mx, dtype=t.float32, device=self.cdev)
             dist.all_gather_into_tensor(everyone, mine)
             if self.rank == 0:
+                idx, sc, cnt = res
                 e = everyone.cpu().numpy().reshape(self.world, mx)
                 s_all = np.concatenate([e[r, :int(allrows[r])] for r in range(self.world)])
                 ent = (np.arange(len(s_all), dtype=np.uint64) << np.uint64(32)) | s_all.view(np.uint32).astype(np.uint64)
                 i1, s1 = capi.replay([ent], self.n_total, self.k)
                 idx[q, :len(i1)], sc[q, :len(i1)], cnt[q] = i1, s1, len(i1)
-        return (idx, sc, cnt) if self.rank == 0 else None
 
     # ------------------------------------------------------------------ public
     def search(self, qq, qc):
