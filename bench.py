@@ -144,7 +144,7 @@ def main():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--batch", type=int, default=0,
-                    help="queries per step (each sweeps the index on its own); default 256, 512 when sharded (amortises the per-call pipeline drain over smaller shards)")
+                    help="queries per step (each sweeps the index on its own); default 256 on one GPU, 256 x world (512..2048) when sharded")
     ap.add_argument("--sim", default="COSINE", choices=["EUCLIDEAN", "COSINE", "MAXIMUM_INNER_PRODUCT"])
     ap.add_argument("--query-bits", type=int, default=4)
     ap.add_argument("--sub-batch", type=int, default=32, help="queries per device launch sequence (pipelined inside a step)")
@@ -190,7 +190,9 @@ def main():
     torch.cuda.set_device(device)
 
     if args.batch <= 0:
-        args.batch = 256 if world == 1 else 512
+        # sharded: every rank sweeps only 1/world of the rows per query, so the batch grows with the world to keep the sweep of one
+        # batch (and with it the share of the per-batch exchange and pipeline drain) what it is on one GPU
+        args.batch = 256 if world == 1 else min(2048, max(512, 256 * world))
     N, dim, k, Q = args.rows, args.dim, args.k, args.batch
     SIM = {"EUCLIDEAN": 0, "COSINE": 1, "MAXIMUM_INNER_PRODUCT": 2}[args.sim]
     QB = args.query_bits
