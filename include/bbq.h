@@ -118,7 +118,8 @@ int32_t bbq_index_bytes_per_row(const bbq_index *idx);
  *   qcorr    [4]     query corrections
  *   query_bits       1 selects the 1-bit formulas, anything else the "4-bit" formulas
  *   out_idx/out_score [k]  (only min(k, size) entries are written); *out_n = number written
- * k == 0 -> *out_n = 0.  k < 0 -> BBQ_ERR_NEGATIVE_K.
+ * k == 0 -> *out_n = 0.  k < 0 -> BBQ_ERR_NEGATIVE_K.  k > 4096 is answered by the dense path (every f32 score to the
+ * host; 16 ms per 10 M-row query instead of 0.15-4 ms).
  */
 int bbq_search(bbq_index *idx, const uint8_t *qquant, const double *qcorr, int32_t query_bits, int32_t sim,
                int64_t k, int32_t *out_idx, float *out_score, int64_t *out_n);
@@ -147,15 +148,19 @@ int bbq_score_rows(bbq_index *idx, const uint8_t *qquant, const double *qcorr, i
  *   dev_packed   device pointer, [packed_cap] bbq_cand; query q's entries at [offsets[q], offsets[q+1])
  *   dev_offsets  device pointer, [n_queries + 1] int64
  *   dev_flags    device pointer, [n_queries] int32; non-zero: this shard could not bound the query
- *                (candidate overflow / NaN score) - it carries no entries and the query must be scored densely
+ *                (NaN score / more candidates than every buffer holds) - it carries no entries and the query must be
+ *                scored densely
  *   *out_total   (host) number of entries written = offsets[n_queries]
+ *   k            1..4096
  * The call returns after the device work has completed (buffers are ready for a collective).
- * BBQ_ERR_OOM if the entries do not fit packed_cap.
+ * A query may leave more than bbq_shard_list_cap entries (a flood: rows stored cluster by cluster); as long as the sum over
+ * the batch fits packed_cap nothing is dropped, otherwise the flooded queries are flagged.  BBQ_ERR_OOM only if packed_cap is
+ * smaller than n_queries x bbq_shard_list_cap and the entries still do not fit.
  */
 int bbq_shard_scan(bbq_index *idx, int32_t n_queries, const uint8_t *qquant, const double *qcorr,
                    int32_t query_bits, int32_t sim, int64_t k, void *dev_packed, int64_t packed_cap,
                    void *dev_offsets, void *dev_flags, int64_t *out_total);
-/* upper estimate of the entries ONE query leaves on this shard (use n_queries x this for packed_cap) */
+/* planned entries ONE query leaves on this shard, with a 4x margin (use n_queries x this for packed_cap) */
 int64_t bbq_shard_list_cap(const bbq_index *idx, int64_t k);
 
 /* Host-only (no device needed): exact replay of the reference heap over candidate lists.
@@ -261,7 +266,10 @@ typedef struct {
 } bbq_stats;
 int bbq_get_stats(bbq_index *idx, bbq_stats *out);
 int bbq_reset_stats(bbq_index *idx);
-/* tuning knobs; returns BBQ_ERR_INVALID_ARG for unknown names.  See DESIGN.md "Knobs". */
+/* tuning knobs; returns BBQ_ERR_INVALID_ARG for unknown names or values out of range (DESIGN.md "Knobs"):
+ *   batch_queries 1..1024 (32)   pipeline_slots 1..4 (2)   segment_growth 2..1024 (8)   first_segment_rows 1024..8192 (4096)
+ *   replay_threads 1..256 (half the host cores, at most 8)   flood_rows 0..2^24 (262144)   force_dense 0|1 (0)
+ *   sweep_share 1|4|8|32 (1: every query sweeps the index itself; 32: shared sweep on the matrix cores) */
 int bbq_set_option(bbq_index *idx, const char *name, int64_t value);
 
 #ifdef __cplusplus
