@@ -97,7 +97,6 @@ int get_ctx(int device, DeviceCtx **out) {
       HIPCHK(hipEventCreate(&c->slots[i].ev1));
       HIPCHK(hipEventCreateWithFlags(&c->slots[i].ev_done, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&c->slots[i].ev_big, hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&c->slots[i].ev_early, hipEventDisableTiming));
     }
     HIPCHK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void **)&c->d_aux_flags, 4));
@@ -259,10 +258,6 @@ void free_slot_buffers(Slot &s) {
   if (s.d_counts) (void)hipFree(s.d_counts);
   if (s.d_topk) (void)hipFree(s.d_topk);
   if (s.h_list_counts) (void)hipHostFree(s.h_list_counts);
-  if (s.h_early_counts) (void)hipHostFree(s.h_early_counts);
-  if (s.h_early_lists) (void)hipHostFree(s.h_early_lists);
-  s.h_early_counts = nullptr;
-  s.h_early_lists = nullptr;
   if (s.d_entries) (void)hipFree(s.d_entries);
   if (s.d_lists) (void)hipFree(s.d_lists);
   if (s.h_lists) (void)hipHostFree(s.h_lists);
@@ -316,8 +311,6 @@ int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
   if (own_lists) {
     HIPCHK(hipMalloc((void **)&s.d_lists, (size_t)(Q * s.list_cap) * 8));
     HIPCHK(hipHostMalloc((void **)&s.h_lists, (size_t)(Q * s.hprefix) * 8, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&s.h_early_lists, (size_t)(Q * s.hprefix) * 8, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&s.h_early_counts, (size_t)Q * 8, hipHostMallocDefault));
   }
   s.q_cap = Q;
   return BBQ_OK;
@@ -415,7 +408,7 @@ struct BatchCtx {
 };
 
 int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64_t *d_lists_ext, int64_t list_cap_ext,
-                     int32_t *d_counts_ext, bool early = false) {
+                     int32_t *d_counts_ext) {
   bbq_index *ix = c.ix;
   const Plan &p = ix->plan;
   const int64_t qb = (int64_t)ix->w16 * c.planes * 16;
@@ -455,9 +448,6 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
   if (d_counts_ext) HIPCHK(hipMemsetAsync(d_counts_ext, 0, (size_t)nq * 8, st));
 
   s.timed = false;
-  s.early_armed = false;
-  s.early_used.clear();  // early state only exists once early_replay has run for THIS sub-batch
-  size_t seg_no = 0;
   for (const Segment &g : p.segs) {
     const Storage &sto = g.storage == 0 ? ix->pilot : ix->main;
     ScanArgs a{};
@@ -523,14 +513,6 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
     f.k = (int32_t)c.k;
     f.need_theta = g.need_theta ? 1 : 0;
     HIPCHK(launch_finalize(f, nq, st));
-    if (early && !d_lists_ext && p.segs.size() >= 2 && ++seg_no == p.segs.size() - 1) {
-      // everything before the last segment is final: hand it to the host now (two small copies ahead of the big sweep)
-      HIPCHK(hipMemcpyAsync(s.h_early_counts, s.d_list_counts, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipMemcpy2DAsync(s.h_early_lists, (size_t)s.hprefix * 8, s.d_lists, (size_t)s.list_cap * 8, (size_t)s.hprefix * 8, (size_t)nq,
-                              hipMemcpyDeviceToHost, st));
-      HIPCHK(hipEventRecord(s.ev_early, st));
-      s.early_armed = true;
-    }
   }
   if (!d_lists_ext) {
     HIPCHK(hipMemcpyAsync(s.h_list_counts, s.d_list_counts, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
@@ -600,33 +582,6 @@ int dense_search_one(const BatchCtx &c, int64_t qi, int32_t *out_idx, float *out
 }
 
 // device work of the slot's sub-batch is done: collect it and start the heap replays (on the pool when replay_threads > 1)
-// replays, on the calling thread, what the lists held before the last segment while that segment is still being swept
-int early_replay(const BatchCtx &c, Slot &s) {
-  if (!s.early_armed || !s.busy) return BBQ_OK;
-  bbq_index *ix = c.ix;
-  HIPCHK(hipEventSynchronize(s.ev_early));
-  const int64_t n_total = ix->main.row_id_base + ix->main.view.n_rows;
-  s.early_heaps.clear();
-  s.early_used.assign((size_t)s.nq, -1);
-  s.early_heaps.reserve((size_t)s.nq);
-  for (int i = 0; i < s.nq; ++i) {
-    s.early_heaps.emplace_back(c.k, n_total);
-    const int32_t cnt = s.h_early_counts[2 * i], flags = s.h_early_counts[2 * i + 1];
-    if (flags != 0) continue;
-    const int64_t head = std::min<int64_t>(cnt, s.hprefix);
-    const uint64_t *l = s.h_early_lists + (size_t)i * s.hprefix;
-    HeapReplay &hr = s.early_heaps.back();
-    for (int64_t j = 0; j < head; ++j) {
-      const uint32_t bits = (uint32_t)l[j];
-      float sc;
-      memcpy(&sc, &bits, 4);
-      hr.offer(sc, (int32_t)(uint32_t)(l[j] >> 32));
-    }
-    s.early_used[(size_t)i] = head;
-  }
-  return BBQ_OK;
-}
-
 int begin_replay(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score, int64_t *out_n) {
   bbq_index *ix = c.ix;
   HIPCHK(hipEventSynchronize(s.ev_done));
@@ -651,12 +606,10 @@ int begin_replay(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score,
     for (int i = lo; i < hi; ++i) {
       const int32_t cnt = s.h_list_counts[2 * i], flags = s.h_list_counts[2 * i + 1];
       if (flags != 0) continue;
-      const bool resumed = s.early_armed && (size_t)i < s.early_used.size() && s.early_used[(size_t)i] >= 0;
-      HeapReplay fresh(k, n_total);
-      HeapReplay &hr = resumed ? s.early_heaps[(size_t)i] : fresh;   // lists only grow: the replayed prefix is final
+      HeapReplay hr(k, n_total);
       const uint64_t *l = s.h_lists + (size_t)i * s.hprefix;
       const int64_t head = std::min<int64_t>(cnt, s.hprefix);
-      for (int64_t j = resumed ? s.early_used[(size_t)i] : 0; j < head; ++j) {
+      for (int64_t j = 0; j < head; ++j) {
         const uint32_t bits = (uint32_t)l[j];
         float sc;
         memcpy(&sc, &bits, 4);
@@ -919,7 +872,7 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
     const int nq = (int)std::min<int64_t>(Q, n_queries - i * Q);
     rc = ensure_slot(ix, s, nq, true);
     if (rc != BBQ_OK) return fail_out(rc);
-    rc = enqueue_subbatch(cs, s, i * Q, nq, nullptr, 0, nullptr, /*early=*/i == nsub - 1);
+    rc = enqueue_subbatch(cs, s, i * Q, nq, nullptr, 0, nullptr);
     if (rc != BBQ_OK) return fail_out(rc);
     // hand finished sub-batches to the replay workers as early as possible (their slot is needed again soon)
     for (int j = 0; j < nslots; ++j) {
@@ -931,10 +884,6 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
     }
   }
   for (int64_t i = std::max<int64_t>(0, nsub - nslots); i < nsub; ++i) {  // oldest first
-    if (i == nsub - 1) {  // nothing else to do for this thread: replay the last sub-batch's early segments while its big sweep runs
-      rc = early_replay(c, ix->slots[i % nslots]);
-      if (rc != BBQ_OK) return fail_out(rc);
-    }
     rc = reclaim_slot(c, ix->slots[i % nslots], out_idx, out_score, out_n);
     if (rc != BBQ_OK) return fail_out(rc);
   }

@@ -65,20 +65,13 @@ struct Plan {
 
 struct Slot {
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr, ev_big = nullptr, ev_early = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr, ev_big = nullptr;
   // capacities the buffers below were allocated for
   int q_cap = 0;
   int64_t qbuf_bytes = 0, chunks_cap = 0, slots_cap = 0, dense_cap = 0, list_cap = 0, k_cap = 0, hprefix = 0, flood_cap = 0;
   uint8_t *d_qbuf = nullptr, *h_qbuf = nullptr;
   uint32_t *d_theta = nullptr, *d_flags = nullptr, *d_counts = nullptr, *d_topk = nullptr;
   int32_t *d_topk_counts = nullptr, *d_list_counts = nullptr, *h_list_counts = nullptr;
-  // early replay (the last sub-batch of a call): counts + list prefix as they stand BEFORE the last, largest segment; the
-  // host replays them while that sweep still runs and continues from there when it is done
-  int32_t *h_early_counts = nullptr;
-  uint64_t *h_early_lists = nullptr;
-  bool early_armed = false;
-  std::vector<HeapReplay> early_heaps;
-  std::vector<int64_t> early_used;  // entries of the query's list already replayed (-1: no early state)
   uint64_t *d_entries = nullptr, *d_lists = nullptr, *h_lists = nullptr, *d_ovf = nullptr;
   uint32_t *d_ovf_counts = nullptr;
   float *d_dense0 = nullptr;
