@@ -28,3 +28,13 @@ def test_js_reference_suite():
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-4000:]
     assert "0 failures" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_js_quickstart_example():
+    """examples/quickstart.js = the reference README's basic usage, unchanged except for the import"""
+    r = subprocess.run(["node", os.path.join(ROOT, "examples", "quickstart.js")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=300)
+    print(r.stdout[-2000:])
+    assert r.returncode == 0, r.stdout[-4000:]
