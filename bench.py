@@ -177,6 +177,9 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         if args.same_device:
             local = 0
+        ndev = torch.cuda.device_count()
+        if ndev > 0:
+            local %= ndev   # a launcher that narrows the visible devices per rank leaves each rank with device 0
         torch.cuda.set_device(local)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
