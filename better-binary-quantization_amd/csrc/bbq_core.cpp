@@ -246,7 +246,10 @@ void build_plan(bbq_index *ix, int64_t k) {
   if (sparse < 0) sparse = 0;
   p.list_cap = dense_rows + (int64_t)(4.0 * sparse) + 4096;
   p.list_cap = (p.list_cap + 1023) / 1024 * 1024;
+  // per query; bounded so that the overflow areas of one pipeline slot stay within 512 MB however many queries a sub-batch has
   p.flood_cap = std::min<int64_t>(ix->opt_flood, (ix->main.view.n_rows + 1023) / 1024 * 1024);
+  if (p.flood_cap > 0)
+    p.flood_cap = std::min<int64_t>(p.flood_cap, std::max<int64_t>(16384, ((64ll << 20) / std::max(32, ix->opt_batch)) / 1024 * 1024));
 }
 
 // ------------------------------------------------------------------------------------------------ slots
