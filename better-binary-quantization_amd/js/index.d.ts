@@ -52,6 +52,17 @@ export interface SiftDataset { vectors: SiftVector[]; count: number; dimension: 
 export declare function loadSiftVectors(filePath: string, maxVectors?: number): SiftDataset;
 export declare function loadSiftDataset(datasetDir: string, fileType?: 'base' | 'learn' | 'query', maxVectors?: number): SiftDataset;
 export declare function loadSiftQueries(datasetDir: string, maxQueries?: number): { queries: SiftVector[]; groundtruth: number[][] };
+export declare function normalizeVector(vector: Float32Array): Float32Array;
+export declare function computeCentroid(vectors: Float32Array[]): Float32Array;
+export declare function computeDotProduct(a: Float32Array, b: Float32Array): number;
+export declare function computeEuclideanDistance(a: Float32Array, b: Float32Array): number;
+export declare function computeEuclideanSimilarity(a: Float32Array, b: Float32Array): number;
+export declare function computeCosineSimilarity(a: Float32Array, b: Float32Array): number;
+export declare function computeMaximumInnerProduct(a: Float32Array, b: Float32Array): number;
+export declare function computeSimilarity(a: Float32Array, b: Float32Array, similarityFunction: 'EUCLIDEAN' | 'COSINE' | 'MAXIMUM_INNER_PRODUCT'): number;
+export declare function computeQuantizedDotProduct(q: Uint8Array, d: Uint8Array): number;
+export declare function computeInt4BitDotProduct(q: Uint8Array, d: Uint8Array): number;
+export declare function computeInt1BitDotProduct(q: Uint8Array, d: Uint8Array): number;
 export interface TopKCandidate { index: number; quantizedScore: number; trueScore: number; }
 /** the original fp32 vectors resident on the GPU; accepted wherever the selectors take `vectors` */
 export declare class DeviceVectors {

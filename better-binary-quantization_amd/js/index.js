@@ -363,6 +363,69 @@ function computeCosineSimilarity(a, b) {
   return dp / (Math.sqrt(na) * Math.sqrt(nb));
 }
 
+// ------------------------------------------------------------------ small host helpers the reference also exports
+// (src/vectorOperations.ts, src/vectorSimilarity.ts, src/bitwiseDotProduct.ts): same names, messages and number model
+// (Float32Array stores round to f32, everything else is f64)
+
+/** normalizeVector, src/vectorOperations.ts:11-34: f64 norm, f32 result; the zero vector stays zero */
+function normalizeVector(vector) {
+  let norm = 0;
+  for (let i = 0; i < vector.length; i++) norm += vector[i] * vector[i];
+  norm = Math.sqrt(norm);
+  const out = new Float32Array(vector.length);
+  if (norm === 0) return out;
+  for (let i = 0; i < vector.length; i++) out[i] = vector[i] / norm;
+  return out;
+}
+/** computeCentroid, src/vectorOperations.ts:126-163: the accumulator is a Float32Array (rounded after every += and the final /=) */
+function computeCentroid(vectors) {
+  if (vectors.length === 0) throw new Error('向量集合不能为空');
+  if (!vectors[0]) throw new Error('第一个向量不能为空');
+  const dim = vectors[0].length, centroid = new Float32Array(dim);
+  for (let i = 0; i < dim; i++) centroid[i] = vectors[0][i];
+  for (let j = 1; j < vectors.length; j++) { const v = vectors[j]; if (v) for (let i = 0; i < dim; i++) if (v[i] !== undefined) centroid[i] += v[i]; }
+  for (let i = 0; i < dim; i++) centroid[i] /= vectors.length;
+  return centroid;
+}
+/** computeDotProduct, src/vectorOperations.ts:171-185 */
+function computeDotProduct(a, b) {
+  if (a.length !== b.length) throw new Error('向量维度不匹配');
+  let sum = 0;
+  for (let i = 0; i < a.length; i++) sum += a[i] * b[i];
+  return sum;
+}
+/** computeEuclideanDistance / computeEuclideanSimilarity, src/vectorSimilarity.ts:38-70 */
+function computeEuclideanDistance(a, b) {
+  if (!a || !b) throw new Error('向量不能为空');
+  if (a.length !== b.length) throw new Error('向量维度不匹配');
+  let sum = 0;
+  for (let i = 0; i < a.length; i++) { const d = a[i] - b[i]; sum += d * d; }
+  return Math.sqrt(sum);
+}
+function computeEuclideanSimilarity(a, b) { return 1.0 / (1.0 + computeEuclideanDistance(a, b)); }
+/** computeMaximumInnerProduct, src/vectorSimilarity.ts:108-118 */
+function computeMaximumInnerProduct(a, b) {
+  let dp = 0;
+  for (let i = 0; i < a.length; i++) if (b[i] !== undefined) dp += a[i] * b[i];
+  return dp;
+}
+/** computeSimilarity, src/vectorSimilarity.ts:14-30 */
+function computeSimilarity(a, b, similarityFunction) {
+  switch (similarityFunction) {
+    case 'EUCLIDEAN': return computeEuclideanSimilarity(a, b);
+    case 'COSINE': return computeCosineSimilarity(a, b);
+    case 'MAXIMUM_INNER_PRODUCT': return computeMaximumInnerProduct(a, b);
+    default: throw new Error('不支持的相似性函数: ' + similarityFunction);
+  }
+}
+/** computeQuantizedDotProduct (= computeInt4BitDotProduct = computeInt1BitDotProduct), src/bitwiseDotProduct.ts:14-55 */
+function computeQuantizedDotProduct(q, d) {
+  if (q.length !== d.length) throw new Error('向量长度不匹配：查询向量长度' + q.length + '，索引向量长度' + d.length);
+  let sum = 0;
+  for (let i = 0; i < q.length; i++) sum += q[i] * d[i];
+  return sum;
+}
+
 /**
  * The original fp32 vectors resident on the GPU (libbbq bbq_vectors_*).  Pass it wherever the reference's selectors
  * take `vectors: Float32Array[]`: the per-candidate computeCosineSimilarity then runs on the device
@@ -525,6 +588,8 @@ module.exports = {
   createBinaryQuantizationFormat, quickQuantize, quickSearch,
   getOversampledTopKWithHeap, getOversampledTopKWithSort, getOversampledTopKBatch, computeCosineSimilarity,
   DeviceVectors, createDeviceVectors, loadSiftVectors, loadSiftDataset, loadSiftQueries,
+  normalizeVector, computeCentroid, computeDotProduct, computeEuclideanDistance, computeEuclideanSimilarity, computeMaximumInnerProduct,
+  computeSimilarity, computeQuantizedDotProduct, computeInt4BitDotProduct: computeQuantizedDotProduct, computeInt1BitDotProduct: computeQuantizedDotProduct,
   deviceCount: native.deviceCount,
   _native: native,
 };

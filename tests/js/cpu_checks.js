@@ -123,4 +123,27 @@ T.check(packed[0] === 0xAA, 'packAsBinary');
   try { bbq.loadSiftVectors(path.join(dir, 'bad.fvecs')); } catch (e) { msg = e.message; }
   T.check(msg.indexOf('向量维度不一致') >= 0, 'inconsistent record dimension');
 })();
+// host helpers the reference exports too: against the rerank fixtures (computeSimilarity of every pair) and known answers
+(function () {
+  const g = T.loadGolden('rerank_3d');
+  const fb = T.dec(g.base_f32, Float32Array), fq = T.dec(g.queries_f32, Float32Array);
+  ['EUCLIDEAN', 'COSINE', 'MAXIMUM_INNER_PRODUCT'].forEach(function (sim) {
+    const want = T.dec(g.true_f64[sim], Float64Array), got = new Float64Array(g.nq * g.n);
+    for (let qi = 0; qi < g.nq; qi++) for (let i = 0; i < g.n; i++)
+      got[qi * g.n + i] = bbq.computeSimilarity(fq.subarray(qi * g.dim, (qi + 1) * g.dim), fb.subarray(i * g.dim, (i + 1) * g.dim), sim);
+    T.check(T.sameBits(got, want), 'computeSimilarity ' + sim + ' equals the reference bit for bit');
+  });
+  const c = bbq.computeCentroid([[1, 2, 3], [4, 5, 6], [7, 8, 9]].map(function (r) { return new Float32Array(r); }));
+  T.check(c[0] === 4 && c[1] === 5 && c[2] === 6, 'computeCentroid known answer');
+  const gm = T.loadGolden('m_64d_cos_qb4'), io = T.inputs(gm);
+  T.check(T.sameBits(bbq.computeCentroid(io.base.map(bbq.normalizeVector)), T.dec(gm.centroid_f32, Float32Array)), 'normalizeVector + computeCentroid reproduce the fixture centroid');
+  const cen = T.dec(gm.centroid_f32, Float32Array);
+  T.check(T.sameBits(new Float64Array([bbq.computeDotProduct(cen, cen)]), T.dec(gm.centroid_dp_f64, Float64Array)), 'computeDotProduct(centroid, centroid) = centroidDP');
+  T.check(bbq.computeQuantizedDotProduct(new Uint8Array([1, 2, 3, 4]), new Uint8Array([5, 6, 7, 8])) === 70 &&
+    bbq.computeInt4BitDotProduct(new Uint8Array([15, 14, 13, 12]), new Uint8Array([1, 1, 0, 1])) === 41, 'bitwise_dot_product.rs:105-120 known answers');
+  T.check(bbq.computeEuclideanDistance(new Float32Array([0, 0]), new Float32Array([3, 4])) === 5 && bbq.computeMaximumInnerProduct(new Float32Array([1, 2]), new Float32Array([3, 4])) === 11, 'distance / inner product known answers');
+  let msg = '';
+  try { bbq.computeDotProduct(new Float32Array(2), new Float32Array(3)); } catch (e) { msg = e.message; }
+  T.check(msg === '向量维度不匹配', 'computeDotProduct dimension message');
+})();
 T.finish('js cpu_checks');
