@@ -298,4 +298,40 @@ int bbq_quantize_query_vector(const float *query, int32_t dim, const float *cent
   return quantize_query_impl(query, dim, centroid, sim, qb, lambda, iters, qquant, qcorr, 1);
 }
 
+int bbq_quantize_queries(const float *queries, int32_t n, int32_t dim, const float *centroid, int32_t sim, int32_t qb, double lambda,
+                         int32_t iters, int32_t n_threads, uint8_t *qquant, double *qcorr, int32_t *bad_query) {
+  bbq::clear_error();
+  if (bad_query) *bad_query = -1;
+  if (n < 0) return bbq::fail(BBQ_ERR_INVALID_ARG, "n < 0");
+  if (n == 0) return BBQ_OK;
+  int rc = check_common(queries, centroid, dim, sim, qb, lambda, iters);
+  if (rc != BBQ_OK) return rc;
+  if (!qquant || !qcorr) return bbq::fail(BBQ_ERR_INVALID_ARG, "null output");
+  int T = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+  T = std::max(1, std::min(T, n / 4 + 1));  // a 768-d query takes ~50 us: below 4 queries per thread spawning costs more
+  std::vector<int> first_bad((size_t)T, -1);
+  auto work = [&](int lo, int hi, int t) {
+    for (int i = lo; i < hi; ++i)
+      if (quantize_query_impl(queries + (size_t)i * dim, dim, centroid, sim, qb, lambda, iters, qquant + (size_t)i * dim, qcorr + (size_t)i * 4, 2) !=
+          BBQ_OK) {
+        first_bad[(size_t)t] = i;
+        return;
+      }
+  };
+  if (T == 1) {
+    work(0, n, 0);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(work, (int)((int64_t)n * t / T), (int)((int64_t)n * (t + 1) / T), t);
+    for (auto &x : th) x.join();
+  }
+  int bad = -1;
+  for (int t = 0; t < T; ++t)
+    if (first_bad[(size_t)t] >= 0 && (bad < 0 || first_bad[(size_t)t] < bad)) bad = first_bad[(size_t)t];
+  if (bad < 0) return BBQ_OK;
+  if (bad_query) *bad_query = bad;
+  // the message lives in the worker's thread-local slot: produce it again on this thread
+  return quantize_query_impl(queries + (size_t)bad * dim, dim, centroid, sim, qb, lambda, iters, qquant + (size_t)bad * dim, qcorr + (size_t)bad * 4, 2);
+}
+
 }  // extern "C"

@@ -236,16 +236,17 @@ class BinaryQuantizationFormat {
     const dim = targetVectors.dimension(), nq = queryVectors.length;
     if (k === 0) return queryVectors.map(function () { return []; });
     const q = this.quantizer, sim = simOrdinal(q.similarityFunction);
-    const qq = new Uint8Array(nq * dim), qc = new Float64Array(nq * 4);
+    const flat = new Float32Array(nq * dim);
     for (let i = 0; i < nq; i++) {
       const v = queryVectors[i];
       if (!v) throw new Error('查询向量不能为空');
       if (v.length !== dim) throw new Error('查询向量维度与目标向量维度不匹配');
-      // searchNearestNeighbors normalises for COSINE and quantizeQueryVector normalises again (:337-347, :279-281)
-      const r = native.quantizeQuery(Float32Array.from(v), targetVectors.getCentroid(), sim, this.config.queryBits, q.lambda, q.iters, true);
-      qq.set(r.quantizedQuery, i * dim);
-      qc.set(r.corrections, i * 4);
+      flat.set(v, i * dim);
     }
+    // searchNearestNeighbors normalises for COSINE and quantizeQueryVector normalises again (:337-347, :279-281); a batch is
+    // quantized on host threads (one 768-d query costs ~50 us on one core, more than its sweep of 1 M rows on the device)
+    const qz = native.quantizeQueries(flat, nq, targetVectors.getCentroid(), sim, this.config.queryBits, q.lambda, q.iters, Number(process.env.BBQ_THREADS || 0));
+    const qq = qz.quantized, qc = qz.corrections;
     const r = native.searchBatch(targetVectors._deviceIndex(), nq, qq, qc, this.config.queryBits, sim, k);
     const out = [];
     for (let i = 0; i < nq; i++) {
@@ -499,16 +500,15 @@ function getOversampledTopKBatch(queries, quantizedVectors, deviceVectors, k, ov
   const dim = quantizedVectors.dimension(), nq = queries.length;
   if (k === 0) return queries.map(function () { return []; });
   const q = format.getQuantizer(), sim = simOrdinal(q.similarityFunction), qb = format.getConfig().queryBits;
-  const flat = new Float32Array(nq * dim), qq = new Uint8Array(nq * dim), qc = new Float64Array(nq * 4);
+  const flat = new Float32Array(nq * dim);
   for (let i = 0; i < nq; i++) {
     const v = queries[i];
     if (!v) throw new Error('查询向量不能为空');
     if (v.length !== dim) throw new Error('查询向量维度与目标向量维度不匹配');
     flat.set(v, i * dim);
-    const r = native.quantizeQuery(Float32Array.from(v), quantizedVectors.getCentroid(), sim, qb, q.lambda, q.iters, true);
-    qq.set(r.quantizedQuery, i * dim);
-    qc.set(r.corrections, i * 4);
   }
+  const qz = native.quantizeQueries(flat, nq, quantizedVectors.getCentroid(), sim, qb, q.lambda, q.iters, Number(process.env.BBQ_THREADS || 0));
+  const qq = qz.quantized, qc = qz.corrections;
   const r = native.searchRerankBatch(quantizedVectors._deviceIndex(), deviceVectors._handle(), nq, flat, qq, qc, qb, sim, k,
     oversampleFactor, selector === 'sort' ? 1 : 0, 1);
   const out = [];

@@ -485,11 +485,36 @@ static napi_value IndexExport(napi_env env, napi_callback_info info) {
   return o;
 }
 
+/* quantizeQueries(flat Float32Array[n*dim], n, centroid Float32Array[dim], sim, queryBits, lambda, iters, threads)
+ *   -> {quantized Uint8Array[n*dim], corrections Float64Array[n*4]}   (bbq_quantize_queries: host threads) */
+static napi_value QuantizeQueries(napi_env env, napi_callback_info info) {
+  napi_value a[8];
+  if (!get_args(env, info, 8, a)) return NULL;
+  void *q, *cen; size_t ql, cl;
+  int64_t n, sim, qb, iters, threads; double lambda;
+  if (!get_typed(env, a[0], napi_float32_array, &q, &ql) || !get_i64(env, a[1], &n) || !get_typed(env, a[2], napi_float32_array, &cen, &cl) ||
+      !get_i64(env, a[3], &sim) || !get_i64(env, a[4], &qb) || !get_f64(env, a[5], &lambda) || !get_i64(env, a[6], &iters) ||
+      !get_i64(env, a[7], &threads)) return NULL;
+  if (n < 0 || cl == 0 || ql != (size_t)n * cl) { napi_throw_error(env, "BBQ6", "查询向量维度与目标向量维度不匹配"); return NULL; }
+  void *oq, *oc;
+  napi_value tq = new_typed(env, napi_uint8_array, ql, 1, &oq);
+  napi_value tc = new_typed(env, napi_float64_array, (size_t)n * 4, 8, &oc);
+  if (!tq || !tc) { napi_throw_error(env, NULL, "bbq_napi: allocation failed"); return NULL; }
+  int rc = bbq_quantize_queries((const float *)q, (int32_t)n, (int32_t)cl, (const float *)cen, (int32_t)sim, (int32_t)qb, lambda, (int32_t)iters,
+                                (int32_t)threads, (uint8_t *)oq, (double *)oc, NULL);
+  if (rc != BBQ_OK) return throw_bbq(env, rc);
+  napi_value o;
+  NAPI_CALL(env, napi_create_object(env, &o));
+  set_prop(env, o, "quantized", tq); set_prop(env, o, "corrections", tc);
+  return o;
+}
+
 static napi_value Init(napi_env env, napi_value exports) {
   napi_property_descriptor d[] = {
       {"deviceCount", NULL, DeviceCount, NULL, NULL, NULL, napi_default, NULL},
       {"quantizeVectors", NULL, QuantizeVectors, NULL, NULL, NULL, napi_default, NULL},
       {"quantizeQuery", NULL, QuantizeQuery, NULL, NULL, NULL, napi_default, NULL},
+      {"quantizeQueries", NULL, QuantizeQueries, NULL, NULL, NULL, napi_default, NULL},
       {"centroidDP", NULL, CentroidDP, NULL, NULL, NULL, napi_default, NULL},
       {"indexCreate", NULL, IndexCreate, NULL, NULL, NULL, napi_default, NULL},
       {"indexBuild", NULL, IndexBuild, NULL, NULL, NULL, napi_default, NULL},

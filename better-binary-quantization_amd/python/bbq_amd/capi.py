@@ -22,7 +22,7 @@ SYMBOLS = [
     "bbq_quantize_vectors", "bbq_quantize_query", "bbq_quantize_query_vector", "bbq_centroid_dp", "bbq_get_stats",
     "bbq_reset_stats", "bbq_set_option", "bbq_vectors_create", "bbq_vectors_destroy", "bbq_vectors_size",
     "bbq_vectors_dimension", "bbq_rerank_scores", "bbq_search_rerank_batch", "bbq_index_save", "bbq_index_file_info",
-    "bbq_index_load", "bbq_index_export",
+    "bbq_index_load", "bbq_index_export", "bbq_quantize_queries",
 ]
 
 
@@ -77,6 +77,7 @@ def lib():
     L.bbq_quantize_vectors.argtypes = [vp, i64, i32, i32, i32, dbl, i32, i32, vp, vp, vp, vp, vp]
     L.bbq_quantize_query.argtypes = [vp, i32, vp, i32, i32, dbl, i32, vp, vp]
     L.bbq_quantize_query_vector.argtypes = [vp, i32, vp, i32, i32, dbl, i32, vp, vp]
+    L.bbq_quantize_queries.argtypes = [vp, i32, i32, vp, i32, i32, dbl, i32, i32, vp, vp, C.POINTER(i32)]
     L.bbq_centroid_dp.argtypes = [vp, i32]
     L.bbq_centroid_dp.restype = dbl
     L.bbq_get_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -138,6 +139,20 @@ def quantize_query(query, centroid, sim, query_bits=4, lam=0.1, iters=5, search_
     qc = np.zeros(4, np.float64)
     fn = lib().bbq_quantize_query if search_path else lib().bbq_quantize_query_vector
     _chk(fn(_ptr(q), dim, _ptr(cen), sim, query_bits, lam, iters, _ptr(qq), _ptr(qc)))
+    return qq, qc
+
+
+def quantize_queries(queries, centroid, sim, query_bits=4, lam=0.1, iters=5, n_threads=0):
+    """searchNearestNeighbors' query preparation for a batch, on host threads: (qquant [n, dim], qcorr [n, 4])"""
+    q = np.ascontiguousarray(queries, np.float32)
+    cen = np.ascontiguousarray(centroid, np.float32)
+    if q.ndim != 2 or q.shape[1] != cen.shape[0]:
+        raise BBQError(ERR_DIM_MISMATCH, "查询向量维度与目标向量维度不匹配")
+    n, dim = q.shape
+    qq = np.zeros((n, dim), np.uint8)
+    qc = np.zeros((n, 4), np.float64)
+    bad = C.c_int32(-1)
+    _chk(lib().bbq_quantize_queries(_ptr(q), n, dim, _ptr(cen), sim, query_bits, lam, iters, n_threads, _ptr(qq), _ptr(qc), C.byref(bad)))
     return qq, qc
 
 

@@ -245,6 +245,12 @@ int bbq_quantize_vectors(const float *vectors, int64_t n, int32_t dim, int32_t s
  * (COSINE: the query is normalised twice) */
 int bbq_quantize_query(const float *query, int32_t dim, const float *centroid, int32_t sim, int32_t query_bits,
                        double lambda, int32_t iters, uint8_t *qquant, double *qcorr);
+/* bbq_quantize_query for n queries at once on n_threads host threads (0 = all cores): queries [n*dim], qquant [n*dim],
+ * qcorr [n*4].  On failure *bad_query (may be NULL) is the first offending query and the error is the one
+ * bbq_quantize_query reports for it.  A 768-d query takes ~50 us on one core; batches feed the device at its own rate. */
+int bbq_quantize_queries(const float *queries, int32_t n, int32_t dim, const float *centroid, int32_t sim,
+                         int32_t query_bits, double lambda, int32_t iters, int32_t n_threads, uint8_t *qquant,
+                         double *qcorr, int32_t *bad_query);
 /* quantizeQueryVector alone, src/binaryQuantizationFormat.ts:271-299 (normalises once for COSINE) */
 int bbq_quantize_query_vector(const float *query, int32_t dim, const float *centroid, int32_t sim,
                               int32_t query_bits, double lambda, int32_t iters, uint8_t *qquant, double *qcorr);

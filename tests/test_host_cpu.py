@@ -159,3 +159,30 @@ def test_vemb_header_spec(tmp_path):
         B.file_info(p)
     with pytest.raises(B.BBQError):
         B.file_info(str(tmp_path / "absent"))
+
+
+@pytest.mark.parametrize("sim,qb", [(0, 4), (1, 4), (2, 1), (1, 8)])
+def test_quantize_queries_batch_equals_one_by_one(sim, qb):
+    """bbq_quantize_queries (host threads) = bbq_quantize_query per query, bit for bit; the first bad query is reported"""
+    rng = np.random.default_rng(17)
+    dim, n = 200, 37
+    cen = (0.05 * rng.standard_normal(dim)).astype(np.float32)
+    qs = rng.standard_normal((n, dim)).astype(np.float32)
+    qs[5] = 0
+    for threads in (1, 3, 0):
+        qq, qc = B.quantize_queries(qs, cen, sim, qb, n_threads=threads)
+        for i in range(n):
+            a, b = B.quantize_query(qs[i], cen, sim, qb)
+            np.testing.assert_array_equal(qq[i], a)
+            np.testing.assert_array_equal(canon64(qc[i]), canon64(b))
+    assert B.quantize_queries(qs[:0], cen, sim, qb)[0].shape == (0, dim)
+    bad = qs.copy()
+    bad[30, 7] = np.inf
+    bad[12, 3] = np.nan
+    with pytest.raises(B.BBQError) as e:
+        B.quantize_queries(bad, cen, sim, qb, n_threads=4)
+    with pytest.raises(B.BBQError) as e1:
+        B.quantize_query(bad[12], cen, sim, qb)
+    assert e.value.code == e1.value.code and str(e.value) == str(e1.value)
+    with pytest.raises(B.BBQError):
+        B.quantize_queries(qs[:, :10], cen, sim, qb)
