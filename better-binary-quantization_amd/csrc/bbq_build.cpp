@@ -103,7 +103,7 @@ int bbq_index_build(const float *vectors, int64_t n, int32_t dim, int32_t sim, d
   }
   ix->has_x1 = 0;  // a freshly quantized 1-bit row's component sum IS its popcount
   ix->layout = ix->want_compact ? kLayoutCompact : kLayoutInline;
-  ix->tile_stride = ix->w16 * 1024 + (ix->layout == kLayoutCompact ? 512 : 1536);
+  ix->tile_stride = tile_stride_of(ix->w16, ix->layout, 0);
   ix->bytes_per_row = ix->tile_stride / kTileRows;
   Storage &sto = ix->main;
   const int64_t n_tiles = npad / kTileRows;
@@ -112,6 +112,7 @@ int bbq_index_build(const float *vectors, int64_t n, int32_t dim, int32_t sim, d
   if (corr) BCHK(hipMalloc((void **)&d_corr, (size_t)n * 32));
   BCHK(launch_build_quantize1(d_vT4, n, dim, npad, d_cen, sim, lambda, iters, sto.d_tiles, sto.d_exact, d_corr, ix->w16, ix->tile_stride,
                               ix->layout, st));  // :221-249
+  if (ix->layout == kLayoutCompact) BCHK(launch_tile_add_range(sto.d_exact, n, sto.d_tiles, ix->w16, ix->tile_stride, st));
   if (corr) BCHK(hipMemcpyAsync(corr, d_corr, (size_t)n * 32, hipMemcpyDeviceToHost, st));
   if (codes) {
     BCHK(hipMalloc((void **)&d_codes, (size_t)n * ix->pb));

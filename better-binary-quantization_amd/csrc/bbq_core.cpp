@@ -151,7 +151,7 @@ int make_storage(bbq_index *ix, Storage &st, const uint8_t *codes, const double 
   }
   // compact corrections (8 B/row streamed + exact side array) need the implicit component sum; otherwise inline
   ix->layout = (ix->want_compact && !ix->has_x1) ? kLayoutCompact : kLayoutInline;
-  ix->tile_stride = ix->w16 * 1024 + (ix->layout == kLayoutCompact ? 512 : 1536 + (ix->has_x1 ? 512 : 0));
+  ix->tile_stride = tile_stride_of(ix->w16, ix->layout, ix->has_x1);
   ix->bytes_per_row = ix->tile_stride / kTileRows;
   st.row_id_base = row_id_base;
   st.view.n_rows = n_rows;
@@ -164,6 +164,7 @@ int make_storage(bbq_index *ix, Storage &st, const uint8_t *codes, const double 
     HIPCHK(hipMalloc((void **)&st.d_tiles, (size_t)(n_tiles * ix->tile_stride)));
     if (ix->layout == kLayoutCompact) HIPCHK(hipMalloc((void **)&st.d_exact, (size_t)(n_tiles * kTileRows) * 32));
     HIPCHK(launch_retile(d_codes, d_corr, n_rows, (int32_t)pb, st.d_tiles, ix->w16, ix->tile_stride, ix->has_x1, ix->layout, st.d_exact, s));
+    if (ix->layout == kLayoutCompact) HIPCHK(launch_tile_add_range(st.d_exact, n_rows, st.d_tiles, ix->w16, ix->tile_stride, s));
     HIPCHK(hipStreamSynchronize(s));
   }
   st.view.exact = st.d_exact;

@@ -189,10 +189,9 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) 
       lu = BBQ_STREAM_LOAD(ex);
       xadd = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(ex + 1));
     } else {
-      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-      const u32x2 c = BBQ_STREAM_LOAD(reinterpret_cast<const u32x2 *>(cr) + lane);
-      cpk0 = c.x;
-      cpk1 = c.y;
+      cpk0 = BBQ_STREAM_LOAD(reinterpret_cast<const uint32_t *>(cr) + lane);
+      // the tile's additive-correction range: EUCLIDEAN scores fall with it (take the minimum), the others rise (maximum)
+      cpk1 = BBQ_STREAM_LOAD(reinterpret_cast<const uint32_t *>(cr + kCompactRowBytes) + (p.sim == 0 ? 0 : 1));
     }
 
     uint32_t acc[QB], ones;
@@ -331,11 +330,11 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_shared_kernel(const ScanA
       if (a.idx.has_x1) x1 = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(cr + 1536) + lane);
       have_exact = true;
     } else {
-      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-      const u32x2 cc = BBQ_STREAM_LOAD(reinterpret_cast<const u32x2 *>(cr) + lane);
-      al = (double)__uint_as_float(cc.x << 16);
-      au = (double)__uint_as_float(cc.x & 0xffff0000u);
-      aadd = (double)__uint_as_float(cc.y);
+      const uint32_t cw = BBQ_STREAM_LOAD(reinterpret_cast<const uint32_t *>(cr) + lane);
+      al = (double)__uint_as_float(cw << 16);
+      au = (double)__uint_as_float(cw & 0xffff0000u);
+      // tile range of the additive correction; the queries of one call share the similarity function
+      aadd = (double)__uint_as_float(BBQ_STREAM_LOAD(reinterpret_cast<const uint32_t *>(cr + kCompactRowBytes) + (s_qp[0].sim == 0 ? 0 : 1)));
     }
     uint32_t ones = 0;
 #pragma unroll
@@ -609,11 +608,7 @@ __global__ __launch_bounds__(256) void bbq_retile_kernel(const uint8_t *__restri
       lu.x = corr[row * 4 + 0]; lu.y = corr[row * 4 + 1]; add = corr[row * 4 + 2]; x1 = corr[row * 4 + 3];
     }
     if (layout == kLayoutCompact) {
-      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-      u32x2 c;
-      c.x = bf16_trunc_bits(lu.x) | (bf16_trunc_bits(lu.y) << 16);
-      c.y = __float_as_uint((float)add);
-      reinterpret_cast<u32x2 *>(cr)[r] = c;
+      reinterpret_cast<uint32_t *>(cr)[r] = bf16_trunc_bits(lu.x) | (bf16_trunc_bits(lu.y) << 16);  // range: bbq_tile_add_range_kernel
       double *e = exact + row * 4;
       e[0] = lu.x; e[1] = lu.y; e[2] = add; e[3] = 0.0;
     } else {
@@ -621,6 +616,34 @@ __global__ __launch_bounds__(256) void bbq_retile_kernel(const uint8_t *__restri
       reinterpret_cast<double *>(cr + 1024)[r] = add;
       if (has_x1) reinterpret_cast<double *>(cr + 1536)[r] = x1;
     }
+  }
+}
+
+// compact layout: {min, max} of additionalCorrection over the valid rows of each tile, as f32 (one wave per tile; the f32
+// rounding is inside the bound's allowance for the additive term).  A NaN anywhere makes both ends NaN: no bound, exact path.
+__global__ __launch_bounds__(256) void bbq_tile_add_range_kernel(const double *__restrict__ exact, int64_t n_rows, uint8_t *__restrict__ tiles,
+                                                                int32_t w16, int32_t tile_stride) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
+  if (tile >= n_tiles) return;
+  const int64_t row = tile * kTileRows + lane;
+  const bool valid = row < n_rows;
+  const double v = valid ? exact[row * 4 + 2] : 0.0;
+  bool nan = valid && (v != v);
+  double lo = valid ? v : __longlong_as_double(0x7ff0000000000000ll), hi = valid ? v : __longlong_as_double(0xfff0000000000000ll);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    lo = fmin(lo, __shfl_xor(lo, d, 64));
+    hi = fmax(hi, __shfl_xor(hi, d, 64));
+  }
+  nan = __any(nan);
+  if (lane == 0) {
+    float4 h;
+    h.x = nan ? __uint_as_float(0x7fc00000u) : (float)lo;
+    h.y = nan ? __uint_as_float(0x7fc00000u) : (float)hi;
+    h.z = 0.f; h.w = 0.f;
+    *reinterpret_cast<float4 *>(tiles + tile * (int64_t)tile_stride + (size_t)w16 * (kTileRows * 16) + kCompactRowBytes) = h;
   }
 }
 
@@ -789,6 +812,13 @@ hipError_t launch_retile(const uint8_t *codes, const double *corr, int64_t n_row
   const int64_t blocks = (threads + 255) / 256;
   hipLaunchKernelGGL(bbq_retile_kernel, dim3((unsigned)blocks), dim3(256), 0, s, codes, corr, n_rows, pb, tiles, w16, tile_stride,
                      has_x1, n_pad, layout, exact);
+  return hipGetLastError();
+}
+
+hipError_t launch_tile_add_range(const double *exact, int64_t n_rows, uint8_t *tiles, int32_t w16, int32_t tile_stride, hipStream_t s) {
+  const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
+  if (n_tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(bbq_tile_add_range_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, exact, n_rows, tiles, w16, tile_stride);
   return hipGetLastError();
 }
 

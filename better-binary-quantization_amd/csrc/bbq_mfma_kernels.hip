@@ -136,14 +136,18 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
   // staged once, and the codes of the next chunk's tile are prefetched into registers while the current one is computed.
   const int lc0 = blockIdx.x * kMfmaChunksPerBlock;
   u32x4m cnext[W];
-  u32x2m ccnext = {0u, 0u};
+  u32x2m ccnext = {0u, 0u};  // .x: this lane's bf16 pair, .y: the tile's additive-correction bound (min for EUCLIDEAN, max otherwise)
   {
     const int64_t t0 = (a.s.chunk_begin + lc0) * kTilesPerChunk + wave;
     if (lc0 < a.s.n_chunks && t0 < n_tiles) {
       const uint8_t *__restrict__ tp0 = a.s.idx.tiles + t0 * (int64_t)a.s.idx.tile_stride;
 #pragma unroll
       for (int j = 0; j < W; ++j) cnext[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4m *>(tp0) + lane + j * kTileRows);
-      if constexpr (COMPACT) ccnext = __builtin_nontemporal_load(reinterpret_cast<const u32x2m *>(tp0 + (size_t)W * (kTileRows * 16)) + lane);
+      if constexpr (COMPACT) {
+        const uint8_t *cr0 = tp0 + (size_t)W * (kTileRows * 16);
+        ccnext.x = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(cr0) + lane);
+        ccnext.y = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(cr0 + kCompactRowBytes) + (s_qp[0].sim == 0 ? 0 : 1));
+      }
     }
   }
 #pragma unroll 1
@@ -183,7 +187,11 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
         const uint8_t *__restrict__ tpn = a.s.idx.tiles + tn * (int64_t)a.s.idx.tile_stride;
 #pragma unroll
         for (int j = 0; j < W; ++j) cnext[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4m *>(tpn) + lane + j * kTileRows);
-        if constexpr (COMPACT) ccnext = __builtin_nontemporal_load(reinterpret_cast<const u32x2m *>(tpn + (size_t)W * (kTileRows * 16)) + lane);
+        if constexpr (COMPACT) {
+          const uint8_t *crn = tpn + (size_t)W * (kTileRows * 16);
+          ccnext.x = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(crn) + lane);
+          ccnext.y = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(crn + kCompactRowBytes) + (s_qp[0].sim == 0 ? 0 : 1));
+        }
       }
     }
     (void)cp;

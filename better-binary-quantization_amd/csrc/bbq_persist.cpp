@@ -25,7 +25,7 @@ struct MetaHeader {
 };
 #pragma pack(pop)
 static_assert(sizeof(MetaHeader) == 104, "vemb header layout");
-constexpr uint32_t kFileVersion = 1;
+constexpr uint32_t kFileVersion = 2;  // 2: compact tiles carry 4 B per row + the tile's additive-correction range
 
 // FNV-1a over little-endian 64-bit words (tail zero-padded): one multiply per 8 bytes keeps up with the disk
 uint64_t fnv64_words(const void *data, size_t n, uint64_t h) {
@@ -46,7 +46,7 @@ uint64_t fnv64_words(const void *data, size_t n, uint64_t h) {
 constexpr uint64_t kFnvSeed = 0xcbf29ce484222325ull;
 
 int32_t expected_tile_stride(int32_t w16, int32_t layout, int32_t has_x1) {
-  return w16 * 1024 + (layout == kLayoutCompact ? 512 : 1536 + (has_x1 ? 512 : 0));
+  return tile_stride_of(w16, layout, has_x1);
 }
 
 struct FileCloser {

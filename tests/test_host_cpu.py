@@ -140,9 +140,9 @@ def test_vemb_header_spec(tmp_path):
     dim, n = 100, 1000
     pb, w16 = (dim + 7) // 8, ((dim + 7) // 8 + 15) // 16
     n_tiles = (n + 63) // 64
-    stride = w16 * 1024 + 512                                        # compact layout
+    stride = w16 * 1024 + 256 + 16                                   # compact layout: 4 B per row + the tile's add range
     tiles, exact = n_tiles * stride, n_tiles * 64 * 32
-    hdr = struct.pack("<4sI4i3qd6i3q", b"BVEC", 1, 0, 0, 1, dim, 0, tiles + exact, n, 0.125, 1, 1, w16, stride, 0, 64, tiles, exact, 0)
+    hdr = struct.pack("<4sI4i3qd6i3q", b"BVEC", 2, 0, 0, 1, dim, 0, tiles + exact, n, 0.125, 1, 1, w16, stride, 0, 64, tiles, exact, 0)
     assert len(hdr) == 104
     cen = np.arange(dim, dtype=np.float32).tobytes()
     dsum = struct.pack("<Q", 0x1234)
@@ -153,7 +153,7 @@ def test_vemb_header_spec(tmp_path):
     open(p + ".vemb", "wb").write(hdr + cen + dsum + struct.pack("<Q", msum ^ 1))
     with pytest.raises(B.BBQError):
         B.file_info(p)
-    bad = struct.pack("<4sI4i3qd6i3q", b"BVEC", 1, 0, 0, 1, dim, 0, tiles + exact, n, 0.125, 1, 1, w16, stride + 16, 0, 64, tiles, exact, 0)
+    bad = struct.pack("<4sI4i3qd6i3q", b"BVEC", 2, 0, 0, 1, dim, 0, tiles + exact, n, 0.125, 1, 1, w16, stride + 16, 0, 64, tiles, exact, 0)
     open(p + ".vemb", "wb").write(bad + cen + dsum + struct.pack("<Q", fnv(dsum, fnv(cen, fnv(bad, 0xcbf29ce484222325)))))
     with pytest.raises(B.BBQError):
         B.file_info(p)
