@@ -108,11 +108,11 @@ int bbq_index_build(const float *vectors, int64_t n, int32_t dim, int32_t sim, d
   Storage &sto = ix->main;
   const int64_t n_tiles = npad / kTileRows;
   BCHK(hipMalloc((void **)&sto.d_tiles, (size_t)n_tiles * ix->tile_stride));
-  if (ix->layout == kLayoutCompact) BCHK(hipMalloc((void **)&sto.d_exact, (size_t)npad * 32));
+  if (ix->layout == kLayoutCompact) BCHK(hipMalloc((void **)&sto.d_exact, (size_t)compact_side_bytes(n_tiles)));
   if (corr) BCHK(hipMalloc((void **)&d_corr, (size_t)n * 32));
   BCHK(launch_build_quantize1(d_vT4, n, dim, npad, d_cen, sim, lambda, iters, sto.d_tiles, sto.d_exact, d_corr, ix->w16, ix->tile_stride,
                               ix->layout, st));  // :221-249
-  if (ix->layout == kLayoutCompact) BCHK(launch_tile_add_range(sto.d_exact, n, sto.d_tiles, ix->w16, ix->tile_stride, st));
+  if (ix->layout == kLayoutCompact) BCHK(launch_tile_add_range(sto.d_exact, n, const_cast<float *>(add_range_of(sto.d_exact, n_tiles)), st));
   if (corr) BCHK(hipMemcpyAsync(corr, d_corr, (size_t)n * 32, hipMemcpyDeviceToHost, st));
   if (codes) {
     BCHK(hipMalloc((void **)&d_codes, (size_t)n * ix->pb));
@@ -125,6 +125,7 @@ int bbq_index_build(const float *vectors, int64_t n, int32_t dim, int32_t sim, d
   sto.row_id_base = 0;
   sto.view.tiles = sto.d_tiles;
   sto.view.exact = sto.d_exact;
+  sto.view.add_range = add_range_of(sto.d_exact, n_tiles);
   sto.view.n_rows = n;
   sto.view.w16 = ix->w16;
   sto.view.tile_stride = ix->tile_stride;

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void bbq_quantize1_kernel(const f32x4 *__restr
   }
   uint8_t *cr = tp + (size_t)out.w16 * (kTileRows * 16);
   if (out.layout == kLayoutCompact) {
-    // the tile's additive-correction range is written afterwards from exact[] (launch_tile_add_range)
+    // the tiles' additive-correction ranges are computed afterwards from exact[] (launch_tile_add_range)
     reinterpret_cast<uint32_t *>(cr)[r] = (__float_as_uint((float)lower) >> 16) | ((__float_as_uint((float)upper) >> 16) << 16);
     double *e = out.exact + vec * 4;
     e[0] = lower; e[1] = upper; e[2] = add; e[3] = 0.0;

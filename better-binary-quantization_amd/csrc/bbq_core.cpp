@@ -162,12 +162,13 @@ int make_storage(bbq_index *ix, Storage &st, const uint8_t *codes, const double 
   st.view.layout = ix->layout;
   if (n_tiles > 0) {
     HIPCHK(hipMalloc((void **)&st.d_tiles, (size_t)(n_tiles * ix->tile_stride)));
-    if (ix->layout == kLayoutCompact) HIPCHK(hipMalloc((void **)&st.d_exact, (size_t)(n_tiles * kTileRows) * 32));
+    if (ix->layout == kLayoutCompact) HIPCHK(hipMalloc((void **)&st.d_exact, (size_t)compact_side_bytes(n_tiles)));
     HIPCHK(launch_retile(d_codes, d_corr, n_rows, (int32_t)pb, st.d_tiles, ix->w16, ix->tile_stride, ix->has_x1, ix->layout, st.d_exact, s));
-    if (ix->layout == kLayoutCompact) HIPCHK(launch_tile_add_range(st.d_exact, n_rows, st.d_tiles, ix->w16, ix->tile_stride, s));
+    if (ix->layout == kLayoutCompact) HIPCHK(launch_tile_add_range(st.d_exact, n_rows, const_cast<float *>(add_range_of(st.d_exact, n_tiles)), s));
     HIPCHK(hipStreamSynchronize(s));
   }
   st.view.exact = st.d_exact;
+  st.view.add_range = add_range_of(st.d_exact, n_tiles);
   st.view.tiles = st.d_tiles;
   HIPCHK(hipStreamSynchronize(s));  // the scratch rows are released on return
   return BBQ_OK;

@@ -22,22 +22,23 @@ constexpr uint32_t kFlagNaN = 2u;        // a NaN score was produced: order stat
 //   [64] double2       {lowerInterval, upperInterval}                      -> 1 KiB
 //   [64] double        additionalCorrection                                -> 512 B
 //   [64] double        quantizedComponentSum (only if has_x1)              -> 512 B
-//  kLayoutCompact (4 B/row + 16 B/tile streamed; exact corrections in a side array, gathered only for rows whose score
-//  BOUND passes the threshold)
-//   [64] uint32        bf16(lower) | bf16(upper) << 16 (f32 bits truncated)
-//   float4             {min, max of the tile's additionalCorrection (f32), 0, 0}: the bound takes whichever end makes the
-//                      score larger; the additive term varies far less inside a tile than scores vary between rows
-//   side array exact[row] = {lower, upper, additional, 0} as 4 doubles (32 B/row)
+//  kLayoutCompact (4 B/row streamed; exact corrections in a side array, gathered only for rows whose score BOUND passes
+//  the threshold)
+//   [64] uint32        bf16(lower) | bf16(upper) << 16 (f32 bits truncated)       -> tiles stay multiples of 128 B
+//   side array exact[row] = {lower, upper, additional, 0} as 4 doubles (32 B/row), followed by
+//   side array add_range[tile] = {min, max} of the tile's additionalCorrection as f32 (8 B per 64 rows, one broadcast load
+//   per wave): the bound takes whichever end makes the score larger; the additive term varies far less inside a tile than
+//   scores vary between rows
 constexpr int kLayoutInline = 0;
 constexpr int kLayoutCompact = 1;
-constexpr int kCompactRowBytes = 4 * kTileRows;  // offset of the tile's {add_min, add_max} behind the per-row words
 // bytes of one tile record
 __host__ __device__ inline int tile_stride_of(int w16, int layout, int has_x1) {
-  return w16 * 1024 + (layout == kLayoutCompact ? kCompactRowBytes + 16 : 1536 + (has_x1 ? 512 : 0));
+  return w16 * 1024 + (layout == kLayoutCompact ? 4 * kTileRows : 1536 + (has_x1 ? 512 : 0));
 }
 struct IndexView {
   const uint8_t *tiles;
   const double *exact;  // kLayoutCompact: [n_rows padded to 64][4]
+  const float *add_range;  // kLayoutCompact: [tiles][2] {min, max} of additionalCorrection inside the tile
   int64_t n_rows;       // valid rows in this storage
   int32_t w16;          // 16-byte chunks per row = ceil(ceil(dim/8)/16)
   int32_t tile_stride;  // bytes per tile record

@@ -39,7 +39,8 @@ constexpr int64_t kMaxFastK = 4096;  // beyond this the dense path is used: the 
 
 struct Storage {
   uint8_t *d_tiles = nullptr;
-  double *d_exact = nullptr;  // kLayoutCompact: exact corrections, gathered for the rows whose bound passes
+  double *d_exact = nullptr;  // kLayoutCompact: exact corrections, gathered for the rows whose bound passes; the per-tile
+                              // additive-correction ranges (view.add_range) live behind them in the same allocation
   IndexView view{};
   int64_t row_id_base = 0;
   int64_t n_chunks() const { return (view.n_rows + kChunkRows - 1) / kChunkRows; }
@@ -107,6 +108,11 @@ int64_t qbuf_bytes_per_query_w(int w16);
 // returns the (lazily created, never destroyed) context of a device; call with hipSetDevice(device) done
 int get_ctx(int device, DeviceCtx **out);
 int ensure_aux_qbuf(DeviceCtx *c, int64_t bytes);
+// bytes of the compact layout's side arrays for n_tiles tiles: exact corrections + add ranges
+inline int64_t compact_side_bytes(int64_t n_tiles) { return n_tiles * kTileRows * 32 + n_tiles * 8; }
+inline const float *add_range_of(const double *d_exact, int64_t n_tiles) {
+  return d_exact ? reinterpret_cast<const float *>(d_exact + n_tiles * kTileRows * 4) : nullptr;
+}
 
 }  // namespace bbq
 

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) 
     } else {
       cpk0 = BBQ_STREAM_LOAD(reinterpret_cast<const uint32_t *>(cr) + lane);
       // the tile's additive-correction range: EUCLIDEAN scores fall with it (take the minimum), the others rise (maximum)
-      cpk1 = BBQ_STREAM_LOAD(reinterpret_cast<const uint32_t *>(cr + kCompactRowBytes) + (p.sim == 0 ? 0 : 1));
+      cpk1 = __float_as_uint(a.idx.add_range[tile * 2 + (p.sim == 0 ? 0 : 1)]);
     }
 
     uint32_t acc[QB], ones;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_shared_kernel(const ScanA
       al = (double)__uint_as_float(cw << 16);
       au = (double)__uint_as_float(cw & 0xffff0000u);
       // tile range of the additive correction; the queries of one call share the similarity function
-      aadd = (double)__uint_as_float(BBQ_STREAM_LOAD(reinterpret_cast<const uint32_t *>(cr + kCompactRowBytes) + (s_qp[0].sim == 0 ? 0 : 1)));
+      aadd = (double)a.idx.add_range[tile * 2 + (s_qp[0].sim == 0 ? 0 : 1)];
     }
     uint32_t ones = 0;
 #pragma unroll
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void bbq_retile_kernel(const uint8_t *__restri
       lu.x = corr[row * 4 + 0]; lu.y = corr[row * 4 + 1]; add = corr[row * 4 + 2]; x1 = corr[row * 4 + 3];
     }
     if (layout == kLayoutCompact) {
-      reinterpret_cast<uint32_t *>(cr)[r] = bf16_trunc_bits(lu.x) | (bf16_trunc_bits(lu.y) << 16);  // range: bbq_tile_add_range_kernel
+      reinterpret_cast<uint32_t *>(cr)[r] = bf16_trunc_bits(lu.x) | (bf16_trunc_bits(lu.y) << 16);  // the additive term: bbq_tile_add_range_kernel
       double *e = exact + row * 4;
       e[0] = lu.x; e[1] = lu.y; e[2] = add; e[3] = 0.0;
     } else {
@@ -621,8 +621,7 @@ __global__ __launch_bounds__(256) void bbq_retile_kernel(const uint8_t *__restri
 
 // compact layout: {min, max} of additionalCorrection over the valid rows of each tile, as f32 (one wave per tile; the f32
 // rounding is inside the bound's allowance for the additive term).  A NaN anywhere makes both ends NaN: no bound, exact path.
-__global__ __launch_bounds__(256) void bbq_tile_add_range_kernel(const double *__restrict__ exact, int64_t n_rows, uint8_t *__restrict__ tiles,
-                                                                int32_t w16, int32_t tile_stride) {
+__global__ __launch_bounds__(256) void bbq_tile_add_range_kernel(const double *__restrict__ exact, int64_t n_rows, float *__restrict__ add_range) {
   const int lane = threadIdx.x & 63;
   const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
@@ -639,11 +638,8 @@ __global__ __launch_bounds__(256) void bbq_tile_add_range_kernel(const double *_
   }
   nan = __any(nan);
   if (lane == 0) {
-    float4 h;
-    h.x = nan ? __uint_as_float(0x7fc00000u) : (float)lo;
-    h.y = nan ? __uint_as_float(0x7fc00000u) : (float)hi;
-    h.z = 0.f; h.w = 0.f;
-    *reinterpret_cast<float4 *>(tiles + tile * (int64_t)tile_stride + (size_t)w16 * (kTileRows * 16) + kCompactRowBytes) = h;
+    add_range[tile * 2] = nan ? __uint_as_float(0x7fc00000u) : (float)lo;
+    add_range[tile * 2 + 1] = nan ? __uint_as_float(0x7fc00000u) : (float)hi;
   }
 }
 
@@ -815,10 +811,10 @@ hipError_t launch_retile(const uint8_t *codes, const double *corr, int64_t n_row
   return hipGetLastError();
 }
 
-hipError_t launch_tile_add_range(const double *exact, int64_t n_rows, uint8_t *tiles, int32_t w16, int32_t tile_stride, hipStream_t s) {
+hipError_t launch_tile_add_range(const double *exact, int64_t n_rows, float *add_range, hipStream_t s) {
   const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
   if (n_tiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(bbq_tile_add_range_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, exact, n_rows, tiles, w16, tile_stride);
+  hipLaunchKernelGGL(bbq_tile_add_range_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, exact, n_rows, add_range);
   return hipGetLastError();
 }
 

@@ -20,8 +20,8 @@ hipError_t launch_pack(const int32_t *counts, const uint64_t *lists, int64_t lis
                        int32_t *flags_out, int64_t *total_out, uint64_t *packed, int64_t packed_cap, hipStream_t s);
 hipError_t launch_retile(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t pb, uint8_t *tiles, int32_t w16,
                          int32_t tile_stride, int32_t has_x1, int32_t layout, double *exact, hipStream_t s);
-// compact layout: writes each tile's {min, max} of additionalCorrection (read from exact[]) behind its per-row words
-hipError_t launch_tile_add_range(const double *exact, int64_t n_rows, uint8_t *tiles, int32_t w16, int32_t tile_stride, hipStream_t s);
+// compact layout: each tile's {min, max} of additionalCorrection (read from exact[]) -> add_range[tile][2]
+hipError_t launch_tile_add_range(const double *exact, int64_t n_rows, float *add_range, hipStream_t s);
 hipError_t launch_check_x1(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t pb, uint32_t *mismatch,
                            hipStream_t s);
 

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
       if constexpr (COMPACT) {
         const uint8_t *cr0 = tp0 + (size_t)W * (kTileRows * 16);
         ccnext.x = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(cr0) + lane);
-        ccnext.y = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(cr0 + kCompactRowBytes) + (s_qp[0].sim == 0 ? 0 : 1));
+        ccnext.y = __float_as_uint(a.s.idx.add_range[t0 * 2 + (s_qp[0].sim == 0 ? 0 : 1)]);
       }
     }
   }
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
         if constexpr (COMPACT) {
           const uint8_t *crn = tpn + (size_t)W * (kTileRows * 16);
           ccnext.x = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(crn) + lane);
-          ccnext.y = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(crn + kCompactRowBytes) + (s_qp[0].sim == 0 ? 0 : 1));
+          ccnext.y = __float_as_uint(a.s.idx.add_range[tn * 2 + (s_qp[0].sim == 0 ? 0 : 1)]);
         }
       }
     }

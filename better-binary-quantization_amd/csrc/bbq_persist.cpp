@@ -25,7 +25,7 @@ struct MetaHeader {
 };
 #pragma pack(pop)
 static_assert(sizeof(MetaHeader) == 104, "vemb header layout");
-constexpr uint32_t kFileVersion = 2;  // 2: compact tiles carry 4 B per row + the tile's additive-correction range
+constexpr uint32_t kFileVersion = 2;  // 2: compact tiles carry 4 B per row; the side section = exact corrections + per-tile add ranges
 
 // FNV-1a over little-endian 64-bit words (tail zero-padded): one multiply per 8 bytes keeps up with the disk
 uint64_t fnv64_words(const void *data, size_t n, uint64_t h) {
@@ -69,7 +69,7 @@ int read_meta(const char *prefix, MetaHeader *h, std::vector<float> *centroid, u
   const int64_t n_tiles = (h->vectorCount + kTileRows - 1) / kTileRows;
   if (h->w16 != (pb + 15) / 16 || h->tileStride != expected_tile_stride(h->w16, h->layout, h->hasX1) ||
       (h->layout == kLayoutCompact && h->hasX1) || h->tilesBytes != n_tiles * h->tileStride ||
-      h->exactBytes != (h->layout == kLayoutCompact ? n_tiles * kTileRows * 32 : 0) ||
+      h->exactBytes != (h->layout == kLayoutCompact ? compact_side_bytes(n_tiles) : 0) ||
       h->vectorDataLength != h->tilesBytes + h->exactBytes || h->vectorDataOffset < 0)
     return fail(BBQ_ERR_INVALID_ARG, "%s: tile geometry does not match dimensions/vectorCount", path.c_str());
   std::vector<float> cen((size_t)h->dimensions);
@@ -111,7 +111,7 @@ int bbq_index_save(bbq_index *ix, const char *prefix, const float *centroid, int
   h.hasX1 = ix->has_x1;
   h.tileRows = kTileRows;
   h.tilesBytes = n_tiles * ix->tile_stride;
-  h.exactBytes = ix->layout == kLayoutCompact ? n_tiles * kTileRows * 32 : 0;
+  h.exactBytes = ix->layout == kLayoutCompact ? compact_side_bytes(n_tiles) : 0;
   h.rowBase = ix->row_base;
   h.vectorDataOffset = 0;
   h.vectorDataLength = h.tilesBytes + h.exactBytes;
@@ -239,6 +239,7 @@ int bbq_index_load(const char *prefix, int32_t device, bbq_index **out, float *c
   st.view.layout = h.layout;
   st.view.tiles = st.d_tiles;
   st.view.exact = st.d_exact;
+  st.view.add_range = add_range_of(st.d_exact, (h.vectorCount + kTileRows - 1) / kTileRows);
   if (centroid_out) memcpy(centroid_out, cen.data(), cen.size() * 4);
   *out = ix.release();
   return BBQ_OK;

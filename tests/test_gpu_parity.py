@@ -58,7 +58,7 @@ def _check(name, options=None, compact=True):
     sim, base, queries, codes, corr, cen, cdp = _index_from_case(g)
     ix = _make_index(codes, corr, g["dim"], cdp, compact)
     pb16 = (g["row_bytes"] + 15) // 16 * 16
-    assert ix.bytes_per_row == pb16 + (4 if compact else 24)   # compact: 4 B per row (+ 16 B per 64-row tile)
+    assert ix.bytes_per_row == pb16 + (4 if compact else 24)   # compact: 4 B per row (+ 8 B per 64-row tile in a side array)
     for k_, v_ in (options or {}).items():
         ix.set_option(k_, v_)
     try:
@@ -754,9 +754,9 @@ def test_save_load_roundtrip(tmp_path, name, compact):
     ix.save(prefix, cen, sim)
     n_tiles = (g["n"] + 63) // 64
     w16 = ((g["dim"] + 7) // 8 + 15) // 16
-    stride = w16 * 1024 + (256 + 16 if compact else 1536)   # compact: 4 B per row + {add_min, add_max} per tile
+    stride = w16 * 1024 + (256 if compact else 1536)   # compact: 4 B per row in the tile; exact corrections + add ranges aside
     assert ix.bytes_per_row == stride // 64
-    assert os.path.getsize(prefix + ".veb") == n_tiles * stride + (n_tiles * 64 * 32 if compact else 0)
+    assert os.path.getsize(prefix + ".veb") == n_tiles * stride + (n_tiles * (64 * 32 + 8) if compact else 0)
     assert os.path.getsize(prefix + ".vemb") == 104 + 4 * g["dim"] + 16
     info = B.file_info(prefix)
     assert info == {"n_rows": g["n"], "dim": g["dim"], "sim": sim, "centroid_dp": cdp, "row_base": 0}

@@ -140,8 +140,8 @@ def test_vemb_header_spec(tmp_path):
     dim, n = 100, 1000
     pb, w16 = (dim + 7) // 8, ((dim + 7) // 8 + 15) // 16
     n_tiles = (n + 63) // 64
-    stride = w16 * 1024 + 256 + 16                                   # compact layout: 4 B per row + the tile's add range
-    tiles, exact = n_tiles * stride, n_tiles * 64 * 32
+    stride = w16 * 1024 + 256                                        # compact layout: 4 B per row
+    tiles, exact = n_tiles * stride, n_tiles * 64 * 32 + n_tiles * 8  # side section: exact corrections + {min, max} of add per tile
     hdr = struct.pack("<4sI4i3qd6i3q", b"BVEC", 2, 0, 0, 1, dim, 0, tiles + exact, n, 0.125, 1, 1, w16, stride, 0, 64, tiles, exact, 0)
     assert len(hdr) == 104
     cen = np.arange(dim, dtype=np.float32).tobytes()
