@@ -17,5 +17,6 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/rp_w -- python3 $R/bench.
 cp $(ls /tmp/rp_w/*/*counter_collection.csv | head -1) $OUT/pmc_write_full.csv
 echo "write pass done"
 cd $R && python3 bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err || exit 1
+./scripts/ubench/hbm_read > $OUT/hbm_read_probe.txt 2>&1 || true
 echo "bench done"
 ls -la $OUT
