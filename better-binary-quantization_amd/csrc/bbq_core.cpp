@@ -149,7 +149,7 @@ int make_storage(bbq_index *ix, Storage &st, const uint8_t *codes, const double 
     HIPCHK(hipStreamSynchronize(s));
     if (mis) ix->has_x1 = 1;
   }
-  // compact corrections (8 B/row streamed + exact side array) need the implicit component sum; otherwise inline
+  // compact corrections (4 B/row streamed + exact and add-range side arrays) need the implicit component sum; otherwise inline
   ix->layout = (ix->want_compact && !ix->has_x1) ? kLayoutCompact : kLayoutInline;
   ix->tile_stride = tile_stride_of(ix->w16, ix->layout, ix->has_x1);
   ix->bytes_per_row = ix->tile_stride / kTileRows;
