@@ -1,5 +1,7 @@
 """GPU parity: the HIP path, called through the C ABI, against the pinned oracle and the golden vectors.
 Bit-exact: integer qcDist, f64 score, f32 score, top-k indices AND their order (ties included)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -853,7 +855,7 @@ def test_load_rejects_damaged_files(tmp_path):
 
 # ---------------------------------------------------------------- randomized sweep of shapes and options
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BBQ_FUZZ_SEEDS", "24"))))   # BBQ_FUZZ_SEEDS=400 for a soak
 def test_fuzz_shapes_options_vs_oracle(seed):
     """random (n, dim, k, queryBits, similarity, layout, segment plan, sweep sharing, data flavour) against the oracle:
     index bytes, per-row integers and f64 scores, and the replayed top-k incl. order"""
