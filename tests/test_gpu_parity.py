@@ -1022,3 +1022,44 @@ def test_sharded_scan_cluster_ordered_rows(squeeze):
         np.testing.assert_array_equal(canon32(sc[qi, :cnt[qi]]), canon32(osc))
     assert (not squeeze) or flagged.any()
     assert squeeze or not flagged.any()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BBQ_FUZZ_MEDIUM_SEEDS", "8"))))
+def test_fuzz_medium_sizes_vs_oracle(seed):
+    """the same sweep at sizes where every segment of the plan, the flood tier and the shared sweeps are exercised"""
+    rng = np.random.default_rng(5000 + seed)
+    dim = int(rng.choice([64, 128, 768]))
+    n = int(rng.choice([20000, 70000, 150000, 300000]))
+    sim = int(rng.integers(0, 3))
+    qb = int(rng.choice([1, 4, 4, 8]))
+    k = int(rng.choice([1, 10, 100, 1000, 4096]))
+    ordered = bool(rng.integers(0, 2))
+    ncl = 50
+    centres = rng.standard_normal((ncl, dim)).astype(np.float32)
+    cid = rng.integers(0, ncl, n)
+    if ordered:
+        cid = np.sort(cid)
+    base = centres[cid] + 0.5 * rng.standard_normal((n, dim)).astype(np.float32)
+    base *= np.exp(0.5 * rng.standard_normal((n, 1))).astype(np.float32)      # norms vary inside every tile
+    nq = int(rng.integers(3, 40))
+    queries = centres[rng.integers(0, ncl, nq)] + 0.5 * rng.standard_normal((nq, dim)).astype(np.float32)
+    ix, codes, corr, cen = B.Index.build(base, sim)
+    ocodes, ocorr, ocen = O.build_index(base, sim)
+    np.testing.assert_array_equal(codes, ocodes)
+    np.testing.assert_array_equal(canon64(corr), canon64(ocorr))
+    cdp = B.centroid_dp(cen)
+    try:
+        ix.set_option("segment_growth", int(rng.choice([4, 8, 16])))
+        ix.set_option("replay_threads", 4)
+        share = int(rng.choice([1, 1, 8, 32]))
+        ix.set_option("sweep_share", share)
+        qq, qc = B.quantize_queries(queries, cen, sim, qb)
+        idx, sc, cnt = ix.search_batch(qq, qc, qb, sim, k)
+        for i in range(nq):
+            d, s64, s32 = O.score_all(codes, corr, dim, qq[i], qc[i], qb, sim, cdp)
+            oi, osc = O.heap_topk(s32, k)
+            np.testing.assert_array_equal(idx[i, :cnt[i]], oi)
+            np.testing.assert_array_equal(canon32(sc[i, :cnt[i]]), canon32(osc))
+        assert ix.stats()["dense_fallbacks"] == 0
+    finally:
+        ix.close()
