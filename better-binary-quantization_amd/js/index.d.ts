@@ -25,6 +25,8 @@ export declare class OptimizedScalarQuantizer {
 }
 export declare class BinaryQuantizedScorer {
   constructor(similarityFunction: VectorSimilarityFunction);
+  /** the single-row path of the reference (src/binaryQuantizedScorer.ts:69-301): host arithmetic, queryBits 1 or 4 */
+  computeQuantizedScore(quantizedQuery: Uint8Array, queryCorrections: QuantizationResult, targetVectors: BinarizedByteVectorValues, targetOrd: number, queryBits: number, originalQueryVector?: Float32Array): QuantizedScoreResult;
   computeBatchQuantizedScores(quantizedQuery: Uint8Array, queryCorrections: QuantizationResult, targetVectors: BinarizedByteVectorValues,
     targetOrds: number[], queryBits: number): QuantizedScoreResult[];
 }

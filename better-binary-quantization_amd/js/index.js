@@ -156,6 +156,33 @@ class OptimizedScalarQuantizer {
 /** BinaryQuantizedScorer as far as the search path uses it (src/binaryQuantizedScorer.ts:315-420) */
 class BinaryQuantizedScorer {
   constructor(similarityFunction) { this.similarityFunction = similarityFunction; }
+  /**
+   * computeQuantizedScore(quantizedQuery, queryCorrections, targetVectors, targetOrd, queryBits, originalQueryVector?)
+   * src/binaryQuantizedScorer.ts:69-301: the single-row path the reference falls back to.  Host arithmetic only (one row);
+   * for 4-bit queries it is defined differently from the batch path: centroidDP = query . centroid if the original query is
+   * given and 0 otherwise, and MAXIMUM_INNER_PRODUCT is scaled without FOUR_BIT_SCALE.
+   */
+  computeQuantizedScore(quantizedQuery, queryCorrections, targetVectors, targetOrd, queryBits, originalQueryVector) {
+    if (queryBits !== 1 && queryBits !== 4) throw new Error('不支持的查询位数: ' + queryBits + '，只支持1位和4位');
+    const qcDist = computeQuantizedDotProduct(quantizedQuery, targetVectors.getUnpackedVector(targetOrd));
+    const ic = targetVectors.getCorrectiveTerms(targetOrd), dimension = targetVectors.dimension();
+    const x1 = ic.quantizedComponentSum, ax = ic.lowerInterval, lx = ic.upperInterval - ax;
+    const ay = queryCorrections.lowerInterval, y1 = queryCorrections.quantizedComponentSum;
+    const ly = queryBits === 1 ? queryCorrections.upperInterval - ay : (queryCorrections.upperInterval - ay) * FOUR_BIT_SCALE;
+    const centroidDP = queryBits === 1 ? targetVectors.getCentroidDP() : (originalQueryVector ? targetVectors.getCentroidDP(originalQueryVector) : 0);
+    let score = ax * ay * dimension + ay * lx * x1 + ax * ly * y1 + lx * ly * qcDist;
+    const sim = this.similarityFunction;
+    if (sim === VectorSimilarityFunction.EUCLIDEAN) {
+      score = queryCorrections.additionalCorrection + ic.additionalCorrection - 2 * score;
+      score = Math.max(1 / (1 + score), 0);
+    } else if (sim === VectorSimilarityFunction.COSINE || sim === VectorSimilarityFunction.MAXIMUM_INNER_PRODUCT) {
+      if (queryBits === 1) score += queryCorrections.additionalCorrection + ic.additionalCorrection - centroidDP;
+      else score = score + queryCorrections.additionalCorrection + ic.additionalCorrection - centroidDP;
+      score = sim === VectorSimilarityFunction.COSINE ? Math.max((1 + score) / 2, 0) : (score < 0 ? 1 / (1 - score) : score + 1);
+    } else throw new Error('不支持的相似性函数: ' + sim);
+    return { score: score, bitDotProduct: qcDist, corrections: { query: queryCorrections, index: ic } };
+  }
+
   /** computeBatchQuantizedScores(quantizedQuery, queryCorrections, targetVectors, targetOrds, queryBits) */
   computeBatchQuantizedScores(quantizedQuery, queryCorrections, targetVectors, targetOrds, queryBits) {
     if (targetOrds.length === 0) return [];

@@ -176,6 +176,17 @@ function runCase(c) {
         rec.topk.push({ k: ks[kk], idx_i32: b64(idx), score_f32: b64(s32) });
       } catch (e) { rec.topk.push({ k: ks[kk], error: String(e.message) }); }
     }
+    if (c.qb === 1 || c.qb === 4) {
+      // the single-row scorer (src/binaryQuantizedScorer.ts:69-301; fallback path, defined differently from the batch path for
+      // 4-bit queries: centroidDP = query . centroid when the original query is passed, 0 otherwise)
+      const rows = Math.min(n, 6), a = new Float64Array(rows), b = new Float64Array(rows), dots = new Int32Array(rows);
+      for (let i = 0; i < rows; i++) {
+        const r0 = format.getScorer().computeQuantizedScore(qq.quantizedQuery, qq.queryCorrections, index, i, c.qb);
+        const r1 = format.getScorer().computeQuantizedScore(qq.quantizedQuery, qq.queryCorrections, index, i, c.qb, query);
+        a[i] = r0.score; b[i] = r1.score; dots[i] = r0.bitDotProduct;
+      }
+      rec.single_row = { score_f64: b64(a), score_with_query_f64: b64(b), dot_i32: b64(dots) };
+    }
     if (c.oversample) {
       const r = getOversampledTopKWithHeap(query, index, base, c.k, c.oversample, format);
       rec.oversample = { factor: c.oversample, idx: r.map(function (x) { return x.index; }) };

@@ -67,6 +67,16 @@ T.goldenNames().filter(function (n) { return !/^(intdot_|api_|rerank_|big_)/.tes
     T.check(T.sameBits(r.quantizedQuery, T.dec(rec.qquant_u8, Uint8Array)), name + ': quantized query ' + qi);
     const c = r.queryCorrections;
     T.check(T.sameBits(new Float64Array([c.lowerInterval, c.upperInterval, c.additionalCorrection, c.quantizedComponentSum]), T.dec(rec.qcorr_f64, Float64Array)), name + ': query corrections ' + qi);
+    if (rec.single_row) {   // the reference's single-row scorer, with and without the original query
+      const want0 = T.dec(rec.single_row.score_f64, Float64Array), want1 = T.dec(rec.single_row.score_with_query_f64, Float64Array);
+      const wantd = T.dec(rec.single_row.dot_i32, Int32Array), got0 = new Float64Array(want0.length), got1 = new Float64Array(want0.length), gotd = new Int32Array(want0.length);
+      for (let i = 0; i < want0.length; i++) {
+        const a = fmt.getScorer().computeQuantizedScore(r.quantizedQuery, c, index, i, g.qb);
+        got0[i] = a.score; gotd[i] = a.bitDotProduct;
+        got1[i] = fmt.getScorer().computeQuantizedScore(r.quantizedQuery, c, index, i, g.qb, io.queries[qi]).score;
+      }
+      T.check(T.sameBits(got0, want0) && T.sameBits(got1, want1) && T.sameBits(gotd, wantd), name + ': computeQuantizedScore (single row) ' + qi);
+    }
   }
 });
 // packAsBinary known answer (rust-wasm/src/optimized_scalar_quantizer.rs:321-327)
