@@ -135,6 +135,69 @@ def cpu_baseline(dim, k, codes, corr, qq, qc, cdp, qb, sim, budget_s=20.0):
     return us_per_row, done, rows, dt
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks (one per GPU) with torch.distributed.run
+    as a FRESH child process - before this process has made any GPU/HIP call - relay rank 0's JSON line (the children inherit
+    stdout) and return the children's exit code.  Returns None when this process is itself a rank (or N == 1).
+    Never prints a line that claims N GPUs while measuring fewer: a launcher/flag mismatch or too few devices is an error."""
+    import subprocess
+    in_group = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if in_group:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            log("bench.py: launched with WORLD_SIZE=%d but --gpus %d: refusing to print a mislabelled line" % (world, args.gpus))
+            return 2
+        return None
+    if args.gpus < 1:
+        log("bench.py: --gpus must be >= 1")
+        return 2
+    if args.gpus == 1:
+        return None
+    if not (args.dry_run or args.same_device):
+        import torch  # importing torch and counting devices does not initialise the GPU runtime
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            log("bench.py: --gpus %d but only %d HIP device(s) visible" % (args.gpus, ndev))
+            return 3
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    # the ranks' stdout is filtered: the JSON line goes to stdout, library chatter (gloo prints its connection report there) to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def dry_run(args):
+    """the launch path and the group plumbing of a run, with no device and no measurement"""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+        t = torch.tensor([0.001 * (1 + dist.get_rank())], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        ranks, backend, rank = dist.get_world_size(), dist.get_backend(), dist.get_rank()
+        dist.destroy_process_group()
+    else:
+        ranks, backend, rank = 1, None, 0
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launch rehearsal, nothing measured)", "value": None, "unit": "queries/s", "n_gpus": ranks,
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "ranks": ranks, "backend": backend}), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,7 +223,16 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1: nccl (= RCCL) or gloo (rehearsal)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the sharded code path (process group, collectives) even with one rank")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch rehearsal without a device: start the ranks, form the process group, run the barriers and the max-over-ranks "
+                         "reduction, print the line with value null - NO measurement is made (CPU test of the --gpus N launch path)")
     args = ap.parse_args()
+
+    rc = self_launch(args)
+    if rc is not None:
+        raise SystemExit(rc)
+    if args.dry_run:
+        raise SystemExit(dry_run(args))
 
     import torch
     import bbq_amd as B
@@ -185,8 +257,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(args.backend)
-    if world != args.gpus:
-        log("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if world != args.gpus:   # self_launch() has already refused this; kept as a guard for callers that bypass main()
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     device = local if world > 1 else 0
     if B.device_count() < 1:
         raise SystemExit("bench.py: no HIP device (libbbq has no CPU fallback)")
@@ -304,6 +376,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "bbq_scan_kernel (largest segment launch)",
                          "bytes_per_launch": launch_bytes, "avg_launch_ms": launch_ms, "launches_timed": st["total_scan_launches"]},
+            "ranks": dist.get_world_size() if dist is not None else 1, "backend": (dist.get_backend() if dist is not None else None),
             "end_to_end_hbm_frac": (qps * (N / world) * bytes_per_row / 1e9) / HBM_PEAK_GBS,
             "candidates_per_query": st["candidates"] / float(Q) if dist is None else None,
             "dense_fallbacks": st["dense_fallbacks"],
