@@ -340,6 +340,62 @@ void orc_score_all(const uint8_t *codes, const double *corr, int64_t n, int dim,
   free(qp);
 }
 
+/* ------------------------------------------------------------------ multi-bit index (indexBits > 1) */
+
+/* src/binaryQuantizedScorer.ts:108-160 (computeOneBitSimilarityScore) and :171-214 (computeFourBitSimilarityScore): the formulas
+ * of the PER-ROW scorer, which is what answers for indexBits > 1 (the batch scorer throws on unpacked rows and
+ * computeBatchQuantizedScores falls back, :403-419).  They differ from the batch forms above for 4-bit queries: MIP goes through
+ * scaleMaxInnerProductScore (src/utils.ts:171-176) WITHOUT the division by FOUR_BIT_SCALE (:207-209). */
+double orc_score_single_row(int32_t qcdist, const double q[4], const double x[4], int dim, double cdp, int sim, int one_bit) {
+  const double FBS = 1.0 / 15.0;
+  double x1 = x[3], ax = x[0], lx = x[1] - ax;
+  double ay = q[0], y1 = q[3];
+  double ly = one_bit ? (q[1] - ay) : (q[1] - ay) * FBS;                       /* :122 / :186 */
+  double score = ax * ay * (double)dim + ay * lx * x1 + ax * ly * y1 + lx * ly * (double)qcdist;   /* :126-129 / :190 */
+  if (sim == ORC_EUCLIDEAN) {
+    double e = q[2] + x[2] - 2 * score;                                        /* :134-137 / :194-197 */
+    return js_max(1 / (1 + e), 0);
+  }
+  double t;
+  if (one_bit) t = score + (q[2] + x[2] - cdp);                                /* `score += ...`, :141-143 / :148-150 */
+  else t = score + q[2] + x[2] - cdp;                                          /* :201-203 */
+  if (sim == ORC_COSINE) return js_max((1 + t) / 2, 0);
+  return t < 0 ? 1 / (1 - t) : t + 1;                                          /* scaleMaxInnerProductScore */
+}
+
+/* computeBatchQuantizedScores (src/binaryQuantizedScorer.ts:315-420) as it behaves for indexBits > 1, rows = unpacked bytes
+ * (src/binaryQuantizationFormat.ts:241-245):
+ *  - createDirectPackedBuffer allocates ceil(dim/8) bytes per row and set()s dim bytes per row (src/batchDotProduct.ts:425-433):
+ *    a RangeError for every dim > 1 -> catch -> per-row computeQuantizedScore (:403-419)
+ *  - per row: queryBits 1 -> one-bit formula with centroidDP = centroid.centroid (:238-244); queryBits 4 -> four-bit formula with
+ *    centroidDP = 0 because searchNearestNeighbors passes no original query (:290); anything else throws (:96) -> returns -1
+ *  - dim == 1 is the one width where nothing throws: the batch kernels read the unpacked byte as a packed one (bit 7) and the
+ *    batch formulas apply
+ * qcDist = computeQuantizedDotProduct over the unpacked bytes (src/bitwiseDotProduct.ts:14-30). */
+int orc_score_all_multibit(const uint8_t *codes, const double *corr, int64_t n, int dim,
+                           const uint8_t *qquant, const double qcorr[4], int qb, int sim, double cdp_centroid,
+                           int32_t *qcdist, double *score64, float *score32) {
+  if (dim == 1) {
+    for (int64_t i = 0; i < n; i++) {
+      int32_t d = (qb == 1) ? (int32_t)bitcount32((uint32_t)(((qquant[0] & 1) << 7) & codes[i])) : (int32_t)qquant[0] * ((codes[i] >> 7) & 1);
+      double s = orc_score(d, qcorr, corr + 4 * i, dim, cdp_centroid, sim, qb == 1);
+      if (qcdist) qcdist[i] = d;
+      if (score64) score64[i] = s;
+      if (score32) score32[i] = (float)s;
+    }
+    return 0;
+  }
+  if (qb != 1 && qb != 4) return -1;                                           /* :95-97 */
+  for (int64_t i = 0; i < n; i++) {
+    int32_t d = orc_dot_u8(qquant, codes + i * dim, dim);
+    double s = orc_score_single_row(d, qcorr, corr + 4 * i, dim, qb == 1 ? cdp_centroid : 0.0, sim, qb == 1);
+    if (qcdist) qcdist[i] = d;
+    if (score64) score64[i] = s;
+    if (score32) score32[i] = (float)s;
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------ MinHeap (src/minHeap.ts:9-130) */
 
 typedef struct { double score; int32_t index; } heap_item;
@@ -409,6 +465,27 @@ int64_t orc_search(const float *query, int query_dim, const uint8_t *codes, cons
   float *s32 = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
   orc_score_all(codes, corr, n, dim, qq, qcorr, qb, sim, cdp, NULL, NULL, s32);
   int64_t cnt = orc_heap_topk(s32, n, k, out_idx, out_score);
+  free(s32); free(qq);
+  return cnt;
+}
+
+/* searchNearestNeighbors on an indexBits > 1 index; -5 where the reference throws '不支持的查询位数' */
+int64_t orc_search_multibit(const float *query, int query_dim, const uint8_t *codes, const double *corr, const float *centroid,
+                            int64_t n, int dim, int sim, int qb, double lambda, int iters, int64_t k,
+                            int32_t *out_idx, float *out_score) {
+  if (!query) return -1;
+  if (!codes) return -2;
+  if (k < 0) return -3;
+  if (query_dim != dim) return -4;
+  if (k == 0) return 0;
+  uint8_t *qq = (uint8_t *)malloc((size_t)(dim > 0 ? dim : 1));
+  double qcorr[4];
+  orc_quantize_query(query, dim, centroid, sim, qb, lambda, iters, qq, qcorr);
+  double cdp = orc_dot_f32(centroid, centroid, dim);
+  float *s32 = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+  int64_t cnt = -5;
+  if (orc_score_all_multibit(codes, corr, n, dim, qq, qcorr, qb, sim, cdp, NULL, NULL, s32) == 0)
+    cnt = orc_heap_topk(s32, n, k, out_idx, out_score);
   free(s32); free(qq);
   return cnt;
 }

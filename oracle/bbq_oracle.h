@@ -73,6 +73,19 @@ void orc_score_all(const uint8_t *codes, const double *corr, int64_t n, int dim,
                    const uint8_t *qquant, const double qcorr[4], int qb, int sim, double centroid_dp,
                    int32_t *qcdist /* may be NULL */, double *score64 /* may be NULL */, float *score32 /* may be NULL */);
 
+/* indexBits > 1 (rows unpacked, one byte per dim): the per-row scorer's formulas (src/binaryQuantizedScorer.ts:108-214) ... */
+double orc_score_single_row(int32_t qcdist, const double qcorr[4], const double xcorr[4], int dim, double centroid_dp,
+                            int sim, int one_bit);
+/* ... and computeBatchQuantizedScores as it behaves on such an index (batch path throws -> per-row fallback, :403-419;
+ * centroidDP = 0 for 4-bit queries, :290).  Returns -1 where the reference throws (queryBits other than 1 and 4). */
+int orc_score_all_multibit(const uint8_t *codes_unpacked, const double *corr, int64_t n, int dim,
+                           const uint8_t *qquant, const double qcorr[4], int qb, int sim, double centroid_dp,
+                           int32_t *qcdist, double *score64, float *score32);
+/* orc_search on an indexBits > 1 index (codes unpacked); -5 where the reference throws on the queryBits */
+int64_t orc_search_multibit(const float *query, int query_dim, const uint8_t *codes_unpacked, const double *corr,
+                            const float *centroid, int64_t n, int dim, int sim, int qb, double lambda, int iters, int64_t k,
+                            int32_t *out_idx, float *out_score);
+
 /* src/binaryQuantizationFormat.ts:383-411 with src/minHeap.ts:9-130 restated exactly.
  * returns the number of results written (min(k, n)). */
 int64_t orc_heap_topk(const float *scores, int64_t n, int64_t k, int32_t *out_idx, float *out_score);

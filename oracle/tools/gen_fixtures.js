@@ -366,11 +366,51 @@ cases.push({ name: 'big_50000x768_cos', sim: 'COSINE', qb: 4, ib: 1, lambda: 0.1
 cases.push({ name: 'big_30000x1536_mip', sim: 'MAXIMUM_INNER_PRODUCT', qb: 4, ib: 1, lambda: 0.1, iters: 5, dim: 1536, n: 30000, k: 100, ks: [100], nq: 1, full: false,
   gen: { kind: 'mulberry32', base_seed: 41, query_seed: 42 } });
 
+// dim 1024 (BASELINE config 5's width): the compile-time 8-chunk kernel instantiations
+cases.push({ name: 'm_1024d_cos_qb4', sim: 'COSINE', qb: 4, ib: 1, lambda: 0.1, iters: 5, dim: 1024, n: 200, k: 10, ks: [1, 10, 100], nq: 2, full: true,
+  gen: { kind: 'mulberry32', base_seed: 401, query_seed: 402 } });
+cases.push({ name: 'm_1024d_euc_qb1', sim: 'EUCLIDEAN', qb: 1, ib: 1, lambda: 0.1, iters: 5, dim: 1024, n: 200, k: 10, ks: [1, 10, 100], nq: 2, full: true,
+  gen: { kind: 'mulberry32', base_seed: 403, query_seed: 404 } });
+cases.push({ name: 'm_1024d_max_qb8', sim: 'MAXIMUM_INNER_PRODUCT', qb: 8, ib: 1, lambda: 0.1, iters: 5, dim: 1024, n: 200, k: 10, ks: [1, 10, 100], nq: 2, full: true,
+  gen: { kind: 'mulberry32', base_seed: 405, query_seed: 406 } });
+cases.push({ name: 'big_20000x1024_cos', sim: 'COSINE', qb: 4, ib: 1, lambda: 0.1, iters: 5, dim: 1024, n: 20000, k: 100, ks: [100], nq: 2, full: false,
+  gen: { kind: 'mulberry32', base_seed: 407, query_seed: 408 } });
+cases.push({ name: 'big_20000x1024_euc_qb8', sim: 'EUCLIDEAN', qb: 8, ib: 1, lambda: 0.1, iters: 5, dim: 1024, n: 20000, k: 100, ks: [100], nq: 1, full: false,
+  gen: { kind: 'mulberry32', base_seed: 409, query_seed: 410 } });
+// multi-bit index (indexBits > 1): rows are unpacked bytes (src/binaryQuantizationFormat.ts:241-245), the batch scorer throws on
+// them and the reference answers through its per-row fallback (src/binaryQuantizedScorer.ts:403-419, :69-301) for queryBits 1
+// and 4 (centroidDP = 0 for 4-bit queries, SURVEY A.7); every other queryBits makes searchNearestNeighbors throw
+seed = 500;
+[[2, 64, 300], [2, 100, 257], [4, 96, 200], [3, 72, 130], [8, 64, 150], [2, 1024, 120]].forEach(function (bdn) {
+  SIMS.forEach(function (sim) {
+    [1, 4].forEach(function (qb) {
+      if (bdn[0] !== 2 && !(sim === 'COSINE' && qb === 4) && !(sim === 'MAXIMUM_INNER_PRODUCT' && qb === 1) && !(sim === 'EUCLIDEAN' && qb === 4 && bdn[0] === 4)) { seed += 2; return; }
+      if (bdn[1] === 1024 && !((sim === 'COSINE' && qb === 4) || (sim === 'EUCLIDEAN' && qb === 1))) { seed += 2; return; }
+      cases.push({ name: 'ib' + bdn[0] + '_' + bdn[1] + 'd_' + sim.slice(0, 3).toLowerCase() + '_qb' + qb, sim: sim, qb: qb, ib: bdn[0], lambda: 0.1, iters: 5,
+        dim: bdn[1], n: bdn[2], k: 10, ks: [1, 10, 100], nq: 2, full: true, gen: { kind: 'mulberry32', base_seed: seed, query_seed: seed + 1 } });
+      seed += 2;
+    });
+  });
+});
+cases.push({ name: 'ib2_ties_cos_qb4', sim: 'COSINE', qb: 4, ib: 2, lambda: 0.1, iters: 5, dim: 64, n: 3000, k: 100, ks: [1, 7, 100, 500], nq: 2, full: false,
+  gen: { kind: 'dup_pool', base_seed: 600, pick_seed: 601, query_seed: 602, pool: 40 } });
+cases.push({ name: 'ib2_big_20000x128_euc', sim: 'EUCLIDEAN', qb: 4, ib: 2, lambda: 0.1, iters: 5, dim: 128, n: 20000, k: 100, ks: [100], nq: 1, full: false,
+  gen: { kind: 'mulberry32', base_seed: 603, query_seed: 604 } });
+// queryBits the fallback does not know: the reference throws (recorded as such)
+cases.push({ name: 'ib2_64d_cos_qb8_throws', sim: 'COSINE', qb: 8, ib: 2, lambda: 0.1, iters: 5, dim: 64, n: 50, k: 5, nq: 1, full: true,
+  gen: { kind: 'mulberry32', base_seed: 605, query_seed: 606 } });
+// dim 1: the one width where the batch scorer does NOT throw on unpacked rows (dim == ceil(dim/8))
+cases.push({ name: 'ib2_edge_dim1', sim: 'MAXIMUM_INNER_PRODUCT', qb: 4, ib: 2, lambda: 0.1, iters: 5, dim: 1, n: 6, k: 3, nq: 1, full: true,
+  gen: { kind: 'inline', base: [[0.5], [-0.5], [2], [3], [-7], [0.25]], queries: [[1.5]] } });
+
 const only = process.env.BBQ_ONLY ? new RegExp(process.env.BBQ_ONLY) : null;
 fs.mkdirSync(OUT, { recursive: true });
 cases.forEach(function (c) { if (!only || only.test(c.name)) runCase(c); });
 if (!only || only.test('intdot')) {
   runIntDot({ name: 'intdot_ib2_qb8_64d', sim: 'EUCLIDEAN', qb: 8, ib: 2, dim: 64, n: 200, nq: 2, base_seed: 51, query_seed: 52 });
+  runIntDot({ name: 'intdot_ib2_qb8_1024d', sim: 'COSINE', qb: 8, ib: 2, dim: 1024, n: 120, nq: 2, base_seed: 55, query_seed: 56 });
+  runIntDot({ name: 'intdot_ib4_qb8_96d', sim: 'MAXIMUM_INNER_PRODUCT', qb: 8, ib: 4, dim: 96, n: 120, nq: 2, base_seed: 57, query_seed: 58 });
+  runIntDot({ name: 'intdot_ib8_qb8_72d', sim: 'EUCLIDEAN', qb: 8, ib: 8, dim: 72, n: 100, nq: 2, base_seed: 59, query_seed: 60 });
   runIntDot({ name: 'intdot_ib2_qb4_100d', sim: 'COSINE', qb: 4, ib: 2, dim: 100, n: 150, nq: 2, base_seed: 53, query_seed: 54 });
 }
 if (!only || only.test('rerank')) {

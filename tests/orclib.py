@@ -53,6 +53,13 @@ def lib():
         L.orc_score.argtypes = [C.c_int32, f64p, f64p, C.c_int, C.c_double, C.c_int, C.c_int]
         L.orc_score.restype = C.c_double
         L.orc_score_all.argtypes = [u8p, f64p, C.c_int64, C.c_int, u8p, f64p, C.c_int, C.c_int, C.c_double, i32p, f64p, f32p]
+        L.orc_score_single_row.argtypes = [C.c_int32, f64p, f64p, C.c_int, C.c_double, C.c_int, C.c_int]
+        L.orc_score_single_row.restype = C.c_double
+        L.orc_score_all_multibit.argtypes = [u8p, f64p, C.c_int64, C.c_int, u8p, f64p, C.c_int, C.c_int, C.c_double, i32p, f64p, f32p]
+        L.orc_score_all_multibit.restype = C.c_int
+        L.orc_search_multibit.argtypes = [f32p, C.c_int, u8p, f64p, f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                          C.c_int64, i32p, f32p]
+        L.orc_search_multibit.restype = C.c_int64
         L.orc_heap_topk.argtypes = [f32p, C.c_int64, C.c_int64, i32p, f32p]
         L.orc_heap_topk.restype = C.c_int64
         L.orc_search.argtypes = [f32p, C.c_int, u8p, f64p, f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
@@ -100,7 +107,9 @@ def mulberry32(seed, count):
     return out
 
 
-def build_index(base, sim, lam=0.1, iters=5):
+def build_index(base, sim, lam=0.1, iters=5, ib=1):
+    if ib != 1:
+        return build_index_unpacked(base, sim, ib, lam, iters)
     base = np.ascontiguousarray(base, np.float32)
     n, dim = base.shape
     pb = (dim + 7) // 8
@@ -134,13 +143,24 @@ def centroid_dp(cen):
     return lib().orc_dot_f32(f32p(cen), f32p(cen), cen.shape[0])
 
 
-def score_all(codes, corr, dim, qq, qc, qb, sim, cdp):
+class ReferenceThrows(Exception):
+    """the reference throws on this input (e.g. indexBits > 1 with queryBits other than 1 and 4)"""
+
+
+def score_all(codes, corr, dim, qq, qc, qb, sim, cdp, ib=1):
+    """ib > 1: codes are unpacked [n, dim]; cdp is centroid.centroid either way (the multi-bit path decides what it uses)"""
     n = codes.shape[0]
     d = np.zeros(n, np.int32)
     s64 = np.zeros(n, np.float64)
     s32 = np.zeros(n, np.float32)
     codes = np.ascontiguousarray(codes)
     corr = np.ascontiguousarray(corr)
+    if ib != 1:
+        assert codes.shape[1] == dim
+        rc = lib().orc_score_all_multibit(u8p(codes), f64p(corr), n, dim, u8p(qq), f64p(qc), qb, sim, cdp, i32p(d), f64p(s64), f32p(s32))
+        if rc != 0:
+            raise ReferenceThrows("不支持的查询位数: %d，只支持1位和4位" % qb)
+        return d, s64, s32
     lib().orc_score_all(u8p(codes), f64p(corr), n, dim, u8p(qq), f64p(qc), qb, sim, cdp, i32p(d), f64p(s64), f32p(s32))
     return d, s64, s32
 
@@ -155,14 +175,15 @@ def heap_topk(s32, k):
     return idx[:cnt].copy(), sc[:cnt].copy()
 
 
-def search(query, codes, corr, cen, sim, qb, k, lam=0.1, iters=5):
+def search(query, codes, corr, cen, sim, qb, k, lam=0.1, iters=5, ib=1):
     query = np.ascontiguousarray(query, np.float32)
     n = codes.shape[0]
     dim = cen.shape[0]
     m = max(min(k, n), 0)
     idx = np.zeros(m + 1, np.int32)
     sc = np.zeros(m + 1, np.float32)
-    cnt = lib().orc_search(f32p(query), query.shape[0], u8p(codes), f64p(corr), f32p(cen), n, dim, sim, qb, lam, iters, k,
+    fn = lib().orc_search if ib == 1 else lib().orc_search_multibit
+    cnt = fn(f32p(query), query.shape[0], u8p(codes), f64p(corr), f32p(cen), n, dim, sim, qb, lam, iters, k,
                            i32p(idx), f32p(sc))
     if cnt < 0:
         return cnt, None

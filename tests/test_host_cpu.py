@@ -19,9 +19,9 @@ def test_product_quantizer_matches_reference(name):
     g = O.load_golden(name)
     sim = O.SIMS[g["sim"]]
     base, queries = O.golden_inputs(g)
-    codes, corr, cen = B.quantize_vectors(base, sim, 1, g["lambda"], g["iters"], n_threads=3)
+    codes, corr, cen = B.quantize_vectors(base, sim, g["ib"], g["lambda"], g["iters"], n_threads=3)
     assert O.sha(codes) == g["codes_sha256"]
-    ocodes, ocorr, ocen = O.build_index(base, sim, g["lambda"], g["iters"])
+    ocodes, ocorr, ocen = O.build_index(base, sim, g["lambda"], g["iters"], g["ib"])
     np.testing.assert_array_equal(canon64(corr), canon64(ocorr))
     assert O.sha(cen) == O.sha(O.dec(g["centroid_f32"], "<f4"))
     for qi, rec in enumerate(g["queries"]):
