@@ -58,6 +58,28 @@ def synth_rows(seed, row0, row1, pb):
     return codes, corr
 
 
+def synth_rows_multibit(seed, row0, row1, dim, ib):
+    """rows [row0,row1) of a synthetic multi-bit index as quantizeVectors hands them over for indexBits > 1: one byte per dimension,
+    uniform values < 2^ib (src/binaryQuantizationFormat.ts:241-245), quantizedComponentSum = the sum of the row's codes"""
+    codes = np.empty((row1 - row0, dim), np.uint8)
+    corr = np.empty((row1 - row0, 4), np.float64)
+    r = row0
+    while r < row1:
+        c0 = r // CHUNK
+        lo, hi = c0 * CHUNK, (c0 + 1) * CHUNK
+        rng = np.random.default_rng([seed, c0, ib])
+        cc = rng.integers(0, 1 << ib, size=(CHUNK, dim), dtype=np.uint8)
+        u = rng.random((CHUNK, 3))
+        a, b = max(r, lo), min(row1, hi)
+        codes[a - row0:b - row0] = cc[a - lo:b - lo]
+        corr[a - row0:b - row0, 0] = -0.04 * (0.9 + 0.2 * u[a - lo:b - lo, 0])
+        corr[a - row0:b - row0, 1] = 0.04 * (0.9 + 0.2 * u[a - lo:b - lo, 1])
+        corr[a - row0:b - row0, 2] = 1e-4 * (2 * u[a - lo:b - lo, 2] - 1)
+        corr[a - row0:b - row0, 3] = cc[a - lo:b - lo].sum(axis=1, dtype=np.int64)
+        r = b
+    return codes, corr
+
+
 def synth_queries(seed, nq, dim, qb=4):
     rng = np.random.default_rng([seed, 777])
     qq = rng.integers(0, 1 << qb, size=(nq, dim), dtype=np.uint8)
@@ -116,16 +138,26 @@ def recall_probe(B, device, n=1_000_000, dim=768, nq=32, k=100):
                         "recall_at_100_oversample3_rerank": float(rec3), "oversample3_rerank_ms_per_query": round(rerank_ms, 3)}
 
 
-def cpu_baseline(dim, k, codes, corr, qq, qc, cdp, qb, sim, budget_s=20.0):
+def oracle_scores(O, codes, corr, dim, qq, qc, qb, sim, cdp, ib):
+    """the checker's f32 scores of every row: the pinned restatement of the reference where the reference answers, the documented
+    extension (per-row 4-bit form over computeQuantizedDotProduct) where it throws (multi-bit index, queryBits other than 1 / 4)"""
+    if ib == 1:
+        return O.score_all(codes, corr, dim, qq, qc, qb, sim, cdp)[2]
+    if qb in (1, 4):
+        return O.score_all(codes, corr, dim, qq, qc, qb, sim, cdp, ib)[2]
+    return O.score_all_multibit_ext(codes, corr, dim, qq, qc, qb, sim, cdp)[2]
+
+
+def cpu_baseline(dim, k, codes, corr, qq, qc, cdp, qb, sim, ib=1, budget_s=20.0):
     """the oracle (CPU restatement of the reference loops, 1 thread) on a bounded sample of the same workload"""
     import orclib as O
     n = codes.shape[0]
-    rows = min(n, 2_000_000)
+    rows = min(n, 2_000_000 if ib == 1 else 1_000_000)
     c, r = np.ascontiguousarray(codes[:rows]), np.ascontiguousarray(corr[:rows])
     t0 = time.perf_counter()
     done = 0
     while True:
-        _, _, s32 = O.score_all(c, r, dim, qq[done % len(qq)], qc[done % len(qq)], qb, sim, cdp)
+        s32 = oracle_scores(O, c, r, dim, qq[done % len(qq)], qc[done % len(qq)], qb, sim, cdp, ib)
         O.heap_topk(s32, k)
         done += 1
         if time.perf_counter() - t0 > budget_s / 2 or done >= 8:
@@ -210,6 +242,10 @@ def main():
                     help="queries per step (each sweeps the index on its own); default 256 on one GPU, 256 x world (512..2048) when sharded")
     ap.add_argument("--sim", default="COSINE", choices=["EUCLIDEAN", "COSINE", "MAXIMUM_INNER_PRODUCT"])
     ap.add_argument("--query-bits", type=int, default=4)
+    ap.add_argument("--index-bits", type=int, default=1, help="2..8: multi-bit index (rows handed over as one byte per dimension)")
+    ap.add_argument("--config", default=None, choices=["c2", "c3", "c4", "c5"],
+                    help="BASELINE.json configs: c2 = 1Mx768 qb4/ib1 k100; c3 = the default (10Mx768); c4 = 10Mx1536 MAXIMUM_INNER_PRODUCT; "
+                         "c5 = 1Mx1024 queryBits 8 / indexBits 2")
     ap.add_argument("--sub-batch", type=int, default=32, help="queries per device launch sequence (pipelined inside a step)")
     ap.add_argument("--slots", type=int, default=3, help="pipeline slots (streams) inside the library")
     ap.add_argument("--replay-threads", type=int, default=16, help="host threads replaying the reference heap")
@@ -227,6 +263,12 @@ def main():
                     help="launch rehearsal without a device: start the ranks, form the process group, run the barriers and the max-over-ranks "
                          "reduction, print the line with value null - NO measurement is made (CPU test of the --gpus N launch path)")
     args = ap.parse_args()
+    if args.config == "c2":
+        args.rows, args.dim = 1_000_000, 768
+    elif args.config == "c4":
+        args.rows, args.dim, args.sim = 10_000_000, 1536, "MAXIMUM_INNER_PRODUCT"
+    elif args.config == "c5":
+        args.rows, args.dim, args.query_bits, args.index_bits = 1_000_000, 1024, 8, 2
 
     rc = self_launch(args)
     if rc is not None:
@@ -270,19 +312,23 @@ def main():
         args.batch = 256 if world == 1 else min(2048, max(512, 256 * world))
     N, dim, k, Q = args.rows, args.dim, args.k, args.batch
     SIM = {"EUCLIDEAN": 0, "COSINE": 1, "MAXIMUM_INNER_PRODUCT": 2}[args.sim]
-    QB = args.query_bits
+    QB, IB = args.query_bits, args.index_bits
     pb = (dim + 7) // 8
     cdp = 0.0009110655808639536
+
+    def rows_of(a, b):
+        return synth_rows(1, a, b, pb) if IB == 1 else synth_rows_multibit(1, a, b, dim, IB)
+
     shard = (N + world - 1) // world
     r0, r1 = min(rank * shard, N), min((rank + 1) * shard, N)
     t0 = time.perf_counter()
-    codes, corr = synth_rows(1, r0, r1, pb)
+    codes, corr = rows_of(r0, r1)
     pilot = None
     if rank > 0:
         P = min(args.pilot, r0) // 1024 * 1024
         if P > 0:
-            pilot = synth_rows(1, 0, P, pb)
-    ix = B.Index(codes, corr, dim, cdp, device=device, row_base=r0,
+            pilot = rows_of(0, P)
+    ix = B.Index(codes, corr, dim, cdp, device=device, index_bits=IB, row_base=r0,
                  pilot_codes=None if pilot is None else pilot[0], pilot_corr=None if pilot is None else pilot[1])
     ix.set_option("batch_queries", min(args.sub_batch, Q))
     ix.set_option("pipeline_slots", args.slots)
@@ -328,7 +374,7 @@ def main():
         dt = float(t.item())
     st = ix.stats()
     batched = None
-    if dist is None and args.shared_sweep in (4, 8, 32):
+    if dist is None and args.shared_sweep in (4, 8, 32) and IB == 1:
         # API extension, reported separately: `shared_sweep` queries share one sweep of the index
         ix.set_option("sweep_share", args.shared_sweep)
         res_b = ix.search_batch(batches[args.warmup][0], batches[args.warmup][1], QB, SIM, k)
@@ -364,12 +410,13 @@ def main():
         out = {
             # BASELINE.json's metric string for the headline configuration; a descriptive one for the other configs
             "metric": ("queries/sec + recall@100 vs fp32 brute-force, 10M\u00d7768 1-bit index, k=100"
-                       if (N, dim, k, QB, args.sim) == (10_000_000, 768, 100, 4, "COSINE")
-                       else "queries/sec, %dx%d 1-bit index, queryBits=%d, k=%d, %s" % (N, dim, QB, k, args.sim)),
+                       if (N, dim, k, QB, IB, args.sim) == (10_000_000, 768, 100, 4, 1, "COSINE")
+                       else "queries/sec, %dx%d %d-bit index, queryBits=%d, k=%d, %s" % (N, dim, IB, QB, k, args.sim)),
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u64 popcount + f64 score epilogue", "data": "synthetic",
-            "config": {"workload": "%dx%d-dim 1-bit index, queryBits=%d, k=%d, %s, row-sharded over %d GPU(s)" % (N, dim, QB, k, args.sim, world),
+            "dtype": "u64 popcount + f64 score epilogue" if IB == 1 else "u4/u8 packed integer dot (u32 accumulate) + f64 score epilogue",
+            "data": "synthetic",
+            "config": {"workload": "%dx%d-dim %d-bit index, queryBits=%d, k=%d, %s, row-sharded over %d GPU(s)" % (N, dim, IB, QB, k, args.sim, world),
                        "queries_per_step": Q, "queries_per_launch": min(args.sub_batch, Q), "sweeps_per_query": 1,
                        "pipeline_slots": args.slots, "replay_threads": args.replay_threads, "bytes_per_row": bytes_per_row,
                        "parallelism": "row-shard x%d" % world},
@@ -384,14 +431,14 @@ def main():
         if batched is not None:
             out["batched"] = batched
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed at N=1 only
-            us_row, done, rows, secs = cpu_baseline(dim, k, codes, corr, qq_all, qc_all, cdp, QB, SIM)
+            us_row, done, rows, secs = cpu_baseline(dim, k, codes, corr, qq_all, qc_all, cdp, QB, SIM, IB)
             out["cpu_baseline"] = {"value": 1e6 / (us_row * N), "unit": "queries/s", "cores": 1, "kind": "port",
                                    "sample": "%d queries x %d rows of the same synthetic index in %.1fs (%.3f us/row), linearly extrapolated to %d rows"
                                              % (done, rows, secs, us_row, N)}
             # the same loops restated in JS, under node on this box's host, 1 core
             import shutil
             import subprocess
-            if shutil.which("node"):
+            if shutil.which("node") and IB == 1:
                 try:
                     r = subprocess.run(["node", os.path.join(ROOT, "oracle", "bbq_oracle_js_baseline.js"), "300000", str(dim), str(k), "3"],
                                        stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
@@ -408,12 +455,15 @@ def main():
             if world == 1:
                 fc, fr = codes, corr
             else:
-                fc, fr = synth_rows(1, 0, N, pb)  # rank 0 rebuilds the whole index for the checker only
-            _, _, s32 = O.score_all(fc, fr, dim, qq_all[args.warmup * Q], qc_all[args.warmup * Q], QB, SIM, cdp)
+                fc, fr = rows_of(0, N)  # rank 0 rebuilds the whole index for the checker only
+            s32 = oracle_scores(O, fc, fr, dim, qq_all[args.warmup * Q], qc_all[args.warmup * Q], QB, SIM, cdp, IB)
             oi, osc = O.heap_topk(s32, k)
             gi, gs, _ = results[args.warmup]
             out["parity_full_size"] = bool((gi[0] == oi).all() and (gs[0].view(np.uint32) == osc.view(np.uint32)).all())
-        if not args.no_recall:
+        if IB != 1 and QB not in (1, 4):
+            out["parity_note"] = ("the reference throws for queryBits=%d on an indexBits=%d index (src/binaryQuantizedScorer.ts:95-97): the integer dot "
+                                  "product is pinned by fixtures of computeQuantizedDotProduct, the float score is its per-row 4-bit form - parity unpinned" % (QB, IB))
+        if not args.no_recall and IB == 1:
             rec, desc = recall_probe(B, device, n=args.recall_rows)
             out["recall_at_100"] = rec
             out["recall_config"] = desc

@@ -132,6 +132,7 @@ int bbq_index_build(const float *vectors, int64_t n, int32_t dim, int32_t sim, d
   sto.view.has_x1 = 0;
   sto.view.dim = dim;
   sto.view.layout = ix->layout;
+  sto.view.store_bits = 1;
   ix->centroid_dp = bbq_centroid_dp(centroid, dim);  // getCentroidDP(undefined), :113-121
   rc = ensure_aux_qbuf(ctx, qbuf_bytes_per_query_w(ix->w16));
   if (rc != BBQ_OK) { destroy_unlocked(ix.release()); return rc; }

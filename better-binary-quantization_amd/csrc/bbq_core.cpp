@@ -126,7 +126,8 @@ namespace {
 int make_storage(bbq_index *ix, Storage &st, const uint8_t *codes, const double *corr, int64_t n_rows, int64_t row_id_base,
                  bool check_x1) {
   const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
-  const int64_t pb = ix->pb;
+  const bool multibit = ix->store_bits > 1;
+  const int64_t pb = multibit ? ix->dim : ix->pb;  // bytes per row as the caller hands them over (multi-bit: one byte per dimension)
   DevMem m_codes, m_corr, m_mis;
   hipStream_t s = ix->aux_stream;
   if (n_rows > 0) {
@@ -144,7 +145,8 @@ int make_storage(bbq_index *ix, Storage &st, const uint8_t *codes, const double 
     HIPCHK(m_mis.alloc(4));
     uint32_t *d_mis = m_mis.as<uint32_t>();
     HIPCHK(hipMemsetAsync(d_mis, 0, 4, s));
-    HIPCHK(launch_check_x1(d_codes, d_corr, n_rows, (int32_t)pb, d_mis, s));
+    if (multibit) HIPCHK(launch_check_x1_multibit(d_codes, d_corr, n_rows, ix->dim, d_mis, s));
+    else HIPCHK(launch_check_x1(d_codes, d_corr, n_rows, (int32_t)pb, d_mis, s));
     HIPCHK(hipMemcpyAsync(&mis, d_mis, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (mis) ix->has_x1 = 1;
@@ -160,10 +162,22 @@ int make_storage(bbq_index *ix, Storage &st, const uint8_t *codes, const double 
   st.view.has_x1 = ix->has_x1;
   st.view.dim = ix->dim;
   st.view.layout = ix->layout;
+  st.view.store_bits = ix->store_bits;
   if (n_tiles > 0) {
     HIPCHK(hipMalloc((void **)&st.d_tiles, (size_t)(n_tiles * ix->tile_stride)));
     if (ix->layout == kLayoutCompact) HIPCHK(hipMalloc((void **)&st.d_exact, (size_t)compact_side_bytes(n_tiles)));
-    HIPCHK(launch_retile(d_codes, d_corr, n_rows, (int32_t)pb, st.d_tiles, ix->w16, ix->tile_stride, ix->has_x1, ix->layout, st.d_exact, s));
+    if (multibit) {
+      uint32_t bad = 0;
+      if (!m_mis.p) HIPCHK(m_mis.alloc(4));
+      HIPCHK(hipMemsetAsync(m_mis.p, 0, 4, s));
+      HIPCHK(launch_retile_multibit(d_codes, d_corr, n_rows, ix->dim, ix->store_bits, st.d_tiles, ix->w16, ix->tile_stride, ix->has_x1, ix->layout,
+                                    st.d_exact, m_mis.as<uint32_t>(), s));
+      HIPCHK(hipMemcpyAsync(&bad, m_mis.p, 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      if (bad) return fail(BBQ_ERR_INVALID_ARG, "indexBits=%d: a quantized value does not fit %d bits", ix->index_bits, ix->store_bits);
+    } else {
+      HIPCHK(launch_retile(d_codes, d_corr, n_rows, (int32_t)pb, st.d_tiles, ix->w16, ix->tile_stride, ix->has_x1, ix->layout, st.d_exact, s));
+    }
     if (ix->layout == kLayoutCompact) HIPCHK(launch_tile_add_range(st.d_exact, n_rows, const_cast<float *>(add_range_of(st.d_exact, n_tiles)), s));
     HIPCHK(hipStreamSynchronize(s));
   }
@@ -343,29 +357,69 @@ int planes_for(const uint8_t *q, int64_t count) {
   return 8;
 }
 
-// writes the bit-planes ([j][p] 16-byte blocks, packed like the rows: dim d -> byte d>>3, bit 7-(d&7)) and the
-// score uniforms of one query into the staging buffer
+// bytes of staged query data per query (bit-planes, or the nibble / byte dwords of a multi-bit index)
+int64_t query_data_bytes(const bbq_index *ix, int planes) { return (int64_t)ix->w16 * query_units_per_chunk(planes, ix->store_bits) * 16; }
+
+// kernel variant for a call: 1-bit index -> number of bit-planes the query values need; multi-bit index -> 4 (values <= 15: low
+// nibbles only) or 8
+int planes_of_call(const bbq_index *ix, const uint8_t *q, int64_t count, int one_bit) {
+  if (ix->store_bits == 1) return one_bit ? 1 : planes_for(q, count);
+  if (ix->store_bits == 8) return 8;
+  return max_value(q, count) <= 15 ? 4 : 8;
+}
+
+// writes the query data and the score uniforms of one query into the staging buffer.
+// 1-bit index: bit-planes ([j][p] 16-byte blocks, packed like the rows: dim d -> byte d>>3, bit 7-(d&7)).
+// multi-bit index: per row dword w the dwords the kernel multiplies its unfolded fields with (dot_chunk_multibit):
+//   store_bits 2: {lo nibbles of dims 16w+0,2,..,14 | lo nibbles of dims 16w+1,3,..,15 [| hi nibbles of the same, planes == 8]}
+//   store_bits 4: {lo nibbles of dims 8w..8w+7 [| hi nibbles]}          store_bits 8: {bytes of dims 4w..4w+3}
 void fill_query(const bbq_index *ix, uint8_t *planes_dst, QueryParams *pp, const uint8_t *q, const double *qc, int planes,
                 int one_bit, int sim) {
-  const int w16 = ix->w16;
-  memset(planes_dst, 0, (size_t)w16 * planes * 16);
-  for (int d = 0; d < ix->dim; ++d) {
-    const uint8_t v = q[d];
-    if (!v) continue;
-    const int byte = d >> 3, j = byte >> 4, b = byte & 15;
-    const uint8_t bit = (uint8_t)(0x80u >> (d & 7));
-    for (int p = 0; p < planes; ++p)
-      if ((v >> p) & 1) planes_dst[((size_t)j * planes + p) * 16 + b] |= bit;
+  memset(planes_dst, 0, (size_t)query_data_bytes(ix, planes));
+  if (ix->store_bits == 1) {
+    for (int d = 0; d < ix->dim; ++d) {
+      const uint8_t v = q[d];
+      if (!v) continue;
+      const int byte = d >> 3, j = byte >> 4, b = byte & 15;
+      const uint8_t bit = (uint8_t)(0x80u >> (d & 7));
+      for (int p = 0; p < planes; ++p)
+        if ((v >> p) & 1) planes_dst[((size_t)j * planes + p) * 16 + b] |= bit;
+    }
+  } else {
+    const int sb = ix->store_bits, per = 32 / sb, qn = query_units_per_chunk(planes, sb);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(planes_dst);
+    for (int d = 0; d < ix->dim; ++d) {
+      const uint32_t v = q[d];
+      if (!v) continue;
+      const int w = d / per, f = d % per;
+      uint32_t *qw = dst + (size_t)w * qn;
+      if (sb == 2) {
+        const int half = f & 1, nib = f >> 1;
+        qw[half] |= (v & 15u) << (4 * nib);
+        if (planes > 4) qw[2 + half] |= (v >> 4) << (4 * nib);
+      } else if (sb == 4) {
+        qw[0] |= (v & 15u) << (4 * f);
+        if (planes > 4) qw[1] |= (v >> 4) << (4 * f);
+      } else {
+        qw[0] |= v << (8 * f);
+      }
+    }
   }
   const double FBS = 1.0 / 15.0;  // src/constants.ts:20
   pp->ay = qc[0];
   pp->ly = one_bit ? (qc[1] - qc[0]) : (qc[1] - qc[0]) * FBS;  // src/batchDotProduct.ts:498 / :574
   pp->y1 = qc[3];
   pp->qadd = qc[2];
-  pp->cdp = ix->centroid_dp;
+  // multi-bit index: the reference's batch scorer throws on unpacked rows and its per-row scorer answers
+  // (src/binaryQuantizedScorer.ts:403-419): centroidDP is 0 for every query width but 1 (searchNearestNeighbors passes no
+  // original query, :290) and MAXIMUM_INNER_PRODUCT is not divided by FOUR_BIT_SCALE (:207-209)
+  const bool per_row_form = ix->store_bits > 1;
+  pp->cdp = (per_row_form && !one_bit) ? 0.0 : ix->centroid_dp;
   pp->dimd = (double)ix->dim;
   pp->sim = sim;
   pp->one_bit = one_bit;
+  pp->mip_plain = per_row_form ? 1 : 0;
+  pp->pad_ = 0;
 }
 
 // MFMA shared sweep: the int8 query values in the order the code bits fall out of the packed words.  For 32-dim word
@@ -416,14 +470,14 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
                      int32_t *d_counts_ext) {
   bbq_index *ix = c.ix;
   const Plan &p = ix->plan;
-  const int64_t qb = (int64_t)ix->w16 * c.planes * 16;
+  const int64_t qb = query_data_bytes(ix, c.planes);
   uint8_t *hp = s.h_qbuf;
   QueryParams *hq = reinterpret_cast<QueryParams *>(s.h_qbuf + (size_t)nq * qb);
   for (int i = 0; i < nq; ++i)
     fill_query(ix, hp + (size_t)i * qb, hq + i, c.qquant + (size_t)(q_first + i) * ix->dim, c.qcorr + (size_t)(q_first + i) * 4,
                c.planes, c.one_bit, c.sim);
   size_t bytes = (size_t)nq * qb + (size_t)nq * sizeof(QueryParams);
-  const bool use_mfma = ix->opt_share == 32 && c.maxq <= 127;
+  const bool use_mfma = ix->opt_share == 32 && c.maxq <= 127 && ix->store_bits == 1;
   size_t off_qbytes = 0, off_qmax = 0;
   if (use_mfma) {  // second copy of the queries as int8 values in MFMA fragment order + per-group maxima for the pre-filter slack
     const int groups = (nq + 31) / 32;
@@ -557,7 +611,7 @@ int dense_search_one(const BatchCtx &c, int64_t qi, int32_t *out_idx, float *out
   }
   int rc_aux = ensure_aux_qbuf(ix->ctx, qbuf_bytes_per_query_w(ix->w16));
   if (rc_aux != BBQ_OK) return rc_aux;
-  const int64_t qb = (int64_t)ix->w16 * c.planes * 16;
+  const int64_t qb = query_data_bytes(ix, c.planes);
   std::vector<uint8_t> hb((size_t)qb + sizeof(QueryParams));
   fill_query(ix, hb.data(), reinterpret_cast<QueryParams *>(hb.data() + qb), c.qquant + (size_t)qi * ix->dim, c.qcorr + (size_t)qi * 4,
              c.planes, c.one_bit, c.sim);
@@ -745,10 +799,7 @@ int bbq_index_create_shard(const uint8_t *codes, const double *corr, int64_t n_r
   if (n_rows < 0 || dim <= 0 || row_base < 0 || n_pilot < 0) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_create: bad size");
   if (n_rows > 0 && (!codes || !corr)) return fail(BBQ_ERR_INVALID_ARG, "目标向量集合不能为空");
   if (index_bits < 1 || index_bits > 8) return fail(BBQ_ERR_INVALID_ARG, "indexBits必须在1-8之间");
-  if (index_bits != 1)
-    return fail(BBQ_ERR_UNSUPPORTED,
-                "indexBits=%d: the reference has no working batch scorer for multi-bit indexes (SURVEY A.7); only indexBits=1 is scored",
-                index_bits);
+  if ((int64_t)dim * 255 * 255 > 0x7fffffffll) return fail(BBQ_ERR_UNSUPPORTED, "dimension %d: the integer dot product would not fit 31 bits", dim);
   if (n_pilot > 0 && (!pilot_codes || !pilot_corr)) return fail(BBQ_ERR_INVALID_ARG, "pilot arrays are null");
   if (n_pilot > 0 && row_base == 0) return fail(BBQ_ERR_INVALID_ARG, "the shard that owns row 0 takes no pilot replica");
   if (n_pilot > 0 && n_pilot > row_base) return fail(BBQ_ERR_INVALID_ARG, "pilot rows must precede the shard (n_pilot <= row_base)");
@@ -764,7 +815,11 @@ int bbq_index_create_shard(const uint8_t *codes, const double *corr, int64_t n_r
   std::unique_ptr<bbq_index> ix(new bbq_index());
   ix->device = device;
   ix->dim = dim;
-  ix->pb = (dim + 7) / 8;
+  ix->index_bits = index_bits;
+  // a multi-bit index of dimension 1 is the one shape the reference's BATCH scorer accepts (the unpacked byte is read as a
+  // packed row, src/batchDotProduct.ts:425-433): it is stored and scored as the packed 1-bit row it is taken for
+  ix->store_bits = dim == 1 ? 1 : store_bits_of(index_bits);
+  ix->pb = row_bytes_of(dim, ix->store_bits);
   ix->w16 = (ix->pb + 15) / 16;
   ix->n_rows = n_rows;
   ix->row_base = row_base;
@@ -825,6 +880,7 @@ void bbq_index_destroy(bbq_index *ix) {
 int64_t bbq_index_size(const bbq_index *ix) { return ix ? ix->n_rows : 0; }
 int32_t bbq_index_dimension(const bbq_index *ix) { return ix ? ix->dim : 0; }
 int32_t bbq_index_bytes_per_row(const bbq_index *ix) { return ix ? ix->bytes_per_row : 0; }
+int32_t bbq_index_bits(const bbq_index *ix) { return ix ? ix->index_bits : 0; }
 
 int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, const double *qcorr, int32_t query_bits,
                      int32_t sim, int64_t k, int32_t *out_idx, float *out_score, int64_t *out_n) {
@@ -843,8 +899,7 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
   ix->stats.dense_fallbacks = 0;
   if (ix->n_rows == 0) return BBQ_OK;
 
-  BatchCtx c{ix, qquant, qcorr, planes_for(qquant, (int64_t)n_queries * ix->dim), query_bits == 1 ? 1 : 0, sim, k};
-  if (c.one_bit) c.planes = 1;
+  BatchCtx c{ix, qquant, qcorr, planes_of_call(ix, qquant, (int64_t)n_queries * ix->dim, query_bits == 1), query_bits == 1 ? 1 : 0, sim, k};
   c.maxq = c.planes <= 4 ? 15 : max_value(qquant, (int64_t)n_queries * ix->dim);
   const int64_t keff = std::min<int64_t>(k, ix->n_rows);
   c.k = k;
@@ -910,11 +965,10 @@ int bbq_score_rows(bbq_index *ix, const uint8_t *qquant, const double *qcorr, in
   if (row_count == 0) return BBQ_OK;
   std::lock_guard<std::mutex> lk(ix->ctx->mu);
   HIPCHK(hipSetDevice(ix->device));
-  BatchCtx c{ix, qquant, qcorr, planes_for(qquant, ix->dim), query_bits == 1 ? 1 : 0, sim, 0};
-  if (c.one_bit) c.planes = 1;
+  BatchCtx c{ix, qquant, qcorr, planes_of_call(ix, qquant, ix->dim, query_bits == 1), query_bits == 1 ? 1 : 0, sim, 0};
   rc = ensure_aux_qbuf(ix->ctx, qbuf_bytes_per_query_w(ix->w16));
   if (rc != BBQ_OK) return rc;
-  const int64_t qb = (int64_t)ix->w16 * c.planes * 16;
+  const int64_t qb = query_data_bytes(ix, c.planes);
   std::vector<uint8_t> hb((size_t)qb + sizeof(QueryParams));
   fill_query(ix, hb.data(), reinterpret_cast<QueryParams *>(hb.data() + qb), qquant, qcorr, c.planes, c.one_bit, sim);
   hipStream_t st = ix->aux_stream;
@@ -985,8 +1039,7 @@ int bbq_shard_scan(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, cons
   if (k == 0 || k > kMaxFastK) return fail(BBQ_ERR_UNSUPPORTED, "bbq_shard_scan: k must be in 1..%lld", (long long)kMaxFastK);
   std::lock_guard<std::mutex> lk(ix->ctx->mu);
   HIPCHK(hipSetDevice(ix->device));
-  BatchCtx c{ix, qquant, qcorr, planes_for(qquant, (int64_t)n_queries * ix->dim), query_bits == 1 ? 1 : 0, sim, k};
-  if (c.one_bit) c.planes = 1;
+  BatchCtx c{ix, qquant, qcorr, planes_of_call(ix, qquant, (int64_t)n_queries * ix->dim, query_bits == 1), query_bits == 1 ? 1 : 0, sim, k};
   build_plan(ix, k);
   // per-query lists with room for a flood (rows stored cluster by cluster); what travels is packed, so the headroom costs
   // device memory only

@@ -31,6 +31,18 @@ constexpr uint32_t kFlagNaN = 2u;        // a NaN score was produced: order stat
 //   scores vary between rows
 constexpr int kLayoutInline = 0;
 constexpr int kLayoutCompact = 1;
+// Multi-bit indexes (indexBits > 1; the reference keeps such rows as one byte per dimension,
+// src/binaryQuantizationFormat.ts:241-245): a row is stored as `store_bits`-wide fields, field f of row dword w = dimension
+// w * (32 / store_bits) + f at bits [f * store_bits, (f + 1) * store_bits); rows are zero-padded to 16-byte chunks and laid out
+// in the same [w16][64] uint4 tile records, followed by the same corrections blocks.
+__host__ __device__ inline int store_bits_of(int index_bits) { return index_bits <= 1 ? 1 : index_bits <= 2 ? 2 : index_bits <= 4 ? 4 : 8; }
+__host__ __device__ inline int row_bytes_of(int dim, int store_bits) { return (dim * store_bits + 7) / 8; }
+// 16-byte units of staged query data per 16-byte chunk of a row.  1-bit rows: one bit-plane per query bit (QB = 1, 2, 4, 8).
+// Multi-bit rows: per row dword, the query's low nibbles (and, for query values above 15: QB = 8, its high nibbles) in the order
+// the kernel unfolds the fields: store_bits 2 -> {even fields, odd fields}, 4 -> the 8 nibbles, 8 -> the 4 bytes.
+__host__ __device__ constexpr int query_units_per_chunk(int qb, int store_bits) {
+  return store_bits == 1 ? qb : store_bits == 2 ? (qb > 4 ? 4 : 2) : store_bits == 4 ? (qb > 4 ? 2 : 1) : 1;
+}
 // bytes of one tile record
 __host__ __device__ inline int tile_stride_of(int w16, int layout, int has_x1) {
   return w16 * 1024 + (layout == kLayoutCompact ? 4 * kTileRows : 1536 + (has_x1 ? 512 : 0));
@@ -45,6 +57,7 @@ struct IndexView {
   int32_t has_x1;       // 0: quantizedComponentSum == popcount(row), recomputed on the fly
   int32_t dim;
   int32_t layout;
+  int32_t store_bits;   // 1: packed 1-bit rows; 2 / 4 / 8: multi-bit fields (indexBits 2 / 3-4 / 5-8)
 };
 
 // Per-query uniforms of the score formula (src/batchDotProduct.ts:478-617)
@@ -57,11 +70,15 @@ struct QueryParams {
   double dimd;   // dimension as a double
   int32_t sim;   // BBQ_EUCLIDEAN / BBQ_COSINE / BBQ_MAXIMUM_INNER_PRODUCT
   int32_t one_bit;
+  int32_t mip_plain;  // 1: MAXIMUM_INNER_PRODUCT is scaleMaxInnerProductScore(t) without the division by FOUR_BIT_SCALE: the
+                      // per-row scorer's form (src/binaryQuantizedScorer.ts:207-209), which answers for multi-bit indexes
+  int32_t pad_;
 };
 
 struct ScanArgs {
   IndexView idx;
-  const uint4 *qplanes;        // [Q][w16][QB] bit-planes of the quantized query, packed like the rows
+  const uint4 *qplanes;        // [Q][w16][QB] bit-planes of the quantized query, packed like the rows (multi-bit index: [Q][w16*4][QN]
+                               // dwords, the query's nibbles / bytes in the field order of the row dwords, see tile_dot_multibit)
   const QueryParams *qparams;  // [Q]
   int64_t chunk_begin;         // first chunk of this launch inside idx
   int64_t row_id_base;         // global row id of idx row 0

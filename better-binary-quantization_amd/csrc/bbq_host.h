@@ -121,6 +121,7 @@ struct bbq_index {
   bbq::DeviceCtx *ctx = nullptr;
   bbq::Slot *slots = nullptr;  // = ctx->slots
   int32_t dim = 0, pb = 0, w16 = 0, tile_stride = 0, has_x1 = 0, bytes_per_row = 0, layout = 0, want_compact = 1;
+  int32_t index_bits = 1, store_bits = 1;  // pb = stored bytes per row = ceil(dim * store_bits / 8)
   int64_t n_rows = 0, row_base = 0;
   double centroid_dp = 0;
   bool has_pilot = false;

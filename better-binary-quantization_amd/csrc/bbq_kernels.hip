@@ -56,7 +56,9 @@ __device__ __forceinline__ double score_f64(double qc, double ax, double ux, dou
   }
   const double t = p.one_bit ? (s + ((p.qadd + xadd) - p.cdp)) : (((s + p.qadd) + xadd) - p.cdp);
   if (p.sim == 1) return js_max0((1.0 + t) / 2.0);  // COSINE
-  if (p.one_bit) return t < 0.0 ? 1.0 / (1.0 - t) : t + 1.0;
+  // scaleMaxInnerProductScore (src/utils.ts:171-176): the 1-bit batch form (:527-533) and the per-row scorer's form for
+  // every query width (src/binaryQuantizedScorer.ts:148-153, :207-209), which is what answers for multi-bit indexes
+  if (p.one_bit || p.mip_plain) return t < 0.0 ? 1.0 / (1.0 - t) : t + 1.0;
   const double FBS = 1.0 / 15.0;  // FOUR_BIT_SCALE, src/constants.ts:20 - a true division by it, not *15
   return t < 0.0 ? 1.0 / (1.0 - t / FBS) : t / FBS + 1.0;
 }
@@ -87,6 +89,63 @@ __device__ __forceinline__ void tile_popcounts(const uint8_t *__restrict__ tp, i
       ones += popc4(c);
     }
   }
+}
+
+// Multi-bit index rows (indexBits > 1): qcDist = sum_d q[d] * x[d] (computeQuantizedDotProduct, src/bitwiseDotProduct.ts:14-30)
+// over SB-bit fields with the packed-nibble / packed-byte dot instructions - 8 (v_dot8_u32_u4) or 4 (v_dot4_u32_u8) exact
+// integer products per lane and instruction.  2-bit fields are unfolded in registers into two dwords of nibbles (even / odd
+// fields: one AND, one shift + AND); query values above 15 (QB == 8) are split into low and high nibbles,
+// q = lo + 16 hi, so the dot is dot(x, lo) + 16 dot(x, hi).  s_q holds, per row dword, the matching query dwords
+// (query_units_per_chunk; written by the host in exactly this order).  `sum` = the row's component sum (= quantizedComponentSum
+// of a freshly quantized row, src/optimizedScalarQuantizer.ts:204-209).
+template <int QB, int SB>
+__device__ __forceinline__ void dot_chunk_multibit(const u32x4 c, const uint32_t *__restrict__ sq, uint32_t &lo, uint32_t &hi, uint32_t &sum) {
+  const uint32_t x[4] = {c.x, c.y, c.z, c.w};
+  constexpr int QN = query_units_per_chunk(QB, SB);  // query dwords per row dword
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const uint32_t *__restrict__ qw = sq + t * QN;
+    if constexpr (SB == 2) {
+      const uint32_t e = x[t] & 0x33333333u, o = (x[t] >> 2) & 0x33333333u;
+      lo = __builtin_amdgcn_udot8(e, qw[0], lo, false);
+      lo = __builtin_amdgcn_udot8(o, qw[1], lo, false);
+      if constexpr (QB > 4) {
+        hi = __builtin_amdgcn_udot8(e, qw[2], hi, false);
+        hi = __builtin_amdgcn_udot8(o, qw[3], hi, false);
+      }
+      sum = __builtin_amdgcn_udot8(e + o, 0x11111111u, sum, false);  // nibbles of e + o are at most 6
+    } else if constexpr (SB == 4) {
+      lo = __builtin_amdgcn_udot8(x[t], qw[0], lo, false);
+      if constexpr (QB > 4) hi = __builtin_amdgcn_udot8(x[t], qw[1], hi, false);
+      sum = __builtin_amdgcn_udot8(x[t], 0x11111111u, sum, false);
+    } else {
+      lo = __builtin_amdgcn_udot4(x[t], qw[0], lo, false);
+      sum = __builtin_amdgcn_udot4(x[t], 0x01010101u, sum, false);
+    }
+  }
+}
+
+template <int QB, int W, int SB>
+__device__ __forceinline__ void tile_dot_multibit(const uint8_t *__restrict__ tp, int lane, int w16, const u32x4 *__restrict__ s_planes,
+                                                  uint32_t &qc, uint32_t &sum) {
+  const u32x4 *__restrict__ cp = reinterpret_cast<const u32x4 *>(tp) + lane;
+  const uint32_t *__restrict__ sq = reinterpret_cast<const uint32_t *>(s_planes);
+  constexpr int QN = query_units_per_chunk(QB, SB);
+  uint32_t lo = 0, hi = 0;
+  sum = 0;
+  if constexpr (W > 0) {
+    u32x4 c[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) c[j] = BBQ_STREAM_LOAD(cp + j * kTileRows);
+#pragma unroll
+    for (int j = 0; j < W; ++j) dot_chunk_multibit<QB, SB>(c[j], sq + j * 4 * QN, lo, hi, sum);
+  } else {
+    for (int j = 0; j < w16; ++j) {
+      const u32x4 c = BBQ_STREAM_LOAD(cp + j * kTileRows);
+      dot_chunk_multibit<QB, SB>(c, sq + j * 4 * QN, lo, hi, sum);
+    }
+  }
+  qc = lo + (hi << 4);
 }
 
 // Upper bound of the score when only the COMPACT corrections are known (kLayoutCompact).
@@ -128,7 +187,7 @@ __device__ __forceinline__ double score_upper_bound(double qc, double al, double
   const double t_up = (((s + p.qadd) + aadd) - p.cdp) + (es + eadd + slop);
   double u;
   if (p.sim == 1) u = js_max0((1.0 + t_up) / 2.0);
-  else if (p.one_bit) u = t_up < 0.0 ? 1.0 / (1.0 - t_up) : t_up + 1.0;
+  else if (p.one_bit || p.mip_plain) u = t_up < 0.0 ? 1.0 / (1.0 - t_up) : t_up + 1.0;
   else {
     const double FBS = 1.0 / 15.0;
     u = t_up < 0.0 ? 1.0 / (1.0 - t_up / FBS) : t_up / FBS + 1.0;
@@ -138,15 +197,18 @@ __device__ __forceinline__ double score_upper_bound(double qc, double al, double
 
 // MODE: 0 sparse / inline corrections, 1 dense / inline, 2 sparse / compact corrections + exact gather, 3 dense / compact
 // grid = (chunks of kChunkRows rows, queries); block = kChunkRows/64 waves: wave w handles tile w of its chunk (one row per lane)
-template <int QB, int W, int MODE>
+// SB = bits per stored field: 1 = packed 1-bit rows (QB bit-planes of the query), 2 / 4 / 8 = multi-bit rows (QB = 4: query values
+// <= 15, QB = 8: any)
+template <int QB, int W, int MODE, int SB = 1>
 __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT = kChunkRows;
   constexpr bool DENSE = (MODE & 1) != 0;
   constexpr bool COMPACT = (MODE & 2) != 0;
+  constexpr int QU = query_units_per_chunk(QB, SB);
   const int w16 = W > 0 ? W : a.idx.w16;
   u32x4 *s_planes = reinterpret_cast<u32x4 *>(smem);
-  uint64_t *s_ent = reinterpret_cast<uint64_t *>(smem + (size_t)w16 * QB * 16);
+  uint64_t *s_ent = reinterpret_cast<uint64_t *>(smem + (size_t)w16 * QU * 16);
   // with a flood tier every passing row of the chunk is staged (it may have to move to the overflow area as a whole)
   const uint32_t stage_cap = DENSE ? 0u : (a.ovf ? (uint32_t)kChunkRows : (uint32_t)a.cap);
   uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_ent + stage_cap);
@@ -157,8 +219,8 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) 
   const int wave = tid >> 6;
 
   {  // stage the query bit-planes once per workgroup
-    const u32x4 *__restrict__ gp = reinterpret_cast<const u32x4 *>(a.qplanes) + (size_t)q * w16 * QB;
-    for (int i = tid; i < w16 * QB; i += NT) s_planes[i] = gp[i];
+    const u32x4 *__restrict__ gp = reinterpret_cast<const u32x4 *>(a.qplanes) + (size_t)q * w16 * QU;
+    for (int i = tid; i < w16 * QU; i += NT) s_planes[i] = gp[i];
     if (!DENSE && tid == 0) *s_cnt = 0;
   }
   const QueryParams p = a.qparams[q];
@@ -194,12 +256,16 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) 
       cpk1 = __float_as_uint(a.idx.add_range[tile * 2 + (p.sim == 0 ? 0 : 1)]);
     }
 
-    uint32_t acc[QB], ones;
-    tile_popcounts<QB, W>(tp, lane, w16, s_planes, acc, ones);
-    uint32_t qc = 0;
+    uint32_t qc = 0, ones;
+    if constexpr (SB == 1) {
+      uint32_t acc[QB];
+      tile_popcounts<QB, W>(tp, lane, w16, s_planes, acc, ones);
 #pragma unroll
-    for (int pl = 0; pl < QB; ++pl) qc += acc[pl] << pl;
-    if (!a.idx.has_x1) x1 = (double)ones;  // quantizedComponentSum of a 1-bit row is its popcount
+      for (int pl = 0; pl < QB; ++pl) qc += acc[pl] << pl;
+    } else {
+      tile_dot_multibit<QB, W, SB>(tp, lane, w16, s_planes, qc, ones);
+    }
+    if (!a.idx.has_x1) x1 = (double)ones;  // quantizedComponentSum of a freshly quantized row is its popcount / component sum
 
     bool need_exact = true;
     if constexpr (COMPACT && !DENSE) {
@@ -619,6 +685,67 @@ __global__ __launch_bounds__(256) void bbq_retile_kernel(const uint8_t *__restri
   }
 }
 
+// multi-bit index: unpacked rows (one byte per dimension, [n][dim]) -> store_bits-wide fields in tile records; the corrections
+// block is written exactly as above.  A code that does not fit its field raises *bad (the index is refused).
+__global__ __launch_bounds__(256) void bbq_retile_multibit_kernel(const uint8_t *__restrict__ codes, const double *__restrict__ corr,
+                                                                 int64_t n_rows, int32_t dim, int32_t store_bits, uint8_t *__restrict__ tiles,
+                                                                 int32_t w16, int32_t tile_stride, int32_t has_x1, int64_t n_rows_padded,
+                                                                 int32_t layout, double *__restrict__ exact, uint32_t *__restrict__ bad) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = gid / (w16 + 1);
+  const int j = (int)(gid % (w16 + 1));
+  if (row >= n_rows_padded) return;
+  const int64_t tile = row / kTileRows;
+  const int r = (int)(row % kTileRows);
+  uint8_t *tp = tiles + tile * (int64_t)tile_stride;
+  if (j < w16) {
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (row < n_rows) {
+      const int per_dword = 32 / store_bits;
+      const uint8_t *src = codes + row * (int64_t)dim;
+      const uint32_t limit = 1u << store_bits;
+      for (int t = 0; t < 4; ++t)
+        for (int f = 0; f < per_dword; ++f) {
+          const int d = (j * 4 + t) * per_dword + f;
+          if (d < dim) {
+            const uint32_t v = src[d];
+            if (v >= limit) atomicOr(bad, 1u);
+            w[t] |= (v & (limit - 1u)) << (f * store_bits);
+          }
+        }
+    }
+    u32x4 v = {w[0], w[1], w[2], w[3]};
+    reinterpret_cast<u32x4 *>(tp)[j * kTileRows + r] = v;
+  } else {
+    uint8_t *cr = tp + (size_t)w16 * (kTileRows * 16);
+    f64x2 lu = {0.0, 0.0};
+    double add = 0.0, x1 = 0.0;
+    if (row < n_rows) {
+      lu.x = corr[row * 4 + 0]; lu.y = corr[row * 4 + 1]; add = corr[row * 4 + 2]; x1 = corr[row * 4 + 3];
+    }
+    if (layout == kLayoutCompact) {
+      reinterpret_cast<uint32_t *>(cr)[r] = bf16_trunc_bits(lu.x) | (bf16_trunc_bits(lu.y) << 16);
+      double *e = exact + row * 4;
+      e[0] = lu.x; e[1] = lu.y; e[2] = add; e[3] = 0.0;
+    } else {
+      reinterpret_cast<f64x2 *>(cr)[r] = lu;
+      reinterpret_cast<double *>(cr + 1024)[r] = add;
+      if (has_x1) reinterpret_cast<double *>(cr + 1536)[r] = x1;
+    }
+  }
+}
+
+// does quantizedComponentSum equal the sum of the row's codes everywhere? (multi-bit rows, one byte per dimension)
+__global__ __launch_bounds__(256) void bbq_check_x1_multibit_kernel(const uint8_t *__restrict__ codes, const double *__restrict__ corr,
+                                                                   int64_t n_rows, int32_t dim, uint32_t *__restrict__ mismatch) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n_rows) return;
+  const uint8_t *src = codes + row * (int64_t)dim;
+  uint32_t sum = 0;
+  for (int d = 0; d < dim; ++d) sum += src[d];
+  if (!(corr[row * 4 + 3] == (double)sum)) atomicOr(mismatch, 1u);
+}
+
 // compact layout: {min, max} of additionalCorrection over the valid rows of each tile, as f32 (one wave per tile; the f32
 // rounding is inside the bound's allowance for the additive term).  A NaN anywhere makes both ends NaN: no bound, exact path.
 __global__ __launch_bounds__(256) void bbq_tile_add_range_kernel(const double *__restrict__ exact, int64_t n_rows, float *__restrict__ add_range) {
@@ -706,13 +833,32 @@ __global__ __launch_bounds__(256) void bbq_pack_copy_kernel(const uint64_t *__re
 // ---------------------------------------------------------------------------------------------------
 // launch wrappers (declared in bbq_launch.h)
 
-template <int QB, int W, int MODE>
+template <int QB, int W, int MODE, int SB = 1>
 static hipError_t launch_scan_t(const ScanArgs &a, int n_queries, int n_chunks, hipStream_t s) {
   const int w16 = W > 0 ? W : a.idx.w16;
-  const size_t smem = (size_t)w16 * QB * 16 + ((MODE & 1) ? 0 : (size_t)(a.ovf ? kChunkRows : a.cap) * 8) + 16;
+  const size_t smem = (size_t)w16 * query_units_per_chunk(QB, SB) * 16 + ((MODE & 1) ? 0 : (size_t)(a.ovf ? kChunkRows : a.cap) * 8) + 16;
   dim3 grid((unsigned)n_chunks, (unsigned)n_queries, 1), block(kChunkRows, 1, 1);
-  hipLaunchKernelGGL((bbq_scan_kernel<QB, W, MODE>), grid, block, smem, s, a);
+  hipLaunchKernelGGL((bbq_scan_kernel<QB, W, MODE, SB>), grid, block, smem, s, a);
   return hipGetLastError();
+}
+
+// multi-bit rows: compile-time widths for 768-d / 1024-d at 2 bits (12 / 16 chunks; 16 is also 512-d at 4 bits), runtime loop otherwise
+template <int QB, int MODE, int SB>
+static hipError_t launch_scan_mb_w(const ScanArgs &a, int nq, int nc, hipStream_t s) {
+  switch (a.idx.w16) {
+    case 12: return launch_scan_t<QB, 12, MODE, SB>(a, nq, nc, s);
+    case 16: return launch_scan_t<QB, 16, MODE, SB>(a, nq, nc, s);
+    default: return launch_scan_t<QB, 0, MODE, SB>(a, nq, nc, s);
+  }
+}
+template <int MODE>
+static hipError_t launch_scan_mb(const ScanArgs &a, int planes, int nq, int nc, hipStream_t s) {
+  switch (a.idx.store_bits) {
+    case 2: return planes > 4 ? launch_scan_mb_w<8, MODE, 2>(a, nq, nc, s) : launch_scan_mb_w<4, MODE, 2>(a, nq, nc, s);
+    case 4: return planes > 4 ? launch_scan_mb_w<8, MODE, 4>(a, nq, nc, s) : launch_scan_mb_w<4, MODE, 4>(a, nq, nc, s);
+    case 8: return launch_scan_t<8, 0, MODE, 8>(a, nq, nc, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 template <int QB, int MODE>
@@ -765,7 +911,7 @@ static hipError_t launch_shared_q(const ScanArgs &a, int planes, int nq, int nc,
 
 bool shared_sweep_supported(const ScanArgs &a, int share) {
   const int w = a.idx.w16;
-  return (share == 4 || share == 8) && (w == 1 || w == 6 || w == 8 || w == 12) && (size_t)share * a.cap * 8 < 48 * 1024;
+  return a.idx.store_bits == 1 && (share == 4 || share == 8) && (w == 1 || w == 6 || w == 8 || w == 12) && (size_t)share * a.cap * 8 < 48 * 1024;
 }
 
 // sparse segments only; `share` queries per workgroup read each row once
@@ -779,6 +925,14 @@ hipError_t launch_scan_shared(const ScanArgs &a, int planes, int share, int n_qu
 hipError_t launch_scan(const ScanArgs &a, int planes, bool dense, int n_queries, int n_chunks, hipStream_t s) {
   if (n_chunks <= 0 || n_queries <= 0) return hipSuccess;
   const int mode = (dense ? 1 : 0) | (a.idx.layout == kLayoutCompact ? 2 : 0);
+  if (a.idx.store_bits > 1) {
+    switch (mode) {
+      case 0: return launch_scan_mb<0>(a, planes, n_queries, n_chunks, s);
+      case 1: return launch_scan_mb<1>(a, planes, n_queries, n_chunks, s);
+      case 2: return launch_scan_mb<2>(a, planes, n_queries, n_chunks, s);
+      default: return launch_scan_mb<3>(a, planes, n_queries, n_chunks, s);
+    }
+  }
   switch (mode) {
     case 0: return launch_scan_q<0>(a, planes, n_queries, n_chunks, s);
     case 1: return launch_scan_q<1>(a, planes, n_queries, n_chunks, s);
@@ -808,6 +962,24 @@ hipError_t launch_retile(const uint8_t *codes, const double *corr, int64_t n_row
   const int64_t blocks = (threads + 255) / 256;
   hipLaunchKernelGGL(bbq_retile_kernel, dim3((unsigned)blocks), dim3(256), 0, s, codes, corr, n_rows, pb, tiles, w16, tile_stride,
                      has_x1, n_pad, layout, exact);
+  return hipGetLastError();
+}
+
+hipError_t launch_retile_multibit(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim, int32_t store_bits, uint8_t *tiles,
+                                  int32_t w16, int32_t tile_stride, int32_t has_x1, int32_t layout, double *exact, uint32_t *bad, hipStream_t s) {
+  const int64_t n_pad = (n_rows + kTileRows - 1) / kTileRows * kTileRows;
+  const int64_t threads = n_pad * (w16 + 1);
+  if (threads == 0) return hipSuccess;
+  const int64_t blocks = (threads + 255) / 256;
+  hipLaunchKernelGGL(bbq_retile_multibit_kernel, dim3((unsigned)blocks), dim3(256), 0, s, codes, corr, n_rows, dim, store_bits, tiles, w16,
+                     tile_stride, has_x1, n_pad, layout, exact, bad);
+  return hipGetLastError();
+}
+
+hipError_t launch_check_x1_multibit(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim, uint32_t *mismatch, hipStream_t s) {
+  if (n_rows == 0) return hipSuccess;
+  const int64_t blocks = (n_rows + 255) / 256;
+  hipLaunchKernelGGL(bbq_check_x1_multibit_kernel, dim3((unsigned)blocks), dim3(256), 0, s, codes, corr, n_rows, dim, mismatch);
   return hipGetLastError();
 }
 

@@ -355,7 +355,7 @@ static hipError_t launch_mfma_t(const MfmaArgs &a, int nq, int nc, hipStream_t s
 
 bool mfma_sweep_supported(const ScanArgs &a) {
   const int w = a.idx.w16;
-  if (!(w == 1 || w == 6 || w == 8 || w == 12)) return false;
+  if (a.idx.store_bits != 1 || !(w == 1 || w == 6 || w == 8 || w == 12)) return false;
   const size_t smem = (size_t)w * 4 * 2 * 32 * 16 + (size_t)(kChunkRows / 64) * (64 * 2 * 16 + kMfmaQueueCap * 4) + 4096 + (size_t)kMfmaQueries * a.cap * 8;
   return smem <= 150 * 1024;
 }

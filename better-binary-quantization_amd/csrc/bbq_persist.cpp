@@ -61,11 +61,11 @@ int read_meta(const char *prefix, MetaHeader *h, std::vector<float> *centroid, u
   if (fread(h, sizeof *h, 1, fc.f) != 1) return fail(BBQ_ERR_INVALID_ARG, "%s: truncated header", path.c_str());
   if (memcmp(h->magic, "BVEC", 4) != 0) return fail(BBQ_ERR_INVALID_ARG, "%s: not a BVEC metadata file", path.c_str());
   if (h->version != kFileVersion) return fail(BBQ_ERR_UNSUPPORTED, "%s: format version %u (this build reads %u)", path.c_str(), h->version, kFileVersion);
-  if (h->dimensions <= 0 || h->dimensions > (1 << 24) || h->vectorCount < 0 || h->rowBase < 0 || h->indexBits != 1 || h->tileRows != kTileRows ||
+  if (h->dimensions <= 0 || h->dimensions > (1 << 24) || h->vectorCount < 0 || h->rowBase < 0 || h->indexBits < 1 || h->indexBits > 8 || h->tileRows != kTileRows ||
       (h->layout != kLayoutCompact && h->layout != kLayoutInline) || (h->hasX1 != 0 && h->hasX1 != 1) ||
       h->vectorSimilarityOrdinal < 0 || h->vectorSimilarityOrdinal > 2)
     return fail(BBQ_ERR_INVALID_ARG, "%s: header fields out of range", path.c_str());
-  const int32_t pb = (h->dimensions + 7) / 8;
+  const int32_t pb = row_bytes_of(h->dimensions, h->dimensions == 1 ? 1 : store_bits_of(h->indexBits));
   const int64_t n_tiles = (h->vectorCount + kTileRows - 1) / kTileRows;
   if (h->w16 != (pb + 15) / 16 || h->tileStride != expected_tile_stride(h->w16, h->layout, h->hasX1) ||
       (h->layout == kLayoutCompact && h->hasX1) || h->tilesBytes != n_tiles * h->tileStride ||
@@ -104,7 +104,7 @@ int bbq_index_save(bbq_index *ix, const char *prefix, const float *centroid, int
   h.dimensions = ix->dim;
   h.vectorCount = ix->n_rows;
   h.centroidSquareMagnitude = ix->centroid_dp;
-  h.indexBits = 1;
+  h.indexBits = ix->index_bits;
   h.layout = ix->layout;
   h.w16 = ix->w16;
   h.tileStride = ix->tile_stride;
@@ -189,7 +189,9 @@ int bbq_index_load(const char *prefix, int32_t device, bbq_index **out, float *c
   std::unique_ptr<bbq_index> ix(new bbq_index());
   ix->device = device;
   ix->dim = h.dimensions;
-  ix->pb = (h.dimensions + 7) / 8;
+  ix->index_bits = h.indexBits;
+  ix->store_bits = h.dimensions == 1 ? 1 : store_bits_of(h.indexBits);
+  ix->pb = row_bytes_of(h.dimensions, ix->store_bits);
   ix->w16 = h.w16;
   ix->n_rows = h.vectorCount;
   ix->row_base = h.rowBase;
@@ -237,6 +239,7 @@ int bbq_index_load(const char *prefix, int32_t device, bbq_index **out, float *c
   st.view.has_x1 = h.hasX1;
   st.view.dim = h.dimensions;
   st.view.layout = h.layout;
+  st.view.store_bits = ix->store_bits;
   st.view.tiles = st.d_tiles;
   st.view.exact = st.d_exact;
   st.view.add_range = add_range_of(st.d_exact, (h.vectorCount + kTileRows - 1) / kTileRows);
@@ -268,11 +271,22 @@ int bbq_index_export(bbq_index *ix, uint8_t *codes, double *corr) {
       for (int r = 0; r < kTileRows; ++r) {
         const int64_t row = (t0 + t) * kTileRows + r;
         if (row >= ix->n_rows) break;
-        int ones = 0;
-        for (int b = 0; b < pb; ++b) {
-          const uint8_t v = tp[((size_t)(b >> 4) * kTileRows + r) * 16 + (b & 15)];
-          if (codes) codes[row * pb + b] = v;
-          ones += __builtin_popcount(v);
+        int ones = 0;  // popcount of a 1-bit row / component sum of a multi-bit row
+        if (ix->store_bits == 1) {
+          for (int b = 0; b < pb; ++b) {
+            const uint8_t v = tp[((size_t)(b >> 4) * kTileRows + r) * 16 + (b & 15)];
+            if (codes) codes[row * pb + b] = v;
+            ones += __builtin_popcount(v);
+          }
+        } else {  // fields back to one byte per dimension (src/binaryQuantizationFormat.ts:241-245)
+          const int sb = ix->store_bits;
+          for (int d = 0; d < ix->dim; ++d) {
+            const int bit = d * sb, b = bit >> 3;
+            const uint8_t byte = tp[((size_t)(b >> 4) * kTileRows + r) * 16 + (b & 15)];
+            const uint8_t v = (uint8_t)((byte >> (bit & 7)) & ((1u << sb) - 1u));
+            if (codes) codes[row * (int64_t)ix->dim + d] = v;
+            ones += v;
+          }
         }
         if (!corr) continue;
         double *c = corr + row * 4;

@@ -28,7 +28,7 @@ export declare class BinaryQuantizedScorer {
   /** the single-row path of the reference (src/binaryQuantizedScorer.ts:69-301): host arithmetic, queryBits 1 or 4 */
   computeQuantizedScore(quantizedQuery: Uint8Array, queryCorrections: QuantizationResult, targetVectors: BinarizedByteVectorValues, targetOrd: number, queryBits: number, originalQueryVector?: Float32Array): QuantizedScoreResult;
   computeBatchQuantizedScores(quantizedQuery: Uint8Array, queryCorrections: QuantizationResult, targetVectors: BinarizedByteVectorValues,
-    targetOrds: number[], queryBits: number): QuantizedScoreResult[];
+    targetOrds: number[], queryBits: number, originalQueryVector?: Float32Array): QuantizedScoreResult[];
 }
 export declare class BinaryQuantizationFormat {
   constructor(config: BinaryQuantizationConfig);

@@ -183,21 +183,61 @@ class BinaryQuantizedScorer {
     return { score: score, bitDotProduct: qcDist, corrections: { query: queryCorrections, index: ic } };
   }
 
-  /** computeBatchQuantizedScores(quantizedQuery, queryCorrections, targetVectors, targetOrds, queryBits) */
-  computeBatchQuantizedScores(quantizedQuery, queryCorrections, targetVectors, targetOrds, queryBits) {
+  /**
+   * computeBatchQuantizedScores(quantizedQuery, queryCorrections, targetVectors, targetOrds, queryBits, originalQueryVector?)
+   * src/binaryQuantizedScorer.ts:315-420.  Scores come from the device (bbq_score_rows).  Two corners follow the reference on the
+   * host, row by row:
+   *  - originalQueryVector given with a multi-bit query on a 1-bit index: centroidDP = query . centroid instead of centroid . centroid
+   *    (:372-381; searchNearestNeighbors never passes it) - the device's integer qcDist, the batch formula restated here;
+   *  - a multi-bit index: the reference's batch kernels throw on its unpacked rows and it falls back to computeQuantizedScore per
+   *    row with one console.warn per call (:403-419) - the device already returns exactly those per-row values; the warning is
+   *    kept, and queryBits other than 1 and 4 throw like the fallback does (:95-97).
+   */
+  computeBatchQuantizedScores(quantizedQuery, queryCorrections, targetVectors, targetOrds, queryBits, originalQueryVector) {
     if (targetOrds.length === 0) return [];
+    const multibit = isMultiBit(targetVectors);
+    if (multibit) {
+      console.warn('批量计算失败，回退到原始方法:', new RangeError('offset is out of bounds'));
+      if (queryBits !== 1 && queryBits !== 4) throw new Error('不支持的查询位数: ' + queryBits + '，只支持1位和4位');
+      if (originalQueryVector && queryBits !== 1) {
+        const self = this;
+        return targetOrds.map(function (ord) {
+          return self.computeQuantizedScore(quantizedQuery, queryCorrections, targetVectors, ord, queryBits, originalQueryVector);
+        });
+      }
+    }
     const qc = new Float64Array([queryCorrections.lowerInterval, queryCorrections.upperInterval,
       queryCorrections.additionalCorrection, queryCorrections.quantizedComponentSum]);
     let lo = targetOrds[0], hi = targetOrds[0];
     for (let i = 1; i < targetOrds.length; i++) { if (targetOrds[i] < lo) lo = targetOrds[i]; if (targetOrds[i] > hi) hi = targetOrds[i]; }
     const r = native.scoreRows(targetVectors._deviceIndex(), quantizedQuery, qc, queryBits, simOrdinal(this.similarityFunction), lo, hi - lo + 1);
+    const withQuery = !multibit && originalQueryVector && queryBits !== 1;
+    const cdp = withQuery ? targetVectors.getCentroidDP(originalQueryVector) : 0, sim = this.similarityFunction, dimension = targetVectors.dimension();
     return targetOrds.map(function (ord) {
-      return {
-        score: r.score64[ord - lo], bitDotProduct: r.qcDist[ord - lo],
-        corrections: { query: queryCorrections, index: targetVectors.getCorrectiveTerms(ord) },
-      };
+      const ic = targetVectors.getCorrectiveTerms(ord);
+      let score = r.score64[ord - lo];
+      if (withQuery) score = fourBitBatchScore(r.qcDist[ord - lo], queryCorrections, ic, dimension, cdp, sim);
+      return { score: score, bitDotProduct: r.qcDist[ord - lo], corrections: { query: queryCorrections, index: ic } };
     });
   }
+}
+
+/** rows are unpacked bytes and the reference's batch scorer throws on them (dimension 1 is the one width where it does not) */
+function isMultiBit(targetVectors) { return targetVectors._indexBits !== 1 && targetVectors.dimension() > 1; }
+
+/** computeBatchFourBitSimilarityScores for one row, src/batchDotProduct.ts:554-617 (used only for the originalQueryVector corner) */
+function fourBitBatchScore(qcDist, q, x, dimension, centroidDP, sim) {
+  const x1 = x.quantizedComponentSum, ax = x.lowerInterval, lx = x.upperInterval - ax;
+  const ay = q.lowerInterval, ly = (q.upperInterval - ay) * FOUR_BIT_SCALE, y1 = q.quantizedComponentSum;
+  let score = ax * ay * dimension + ay * lx * x1 + ax * ly * y1 + lx * ly * qcDist;
+  if (sim === VectorSimilarityFunction.EUCLIDEAN) {
+    score = q.additionalCorrection + x.additionalCorrection - 2 * score;
+    return Math.max(1 / (1 + score), 0);
+  }
+  score = score + q.additionalCorrection + x.additionalCorrection - centroidDP;
+  if (sim === VectorSimilarityFunction.COSINE) return Math.max((1 + score) / 2, 0);
+  if (sim === VectorSimilarityFunction.MAXIMUM_INNER_PRODUCT) return score < 0 ? 1 / (1 - score / FOUR_BIT_SCALE) : score / FOUR_BIT_SCALE + 1;
+  throw new Error('不支持的相似性函数: ' + sim);
 }
 
 /** BinaryQuantizationFormat, src/binaryQuantizationFormat.ts:132-412 */
@@ -263,6 +303,12 @@ class BinaryQuantizationFormat {
     const dim = targetVectors.dimension(), nq = queryVectors.length;
     if (k === 0) return queryVectors.map(function () { return []; });
     const q = this.quantizer, sim = simOrdinal(q.similarityFunction);
+    if (isMultiBit(targetVectors) && nq > 0) {
+      // the reference answers a multi-bit index through its per-row fallback, warning once per batch of 1000 rows
+      // (src/binaryQuantizedScorer.ts:403-405), and throws for queryBits its fallback does not know (:95-97); one warning per call here
+      console.warn('批量计算失败，回退到原始方法:', new RangeError('offset is out of bounds'));
+      if (this.config.queryBits !== 1 && this.config.queryBits !== 4) throw new Error('不支持的查询位数: ' + this.config.queryBits + '，只支持1位和4位');
+    }
     const flat = new Float32Array(nq * dim);
     for (let i = 0; i < nq; i++) {
       const v = queryVectors[i];

@@ -116,6 +116,10 @@ class BinaryQuantizationFormat:
         if k == 0:
             return []
         sim = capi.SIMS[self._sim]
+        if targetVectors._index_bits != 1 and targetVectors.dimension() > 1 and self._config["queryBits"] not in (1, 4):
+            # the reference's batch scorer throws on a multi-bit index and its per-row fallback only knows 1- and 4-bit queries
+            # (src/binaryQuantizedScorer.ts:95-97, :403-419); libbbq itself would score it (4-bit form, parity unpinned)
+            raise Exception("不支持的查询位数: %d，只支持1位和4位" % self._config["queryBits"])
         try:
             qq, qc = capi.quantize_query(queryVector, targetVectors.getCentroid(), sim, self._config["queryBits"], self._lambda,
                                          self._iters, search_path=True)

@@ -17,7 +17,7 @@ SIMS = {"EUCLIDEAN": 0, "COSINE": 1, "MAXIMUM_INNER_PRODUCT": 2}
 # every symbol include/bbq.h declares (tests/test_capi_symbols.py checks the library exports all of them)
 SYMBOLS = [
     "bbq_last_error", "bbq_abi_version", "bbq_device_count", "bbq_index_create", "bbq_index_create_shard", "bbq_index_build",
-    "bbq_index_destroy", "bbq_index_size", "bbq_index_dimension", "bbq_index_bytes_per_row", "bbq_search",
+    "bbq_index_destroy", "bbq_index_size", "bbq_index_dimension", "bbq_index_bytes_per_row", "bbq_index_bits", "bbq_search",
     "bbq_search_batch", "bbq_score_rows", "bbq_shard_scan", "bbq_shard_list_cap", "bbq_replay", "bbq_replay_batch",
     "bbq_quantize_vectors", "bbq_quantize_query", "bbq_quantize_query_vector", "bbq_centroid_dp", "bbq_get_stats",
     "bbq_reset_stats", "bbq_set_option", "bbq_vectors_create", "bbq_vectors_destroy", "bbq_vectors_size",
@@ -66,6 +66,8 @@ def lib():
     L.bbq_index_dimension.restype = i32
     L.bbq_index_bytes_per_row.argtypes = [vp]
     L.bbq_index_bytes_per_row.restype = i32
+    L.bbq_index_bits.argtypes = [vp]
+    L.bbq_index_bits.restype = i32
     L.bbq_search.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp, vp]
     L.bbq_search_batch.argtypes = [vp, i32, vp, vp, i32, i32, i64, vp, vp, vp]
     L.bbq_score_rows.argtypes = [vp, vp, vp, i32, i32, i64, i64, vp, vp, vp]
@@ -182,6 +184,7 @@ class Index:
         self._h = h
         self.dim = dim
         self.n = n
+        self.index_bits = index_bits
 
     @classmethod
     def build(cls, vectors, sim, lam=0.1, iters=5, device=0, want_host_copy=True):
@@ -197,7 +200,7 @@ class Index:
         h = C.c_void_p()
         _chk(lib().bbq_index_build(_ptr(v), n, dim, sim, lam, iters, device, C.byref(h), _ptr(cen), _ptr(codes), _ptr(corr), None, None))
         self = cls.__new__(cls)
-        self._h, self.dim, self.n = h, dim, n
+        self._h, self.dim, self.n, self.index_bits = h, dim, n, 1
         return self, codes, corr, cen
 
     def save(self, path_prefix, centroid, sim):
@@ -216,11 +219,12 @@ class Index:
         _chk(lib().bbq_index_load(os.fsencode(path_prefix), device, C.byref(h), _ptr(cen)))
         self = cls.__new__(cls)
         self._h, self.dim, self.n = h, info["dim"], info["n_rows"]
+        self.index_bits = lib().bbq_index_bits(h)
         return self, cen, info
 
     def export(self):
         """(codes [n, ceil(dim/8)], corr [n, 4]) as vectorValue / getCorrectiveTerms would return them"""
-        codes = np.zeros((self.n, (self.dim + 7) // 8), np.uint8)
+        codes = np.zeros((self.n, (self.dim + 7) // 8 if self.index_bits == 1 else self.dim), np.uint8)
         corr = np.zeros((self.n, 4), np.float64)
         _chk(lib().bbq_index_export(self._h, _ptr(codes), _ptr(corr)))
         return codes, corr

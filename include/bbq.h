@@ -39,7 +39,7 @@ enum {
   BBQ_ERR_NO_DEVICE = 2,     /* no HIP device / runtime unusable: the product path refuses to run */
   BBQ_ERR_HIP = 3,           /* a HIP call failed; message carries hipGetErrorString */
   BBQ_ERR_OOM = 4,
-  BBQ_ERR_UNSUPPORTED = 5,   /* e.g. indexBits != 1 scoring (reference: SURVEY A.7 / H4) */
+  BBQ_ERR_UNSUPPORTED = 5,   /* e.g. more than 2^32 rows, k out of the sharded range, a file of another format version */
   BBQ_ERR_DIM_MISMATCH = 6,  /* src/binaryQuantizationFormat.ts:327-329 */
   BBQ_ERR_NEGATIVE_K = 7,    /* src/binaryQuantizationFormat.ts:324-326 */
   BBQ_ERR_NAN_INPUT = 8,     /* src/binaryQuantizationFormat.ts:202-204 */
@@ -66,7 +66,17 @@ int bbq_device_count(void);
  * are staged ONCE, re-tiled into the device layout (DESIGN.md "HBM layout"), instead of being
  * gathered into a contiguous buffer for every batch of 1000.
  *
- *   codes        [n_rows * ceil(dim/8)]  packed 1-bit rows (index_bits must be 1 for scoring)
+ *   codes        index_bits == 1: [n_rows * ceil(dim/8)] packed 1-bit rows
+ *                index_bits  > 1: [n_rows * dim] one byte per dimension, values < 2^index_bits - the shape quantizeVectors
+ *                gives such rows (src/binaryQuantizationFormat.ts:241-245).  Stored as 2-bit (index_bits 2), 4-bit (3-4) or
+ *                8-bit (5-8) fields and scanned with the packed-nibble / packed-byte dot instructions.  Scores follow what
+ *                the reference RETURNS for such an index: its batch scorer throws on unpacked rows and the per-row scorer
+ *                answers (src/binaryQuantizedScorer.ts:403-419, :69-301): bitDotProduct = computeQuantizedDotProduct
+ *                (src/bitwiseDotProduct.ts:14-30), centroidDP = 0 unless query_bits == 1 (:290), MAXIMUM_INNER_PRODUCT without the
+ *                FOUR_BIT_SCALE division (:207-209).  The reference's per-row scorer only knows query_bits 1 and 4 and throws
+ *                for the rest (:95-97); this library scores every query_bits 2..8 with the 4-bit form ("parity unpinned"
+ *                beyond the integer dot product, which the reference defines for any widths) - the JS host throws like the
+ *                reference does.
  *   corr         [n_rows * 4]            corrections as doubles
  *   centroid_dp  getCentroidDP(undefined) = centroid . centroid  (src/binaryQuantizationFormat.ts:113-121)
  *   device       HIP device ordinal
@@ -103,6 +113,7 @@ int bbq_index_create_shard(const uint8_t *codes, const double *corr, int64_t n_r
 void bbq_index_destroy(bbq_index *idx);
 int64_t bbq_index_size(const bbq_index *idx);      /* BinarizedByteVectorValues.size()      src/types.ts:46 */
 int32_t bbq_index_dimension(const bbq_index *idx); /* BinarizedByteVectorValues.dimension() src/types.ts:34 */
+int32_t bbq_index_bits(const bbq_index *idx);      /* indexBits the index was created with (1..8) */
 /* bytes of HBM one query sweep reads per row: the figure bench.py prices the roofline with */
 int32_t bbq_index_bytes_per_row(const bbq_index *idx);
 
@@ -194,7 +205,7 @@ int bbq_index_file_info(const char *path_prefix, int64_t *n_rows, int32_t *dim, 
                         double *centroid_dp, int64_t *row_base);
 /* centroid_out [dim] (may be NULL).  Fails with BBQ_ERR_INVALID_ARG on a malformed, truncated or corrupted file. */
 int bbq_index_load(const char *path_prefix, int32_t device, bbq_index **out, float *centroid_out);
-/* the rows back in the reference's shape: codes [n*ceil(dim/8)], corr [n*4] (either may be NULL) - what
+/* the rows back in the reference's shape: codes [n*ceil(dim/8)] (multi-bit index: [n*dim]), corr [n*4] (either may be NULL) - what
  * vectorValue(ord) / getCorrectiveTerms(ord) return (src/binaryQuantizationFormat.ts:52-76) */
 int bbq_index_export(bbq_index *idx, uint8_t *codes, double *corr);
 

@@ -396,6 +396,22 @@ int orc_score_all_multibit(const uint8_t *codes, const double *corr, int64_t n, 
   return 0;
 }
 
+/* NOT a reference behaviour: the reference throws for queryBits other than 1 and 4 on a multi-bit index (:95-97).  libbbq documents
+ * that it scores such queries with the per-row scorer's 4-bit form (centroidDP = 0) over computeQuantizedDotProduct - the integer
+ * part is the reference's definition for any widths (src/bitwiseDotProduct.ts:14-30), the float part is "parity unpinned".  This is
+ * that definition, used to check the library and as the CPU baseline of BASELINE config 5 (queryBits 8 / indexBits 2). */
+void orc_score_all_multibit_ext(const uint8_t *codes, const double *corr, int64_t n, int dim,
+                                const uint8_t *qquant, const double qcorr[4], int qb, int sim, double cdp_centroid,
+                                int32_t *qcdist, double *score64, float *score32) {
+  for (int64_t i = 0; i < n; i++) {
+    int32_t d = orc_dot_u8(qquant, codes + i * dim, dim);
+    double s = orc_score_single_row(d, qcorr, corr + 4 * i, dim, qb == 1 ? cdp_centroid : 0.0, sim, qb == 1);
+    if (qcdist) qcdist[i] = d;
+    if (score64) score64[i] = s;
+    if (score32) score32[i] = (float)s;
+  }
+}
+
 /* ------------------------------------------------------------------ MinHeap (src/minHeap.ts:9-130) */
 
 typedef struct { double score; int32_t index; } heap_item;

@@ -81,6 +81,11 @@ double orc_score_single_row(int32_t qcdist, const double qcorr[4], const double 
 int orc_score_all_multibit(const uint8_t *codes_unpacked, const double *corr, int64_t n, int dim,
                            const uint8_t *qquant, const double qcorr[4], int qb, int sim, double centroid_dp,
                            int32_t *qcdist, double *score64, float *score32);
+/* NOT a reference behaviour (it throws): the per-row 4-bit form applied to ANY queryBits on a multi-bit index - the definition of
+ * libbbq's documented extension ("parity unpinned" beyond the integer dot) and the CPU baseline of BASELINE config 5 */
+void orc_score_all_multibit_ext(const uint8_t *codes_unpacked, const double *corr, int64_t n, int dim,
+                                const uint8_t *qquant, const double qcorr[4], int qb, int sim, double centroid_dp,
+                                int32_t *qcdist, double *score64, float *score32);
 /* orc_search on an indexBits > 1 index (codes unpacked); -5 where the reference throws on the queryBits */
 int64_t orc_search_multibit(const float *query, int query_dim, const uint8_t *codes_unpacked, const double *corr,
                             const float *centroid, int64_t n, int dim, int sim, int qb, double lambda, int iters, int64_t k,

@@ -187,6 +187,15 @@ function runCase(c) {
       }
       rec.single_row = { score_f64: b64(a), score_with_query_f64: b64(b), dot_i32: b64(dots) };
     }
+    if (c.ib === 1 && c.qb !== 1) {
+      // the optional 6th argument of computeBatchQuantizedScores (src/binaryQuantizedScorer.ts:315-321, :372-381): centroidDP becomes
+      // query . centroid for multi-bit queries; searchNearestNeighbors never passes it, so only this entry pins it
+      const rows = Math.min(n, 6), ords = [], b = new Float64Array(rows);
+      for (let i = 0; i < rows; i++) ords.push(i);
+      const res = format.getScorer().computeBatchQuantizedScores(qq.quantizedQuery, qq.queryCorrections, index, ords, c.qb, query);
+      for (let i = 0; i < rows; i++) b[i] = res[i].score;
+      rec.batch_with_query = { score_f64: b64(b) };
+    }
     if (c.oversample) {
       const r = getOversampledTopKWithHeap(query, index, base, c.k, c.oversample, format);
       rec.oversample = { factor: c.oversample, idx: r.map(function (x) { return x.index; }) };

@@ -3,6 +3,9 @@
 const T = require('./common');
 const bbq = T.bbq;
 if (bbq.deviceCount() < 1) { console.error('no HIP device'); process.exit(2); }
+// multi-bit indexes warn like the reference's fallback does; counted, not printed
+let warnings = 0;
+console.warn = function () { warnings++; };
 
 T.goldenNames().filter(function (n) { return !/^(intdot_|api_|rerank_)/.test(n); }).forEach(function (name) {
   if (/^big_(50000|30000)/.test(name)) return;  // covered by pytest; keeps the node run short
@@ -12,13 +15,19 @@ T.goldenNames().filter(function (n) { return !/^(intdot_|api_|rerank_)/.test(n);
   for (let qi = 0; qi < g.nq; qi++) {
     const rec = g.queries[qi];
     rec.topk.forEach(function (tk) {
+      if (tk.error) {   // the reference throws here (multi-bit index, queryBits its per-row fallback does not know)
+        let msg = null;
+        try { fmt.searchNearestNeighbors(io.queries[qi], index, tk.k); } catch (e) { msg = e.message; }
+        T.check(msg === tk.error, name + ' q' + qi + ': throws like the reference (' + msg + ')');
+        return;
+      }
       const res = fmt.searchNearestNeighbors(io.queries[qi], index, tk.k);
       const wi = T.dec(tk.idx_i32, Int32Array), ws = T.dec(tk.score_f32, Float32Array);
       let ok = res.length === wi.length;
       for (let i = 0; ok && i < res.length; i++) ok = res[i].index === wi[i] && (res[i].score === ws[i] || (res[i].score !== res[i].score && ws[i] !== ws[i]));
       T.check(ok, name + ' q' + qi + ' k=' + tk.k + ': top-k list');
     });
-    if (g.full && g.n <= 1000) {  // computeBatchQuantizedScores with scattered ords
+    if (g.full && g.n <= 1000 && !rec.per_row_error) {  // computeBatchQuantizedScores with scattered ords
       const q = fmt.quantizeQueryVector(g.sim === 'COSINE' ? normalise(io.queries[qi]) : io.queries[qi], index.getCentroid());
       const ords = []; for (let i = g.n - 1; i >= 0; i -= 3) ords.push(i);
       const out = fmt.getScorer().computeBatchQuantizedScores(q.quantizedQuery, q.queryCorrections, index, ords, g.qb);
@@ -26,6 +35,16 @@ T.goldenNames().filter(function (n) { return !/^(intdot_|api_|rerank_)/.test(n);
       let ok = out.length === ords.length;
       for (let i = 0; ok && i < ords.length; i++) ok = out[i].bitDotProduct === wd[ords[i]] && (out[i].score === w64[ords[i]] || (out[i].score !== out[i].score && w64[ords[i]] !== w64[ords[i]]));
       T.check(ok, name + ' q' + qi + ': computeBatchQuantizedScores');
+    }
+    // the optional originalQueryVector argument (centroidDP = query . centroid): batch path on a 1-bit index, per-row fallback on
+    // a multi-bit one - both pinned by values the reference returned
+    const want6 = rec.batch_with_query ? T.dec(rec.batch_with_query.score_f64, Float64Array)
+      : (g.ib !== 1 && g.dim > 1 && g.qb === 4 && rec.single_row) ? T.dec(rec.single_row.score_with_query_f64, Float64Array) : null;
+    if (want6) {
+      const q = fmt.quantizeQueryVector(g.sim === 'COSINE' ? normalise(io.queries[qi]) : io.queries[qi], index.getCentroid());
+      const ords = []; for (let i = 0; i < want6.length; i++) ords.push(i);
+      const out = fmt.getScorer().computeBatchQuantizedScores(q.quantizedQuery, q.queryCorrections, index, ords, g.qb, io.queries[qi]);
+      T.check(T.sameBits(Float64Array.from(out.map(function (o) { return o.score; })), want6), name + ' q' + qi + ': computeBatchQuantizedScores with originalQueryVector');
     }
   }
   index.dispose();
@@ -139,4 +158,5 @@ T.goldenNames().filter(function (n) { return /^rerank_/.test(n); }).forEach(func
   loaded.dispose(); back.dispose(); index.dispose();
 })();
 
+T.check(warnings > 0, 'multi-bit indexes warn like the reference fallback');
 T.finish('js gpu_parity');

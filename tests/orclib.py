@@ -57,6 +57,8 @@ def lib():
         L.orc_score_single_row.restype = C.c_double
         L.orc_score_all_multibit.argtypes = [u8p, f64p, C.c_int64, C.c_int, u8p, f64p, C.c_int, C.c_int, C.c_double, i32p, f64p, f32p]
         L.orc_score_all_multibit.restype = C.c_int
+        L.orc_score_all_multibit_ext.argtypes = [u8p, f64p, C.c_int64, C.c_int, u8p, f64p, C.c_int, C.c_int, C.c_double, i32p, f64p, f32p]
+        L.orc_score_all_multibit_ext.restype = None
         L.orc_search_multibit.argtypes = [f32p, C.c_int, u8p, f64p, f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
                                           C.c_int64, i32p, f32p]
         L.orc_search_multibit.restype = C.c_int64
@@ -162,6 +164,19 @@ def score_all(codes, corr, dim, qq, qc, qb, sim, cdp, ib=1):
             raise ReferenceThrows("不支持的查询位数: %d，只支持1位和4位" % qb)
         return d, s64, s32
     lib().orc_score_all(u8p(codes), f64p(corr), n, dim, u8p(qq), f64p(qc), qb, sim, cdp, i32p(d), f64p(s64), f32p(s32))
+    return d, s64, s32
+
+
+def score_all_multibit_ext(codes, corr, dim, qq, qc, qb, sim, cdp):
+    """libbbq's documented extension for queryBits the reference throws on (multi-bit index): per-row 4-bit form, any queryBits"""
+    n = codes.shape[0]
+    d = np.zeros(n, np.int32)
+    s64 = np.zeros(n, np.float64)
+    s32 = np.zeros(n, np.float32)
+    codes = np.ascontiguousarray(codes)
+    corr = np.ascontiguousarray(corr)
+    assert codes.shape[1] == dim
+    lib().orc_score_all_multibit_ext(u8p(codes), f64p(corr), n, dim, u8p(qq), f64p(qc), qb, sim, cdp, i32p(d), f64p(s64), f32p(s32))
     return d, s64, s32
 
 

@@ -31,7 +31,7 @@ def _index_from_case(g):
     sim = O.SIMS[g["sim"]]
     base, queries = O.golden_inputs(g)
     # the product's own host quantizer builds the index; it must reproduce the reference's bytes
-    codes, corr, cen = B.quantize_vectors(base, sim, 1, g["lambda"], g["iters"])
+    codes, corr, cen = B.quantize_vectors(base, sim, g["ib"], g["lambda"], g["iters"])
     assert O.sha(codes) == g["codes_sha256"]
     if not np.isnan(corr).any():
         assert O.sha(corr) == g["corr_sha256"]
@@ -55,12 +55,20 @@ def _make_index(codes, corr, dim, cdp, compact=True, **kw):
             os.environ["BBQ_COMPACT_CORRECTIONS"] = old
 
 
+def _stored_row_bytes(g):
+    """bytes of one row in HBM, padded to 16: packed bits, or 2 / 4 / 8-bit fields for indexBits 2 / 3-4 / 5-8 (dim 1 excepted)"""
+    ib, dim = g["ib"], g["dim"]
+    sb = 1 if (ib == 1 or dim == 1) else 2 if ib == 2 else 4 if ib <= 4 else 8
+    return ((dim * sb + 7) // 8 + 15) // 16 * 16
+
+
 def _check(name, options=None, compact=True):
     g = O.load_golden(name)
     sim, base, queries, codes, corr, cen, cdp = _index_from_case(g)
-    ix = _make_index(codes, corr, g["dim"], cdp, compact)
-    pb16 = (g["row_bytes"] + 15) // 16 * 16
-    assert ix.bytes_per_row == pb16 + (4 if compact else 24)   # compact: 4 B per row (+ 8 B per 64-row tile in a side array)
+    ib = g["ib"]
+    ix = _make_index(codes, corr, g["dim"], cdp, compact, index_bits=ib)
+    implicit_sum = ib == 1 or (g["dim"] > 1 and (corr[:, 3] == codes.sum(axis=1)).all())   # else the sums are stored: 8 B more, inline
+    assert ix.bytes_per_row == _stored_row_bytes(g) + ((4 if compact else 24) if implicit_sum else 32)
     for k_, v_ in (options or {}).items():
         ix.set_option(k_, v_)
     try:
@@ -69,6 +77,16 @@ def _check(name, options=None, compact=True):
             np.testing.assert_array_equal(qq, O.dec(rec["qquant_u8"], "u1"))
             np.testing.assert_array_equal(canon64(qc), canon64(O.dec(rec["qcorr_f64"], "<f8")))
             d, s64, s32 = ix.score_rows(qq, qc, g["qb"], sim)
+            if "per_row_error" in rec:
+                # the reference throws for this queryBits on a multi-bit index; the integer dot product is still defined
+                # (src/bitwiseDotProduct.ts:14-30) and the API mirror throws the reference's message
+                np.testing.assert_array_equal(d, [O.lib().orc_dot_u8(O.u8p(qq), O.u8p(codes[i]), g["dim"]) for i in range(g["n"])])
+                f = B.createBinaryQuantizationFormat({"queryBits": g["qb"], "indexBits": ib, "quantizer": {
+                    "similarityFunction": g["sim"], "lambda": g["lambda"], "iters": g["iters"]}})
+                with pytest.raises(Exception) as e:
+                    f.searchNearestNeighbors(queries[qi], f.quantizeVectors(list(base))["quantizedVectors"], 5)
+                assert str(e.value) == rec["per_row_error"]
+                continue
             assert O.sha(d) == rec["qcdist_sha256"], "integer qcDist"
             if g["full"]:
                 np.testing.assert_array_equal(d, O.dec(rec["qcdist_i32"], "<i4"))
@@ -100,7 +118,8 @@ def test_golden_ties_and_big(name):
 
 
 @pytest.mark.parametrize("compact", [True, False])
-@pytest.mark.parametrize("name", ["ties_cos_qb4", "ties_16d_qb1", "big_20000x128_cos", "ties_max_qb4", "ties_euc_qb4", "ties_cos_qb1"])
+@pytest.mark.parametrize("name", ["ties_cos_qb4", "ties_16d_qb1", "big_20000x128_cos", "ties_max_qb4", "ties_euc_qb4", "ties_cos_qb1",
+                                  "big_20000x1024_cos", "big_20000x1024_euc_qb8", "ib2_ties_cos_qb4", "ib2_big_20000x128_euc"])
 def test_golden_many_small_segments(name, compact):
     """force the multi-segment sparse path on small indexes: 1024-row first segment, x2 growth"""
     _check(name, {"first_segment_rows": 1024, "segment_growth": 2}, compact=compact)
@@ -256,9 +275,12 @@ def test_empty_and_argument_errors():
             ix.score_rows(qq, qc, 4, sim, 0, 5)
     finally:
         ix.close()
+    with pytest.raises(B.BBQError) as e:     # a code that does not fit its 2-bit field
+        B.Index(np.full((4, 8), 4, np.uint8), np.zeros((4, 4)), 8, 0.0, index_bits=2)
+    assert e.value.code == 1
     with pytest.raises(B.BBQError) as e:
-        B.Index(np.zeros((4, 8), np.uint8), np.zeros((4, 4)), 8, 0.0, index_bits=2)
-    assert e.value.code == 5
+        B.Index(np.zeros((4, 8), np.uint8), np.zeros((4, 4)), 8, 0.0, index_bits=9)
+    assert e.value.code == 1 and "indexBits必须在1-8之间" in str(e.value)
     empty = B.Index(np.zeros((0, 1), np.uint8), np.zeros((0, 4)), 8, 0.0)
     idx, sc = empty.search(np.zeros(8, np.uint8), np.zeros(4), 4, 0, 5)
     assert len(idx) == 0
@@ -459,7 +481,8 @@ def test_device_index_build_errors_and_odd_shapes():
 @pytest.mark.parametrize("compact", [True, False])
 @pytest.mark.parametrize("share", [4, 8, 32])
 @pytest.mark.parametrize("name", ["ties_cos_qb4", "big_20000x128_cos", "ties_16d_qb1", "m_768d_max_qb4", "big_30000x1536_mip",
-                                  "ties_euc_qb4", "ties_max_qb4", "m_768d_euc_qb1", "qb8_128d_cos", "big_50000x768_cos"])
+                                  "ties_euc_qb4", "ties_max_qb4", "m_768d_euc_qb1", "qb8_128d_cos", "big_50000x768_cos",
+                                  "big_20000x1024_cos", "big_20000x1024_euc_qb8", "m_1024d_euc_qb1"])
 def test_shared_sweep_gives_identical_results(name, share, compact):
     """API extension: several queries per sweep (one load of each row, `share` queries scored from registers).
     Must return exactly what one-sweep-per-query returns."""
@@ -860,7 +883,7 @@ def test_fuzz_shapes_options_vs_oracle(seed):
     """random (n, dim, k, queryBits, similarity, layout, segment plan, sweep sharing, data flavour) against the oracle:
     index bytes, per-row integers and f64 scores, and the replayed top-k incl. order"""
     rng = np.random.default_rng(1000 + seed)
-    dim = int(rng.choice([1, 2, 7, 8, 9, 63, 64, 65, 96, 127, 128, 129, 200, 256, 384, 500, 768, 1000]))
+    dim = int(rng.choice([1, 2, 7, 8, 9, 63, 64, 65, 96, 127, 128, 129, 200, 256, 384, 500, 768, 1000, 1024, 1024, 1536]))
     n = int(rng.choice([1, 2, 63, 64, 65, 511, 512, 513, 1500, 4097, 9000]))
     sim = int(rng.integers(0, 3))
     qb = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 7, 8]))
@@ -1028,7 +1051,7 @@ def test_sharded_scan_cluster_ordered_rows(squeeze):
 def test_fuzz_medium_sizes_vs_oracle(seed):
     """the same sweep at sizes where every segment of the plan, the flood tier and the shared sweeps are exercised"""
     rng = np.random.default_rng(5000 + seed)
-    dim = int(rng.choice([64, 128, 768]))
+    dim = int(rng.choice([64, 128, 768, 1024]))
     n = int(rng.choice([20000, 70000, 150000, 300000]))
     sim = int(rng.integers(0, 3))
     qb = int(rng.choice([1, 4, 4, 8]))
