@@ -494,7 +494,11 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
       // upper bounds (rounded up) of the group's |ay|, |ly|, y1, |qadd - cdp|
       m[0] = std::max(m[0], (float)(fabs(hq[i].ay) * 1.000001));
       m[1] = std::max(m[1], (float)(fabs(hq[i].ly) * 1.000001));
-      m[2] = std::max(m[2], (float)(fabs(hq[i].y1) * 1.000001));
+      // the slack bounds |qcDist| and |y1 - qcDist| by this: qcDist <= the sum of the query's values whatever y1 the caller passed
+      double qsum = 0;
+      const uint8_t *qv = c.qquant + (size_t)(q_first + i) * ix->dim;
+      for (int d = 0; d < ix->dim; ++d) qsum += qv[d];
+      m[2] = std::max(m[2], (float)((fabs(hq[i].y1) + qsum) * 1.000001));
       m[3] = std::max(m[3], (float)(fabs(hq[i].qadd - hq[i].cdp) * 1.000001));
     }
   }
@@ -598,8 +602,8 @@ void account_timing(bbq_index *ix, Slot &s) {
   }
 }
 
-// dense path for one query: every f32 score to the host, full replay of the reference loop
-int dense_search_one(const BatchCtx &c, int64_t qi, int32_t *out_idx, float *out_score, int64_t *out_n) {
+// every f32 score of one query to the host (out [n_rows] of this index)
+int dense_scores_one(const BatchCtx &c, int64_t qi, float *out) {
   bbq_index *ix = c.ix;
   const int64_t n = ix->main.view.n_rows;
   const int64_t chunks = ix->main.n_chunks();
@@ -629,9 +633,18 @@ int dense_search_one(const BatchCtx &c, int64_t qi, int32_t *out_idx, float *out
   a.dense_stride = n;
   // gridDim.x is limited to 2^31-1: fine for any index that fits in HBM
   HIPCHK(launch_scan(a, c.planes, true, 1, (int)chunks, st));
-  std::vector<float> h((size_t)std::max<int64_t>(n, 1));
-  HIPCHK(hipMemcpyAsync(h.data(), ix->d_dense_all, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(out, ix->d_dense_all, (size_t)n * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  return BBQ_OK;
+}
+
+// dense path for one query: every f32 score to the host, full replay of the reference loop
+int dense_search_one(const BatchCtx &c, int64_t qi, int32_t *out_idx, float *out_score, int64_t *out_n) {
+  bbq_index *ix = c.ix;
+  const int64_t n = ix->main.view.n_rows;
+  std::vector<float> h((size_t)std::max<int64_t>(n, 1));
+  int rc = dense_scores_one(c, qi, h.data());
+  if (rc != BBQ_OK) return rc;
   HeapReplay hr(c.k, n);
   for (int64_t i = 0; i < n; ++i) hr.offer(h[(size_t)i], (int32_t)(ix->main.row_id_base + i));
   *out_n = hr.finish(out_idx, out_score);
@@ -764,6 +777,16 @@ int drain(bbq_index *ix) {
 
 namespace bbq {
 
+// every f32 score of one query on this index (shard), to host memory: the dense path of a multi-device index
+int dense_scores_host(bbq_index *ix, const uint8_t *qquant, const double *qcorr, int32_t query_bits, int32_t sim, float *out) {
+  std::lock_guard<std::mutex> lk(ix->ctx->mu);
+  HIPCHK(hipSetDevice(ix->device));
+  if (ix->n_rows == 0) return BBQ_OK;
+  BatchCtx c{ix, qquant, qcorr, planes_of_call(ix, qquant, ix->dim, query_bits == 1), query_bits == 1 ? 1 : 0, sim, 0};
+  ix->stats.dense_fallbacks += 1;
+  return dense_scores_one(c, 0, out);
+}
+
 // frees what the index owns; the device context (streams, workspace) stays
 void destroy_unlocked(bbq_index *ix) {
   if (!ix) return;
@@ -869,6 +892,7 @@ int bbq_index_create(const uint8_t *codes, const double *corr, int64_t n_rows, i
 
 void bbq_index_destroy(bbq_index *ix) {
   if (!ix) return;
+  if (ix->multi) { multi_destroy(ix); return; }
   if (ix->ctx) {
     std::lock_guard<std::mutex> lk(ix->ctx->mu);
     destroy_unlocked(ix);
@@ -891,6 +915,12 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
   for (int32_t i = 0; i < n_queries; ++i) out_n[i] = 0;
   if (k == 0 || n_queries == 0) return BBQ_OK;  // src/binaryQuantizationFormat.ts:332-334
   if (!out_idx || !out_score) return fail(BBQ_ERR_INVALID_ARG, "output arrays are null");
+  if (ix->multi) {
+    ix->stats.candidates = 0;
+    ix->stats.dense_fallbacks = 0;
+    if (ix->n_rows == 0) return BBQ_OK;
+    return multi_search_batch(ix, n_queries, qquant, qcorr, query_bits, sim, k, out_idx, out_score, out_n);
+  }
   if (ix->has_pilot || ix->row_base != 0)
     return fail(BBQ_ERR_INVALID_ARG, "bbq_search on a non-root shard: use bbq_shard_scan + bbq_replay");
   std::lock_guard<std::mutex> lk(ix->ctx->mu);
@@ -963,6 +993,7 @@ int bbq_score_rows(bbq_index *ix, const uint8_t *qquant, const double *qcorr, in
   if (row_begin < 0 || row_count < 0 || row_begin + row_count > ix->n_rows)
     return fail(BBQ_ERR_INVALID_ARG, "向量索引 %lld 不存在", (long long)(row_begin + row_count - 1));
   if (row_count == 0) return BBQ_OK;
+  if (ix->multi) return multi_score_rows(ix, qquant, qcorr, query_bits, sim, row_begin, row_count, out_qcdist, out_score64, out_score32);
   std::lock_guard<std::mutex> lk(ix->ctx->mu);
   HIPCHK(hipSetDevice(ix->device));
   BatchCtx c{ix, qquant, qcorr, planes_of_call(ix, qquant, ix->dim, query_bits == 1), query_bits == 1 ? 1 : 0, sim, 0};
@@ -1019,7 +1050,7 @@ int bbq_score_rows(bbq_index *ix, const uint8_t *qquant, const double *qcorr, in
 }
 
 int64_t bbq_shard_list_cap(const bbq_index *cix, int64_t k) {
-  if (!cix || k <= 0) return 0;
+  if (!cix || k <= 0 || cix->multi) return 0;
   bbq_index *ix = const_cast<bbq_index *>(cix);
   const int64_t keff = std::min<int64_t>(k, kMaxFastK);
   build_plan(ix, keff);
@@ -1037,6 +1068,7 @@ int bbq_shard_scan(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, cons
   if (!dev_packed || !dev_offsets || !dev_flags || !out_total || packed_cap <= 0)
     return fail(BBQ_ERR_INVALID_ARG, "bbq_shard_scan: null output buffers");
   if (k == 0 || k > kMaxFastK) return fail(BBQ_ERR_UNSUPPORTED, "bbq_shard_scan: k must be in 1..%lld", (long long)kMaxFastK);
+  if (ix->multi) return fail(BBQ_ERR_INVALID_ARG, "bbq_shard_scan: the handle is a multi-device index (it shards by itself)");
   std::lock_guard<std::mutex> lk(ix->ctx->mu);
   HIPCHK(hipSetDevice(ix->device));
   BatchCtx c{ix, qquant, qcorr, planes_of_call(ix, qquant, (int64_t)n_queries * ix->dim, query_bits == 1), query_bits == 1 ? 1 : 0, sim, k};
@@ -1089,17 +1121,20 @@ int bbq_shard_scan(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, cons
 
 int bbq_get_stats(bbq_index *ix, bbq_stats *out) {
   if (!ix || !out) return fail(BBQ_ERR_INVALID_ARG, "bbq_get_stats: null");
+  if (ix->multi) return multi_get_stats(ix, out);
   *out = ix->stats;
   return BBQ_OK;
 }
 int bbq_reset_stats(bbq_index *ix) {
   if (!ix) return fail(BBQ_ERR_INVALID_ARG, "bbq_reset_stats: null");
+  if (ix->multi) return multi_reset_stats(ix);
   ix->stats = bbq_stats{};
   return BBQ_OK;
 }
 
 int bbq_set_option(bbq_index *ix, const char *name, int64_t v) {
   if (!ix || !name) return fail(BBQ_ERR_INVALID_ARG, "bbq_set_option: null");
+  if (ix->multi) return multi_set_option(ix, name, v);
   const std::string n(name);
   if (n == "batch_queries" && v >= 1 && v <= 1024) ix->opt_batch = (int)v;
   else if (n == "pipeline_slots" && v >= 1 && v <= kMaxSlots) ix->opt_slots = (int)v;

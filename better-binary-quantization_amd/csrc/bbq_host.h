@@ -116,7 +116,11 @@ inline const float *add_range_of(const double *d_exact, int64_t n_tiles) {
 
 }  // namespace bbq
 
+namespace bbq { struct MultiState; }
+
 struct bbq_index {
+  bbq::MultiState *multi = nullptr;  // non-null: this handle is a row-sharded index over several devices (bbq_multi.cpp); it owns no
+                                     // storage itself and every entry point dispatches to the shards
   int device = 0;
   bbq::DeviceCtx *ctx = nullptr;
   bbq::Slot *slots = nullptr;  // = ctx->slots
@@ -150,4 +154,16 @@ struct bbq_index {
 namespace bbq {
 // frees what the index owns; the device context (streams, workspace) stays.  Call with the context mutex held.
 void destroy_unlocked(bbq_index *ix);
+// every f32 score of one query on this (single-device) index, to host memory [n_rows]
+int dense_scores_host(bbq_index *ix, const uint8_t *qquant, const double *qcorr, int32_t query_bits, int32_t sim, float *out);
+// multi-device index (bbq_multi.cpp): what the entry points of a handle with ix->multi != nullptr dispatch to
+void multi_destroy(bbq_index *ix);
+int multi_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, const double *qcorr, int32_t query_bits, int32_t sim,
+                       int64_t k, int32_t *out_idx, float *out_score, int64_t *out_n);
+int multi_score_rows(bbq_index *ix, const uint8_t *qquant, const double *qcorr, int32_t query_bits, int32_t sim, int64_t row_begin,
+                     int64_t row_count, int32_t *out_qcdist, double *out_score64, float *out_score32);
+int multi_export(bbq_index *ix, uint8_t *codes, double *corr);
+int multi_set_option(bbq_index *ix, const char *name, int64_t v);
+int multi_get_stats(bbq_index *ix, bbq_stats *out);
+int multi_reset_stats(bbq_index *ix);
 }  // namespace bbq

@@ -572,6 +572,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
       // SUBSET of the rows seen so far is a valid (weaker) lower bound of the reference heap's minimum, so the
       // query stays exact and on the sparse path
       const uint32_t m_use = min(m_new, (uint32_t)kFinalizeKeyCap - tcount);
+      __syncthreads();  // a flood can have written new keys at indices >= m_use: those writes end before the running top-k lands there
       for (uint32_t i = tid; i < tcount; i += kFinalizeThreads) s_keys[m_use + i] = tk[i];
       const uint32_t M = m_use + tcount;
       __syncthreads();

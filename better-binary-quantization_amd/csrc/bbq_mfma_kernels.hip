@@ -274,7 +274,8 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
         const float Ae = fmaf(lyq, y1q - qcf, ayq * k0.y);           // ay*(D-x1) + ly*(y1-qc)
         const float Be = fmaf(lyq, qcf, ayq * k0.z);                 // ay*x1 + ly*qc
         const float zu = fmaf(fabsf(Ae), k1.z, fmaf(fabsf(Be), k1.w, z));
-        const bool pass = have_q && rit < rows_here && !(zu <= (zth - zth_margin));  // NaN / inf anywhere => pass
+        // NaN anywhere => the compare fails => pass; an overflowed (infinite) zu proves nothing either: pass
+        const bool pass = have_q && rit < rows_here && (!(zu <= (zth - zth_margin)) || !(fabsf(zu) <= 3.0e38f));
         if (pass) {
           const uint32_t slot = atomicAdd(&s_qcount[wave], 1u);
           if (slot < (uint32_t)kMfmaQueueCap) queue[slot] = (uint32_t)qc | ((uint32_t)rit << 20) | ((uint32_t)n << 26);

@@ -93,6 +93,7 @@ int bbq_index_save(bbq_index *ix, const char *prefix, const float *centroid, int
   clear_error();
   if (!ix || !prefix || !centroid) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_save: null argument");
   if (sim < 0 || sim > 2) return fail(BBQ_ERR_INVALID_ARG, "不支持的相似性函数: %d", sim);
+  if (ix->multi) return fail(BBQ_ERR_UNSUPPORTED, "bbq_index_save: a multi-device index is not saved as such (save a single-device copy of the rows)");
   if (ix->has_pilot) return fail(BBQ_ERR_UNSUPPORTED, "bbq_index_save: a shard with a pilot replica cannot be saved");
   std::lock_guard<std::mutex> lk(ix->ctx->mu);
   HIPCHK(hipSetDevice(ix->device));
@@ -252,6 +253,7 @@ int bbq_index_export(bbq_index *ix, uint8_t *codes, double *corr) {
   clear_error();
   if (!ix) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_export: null handle");
   if (ix->n_rows == 0 || (!codes && !corr)) return BBQ_OK;
+  if (ix->multi) return multi_export(ix, codes, corr);
   std::lock_guard<std::mutex> lk(ix->ctx->mu);
   HIPCHK(hipSetDevice(ix->device));
   const int64_t n_tiles = (ix->n_rows + kTileRows - 1) / kTileRows;

@@ -69,11 +69,15 @@ int bbq_vectors_create(const float *vectors, int64_t n, int32_t dim, int32_t dev
   *out = nullptr;
   if (n < 0 || dim <= 0 || (n > 0 && !vectors)) return fail(BBQ_ERR_INVALID_ARG, "bbq_vectors_create: bad arguments");
   if (n > 0x7fffffffLL) return fail(BBQ_ERR_INVALID_ARG, "bbq_vectors_create: more than 2^31-1 rows");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(BBQ_ERR_NO_DEVICE, "no HIP device available: libbbq has no CPU fallback (hipGetDeviceCount found %d)", ndev);
+  if (device < 0 || device >= ndev) return fail(BBQ_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+  HIPCHK(hipSetDevice(device));  // before get_ctx: a new context creates its streams on the current device
   DeviceCtx *ctx = nullptr;
   int rc = get_ctx(device, &ctx);
   if (rc != BBQ_OK) return rc;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  HIPCHK(hipSetDevice(device));
   bbq_vectors *v = new bbq_vectors();
   v->device = device;
   v->ctx = ctx;

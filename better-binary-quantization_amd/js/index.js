@@ -97,8 +97,15 @@ class BinarizedByteVectorValuesImpl {
   _deviceIndex() {
     if (!this._device) {
       if (!this._codes) throw new Error('目标向量集合不能为空');
-      this._device = native.indexCreate(this._codes, this._corr, this._size, this.dimension(), this._indexBits,
-        this.getCentroidDP(), Number(process.env.BBQ_DEVICE || 0));
+      const devices = shardDevices(this._size);
+      if (devices.length > 1) {
+        // one index row-sharded over several GPUs behind the same handle: every search below uses all of them
+        this._device = native.indexCreateMulti(this._codes, this._corr, this._size, this.dimension(), this._indexBits, this.getCentroidDP(),
+          Int32Array.from(devices), Number(process.env.BBQ_PILOT_ROWS || 32768));
+      } else {
+        this._device = native.indexCreate(this._codes, this._corr, this._size, this.dimension(), this._indexBits,
+          this.getCentroidDP(), devices[0]);
+      }
     }
     return this._device;
   }
@@ -106,6 +113,30 @@ class BinarizedByteVectorValuesImpl {
   /** tuning knobs of the device index (libbbq bbq_set_option), e.g. ('sweep_share', 32) for searchNearestNeighborsBatch */
   setDeviceOption(name, value) { native.setOption(this._deviceIndex(), name, value); }
   deviceStats() { return native.stats(this._deviceIndex()); }
+}
+
+/**
+ * Devices an index of `rows` rows is sharded over.  BBQ_DEVICES = a list of HIP ordinals ("0,1,2,3"; repeats allowed: several
+ * shards on one GPU) or a count ("8" = devices 0..7); unset: every visible GPU once the index is large enough for the sharding to
+ * pay (BBQ_SHARD_MIN_ROWS, default 4 M rows), else BBQ_DEVICE (default 0) alone.
+ */
+function shardDevices(rows) {
+  const one = [Number(process.env.BBQ_DEVICE || 0)];
+  const spec = process.env.BBQ_DEVICES;
+  if (spec !== undefined && spec !== '') {
+    if (spec.indexOf(',') >= 0) return spec.split(',').map(Number);
+    const n = Number(spec);
+    if (!(n >= 1)) return one;
+    if (n === 1) return one;
+    const out = []; for (let i = 0; i < n; i++) out.push(i);
+    return out;
+  }
+  const visible = native.deviceCount();
+  if (visible > 1 && rows >= Number(process.env.BBQ_SHARD_MIN_ROWS || 4000000)) {
+    const out = []; for (let i = 0; i < visible; i++) out.push(i);
+    return out;
+  }
+  return one;
 }
 
 function flatten(vectors, dim) {
@@ -268,7 +299,8 @@ class BinaryQuantizationFormat {
       const r = native.indexBuild(flatten(vectors, dim), vectors.length, dim, simOrdinal(q.similarityFunction), q.lambda, q.iters,
         Number(process.env.BBQ_DEVICE || 0));
       values = new BinarizedByteVectorValuesImpl(r.codes, r.corr, r.centroid, 1, vectors.length);
-      values._device = r.handle;
+      if (shardDevices(vectors.length).length > 1) native.indexDestroy(r.handle);  // the sharded index is created from the rows on first search
+      else values._device = r.handle;
     } else {
       const r = native.quantizeVectors(flatten(vectors, dim), vectors.length, dim, simOrdinal(q.similarityFunction),
         this.config.indexBits, q.lambda, q.iters, Number(process.env.BBQ_THREADS || 0));
@@ -369,6 +401,13 @@ class BinaryQuantizationFormat {
    */
   saveIndex(quantizedVectors, pathPrefix) {
     if (!quantizedVectors) throw new Error('目标向量集合不能为空');
+    const qv = quantizedVectors;
+    if (qv._codes && shardDevices(qv._size).length > 1) {
+      // the file pair holds ONE device layout: a sharded index is written from a single-device copy of its rows
+      const tmp = native.indexCreate(qv._codes, qv._corr, qv._size, qv.dimension(), qv._indexBits, qv.getCentroidDP(), Number(process.env.BBQ_DEVICE || 0));
+      try { native.indexSave(tmp, String(pathPrefix), qv.getCentroid(), simOrdinal(this.quantizer.similarityFunction)); } finally { native.indexDestroy(tmp); }
+      return;
+    }
     native.indexSave(quantizedVectors._deviceIndex(), String(pathPrefix), quantizedVectors.getCentroid(), simOrdinal(this.quantizer.similarityFunction));
   }
   /** loads <prefix>.veb/.vemb straight into HBM; vectorValue()/getCorrectiveTerms() fetch the rows back lazily */

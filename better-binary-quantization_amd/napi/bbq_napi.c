@@ -167,11 +167,33 @@ static napi_value IndexCreate(napi_env env, napi_callback_info info) {
   if (!get_typed(env, a[0], napi_uint8_array, &codes, &cl) || !get_typed(env, a[1], napi_float64_array, &corr, &rl) ||
       !get_i64(env, a[2], &n) || !get_i64(env, a[3], &dim) || !get_i64(env, a[4], &ib) || !get_f64(env, a[5], &cdp) ||
       !get_i64(env, a[6], &dev)) return NULL;
-  if (n < 0 || dim <= 0 || rl != (size_t)n * 4 || cl < (size_t)n * (size_t)((dim + 7) / 8)) {
+  if (n < 0 || dim <= 0 || rl != (size_t)n * 4 || cl < (size_t)n * (size_t)(ib == 1 ? (dim + 7) / 8 : dim)) {
     napi_throw_range_error(env, NULL, "bbq_napi: array sizes do not match n/dim"); return NULL;
   }
   bbq_index **box = (bbq_index **)calloc(1, sizeof *box);
   int rc = bbq_index_create((const uint8_t *)codes, (const double *)corr, n, (int32_t)dim, (int32_t)ib, cdp, (int32_t)dev, box);
+  if (rc != BBQ_OK) { free(box); return throw_bbq(env, rc); }
+  napi_value ext;
+  if (napi_create_external(env, box, finalize_index, NULL, &ext) != napi_ok) { bbq_index_destroy(*box); free(box); napi_throw_error(env, NULL, "bbq_napi: external"); return NULL; }
+  return ext;
+}
+
+/* indexCreateMulti(codes Uint8Array, corr Float64Array, n, dim, indexBits, centroidDP, devices Int32Array, pilotRows) -> external
+ * one index row-sharded over the listed devices behind one handle (bbq_index_create_multi) */
+static napi_value IndexCreateMulti(napi_env env, napi_callback_info info) {
+  napi_value a[8];
+  if (!get_args(env, info, 8, a)) return NULL;
+  void *codes, *corr, *devs; size_t cl, rl, dl;
+  int64_t n, dim, ib, pilot; double cdp;
+  if (!get_typed(env, a[0], napi_uint8_array, &codes, &cl) || !get_typed(env, a[1], napi_float64_array, &corr, &rl) ||
+      !get_i64(env, a[2], &n) || !get_i64(env, a[3], &dim) || !get_i64(env, a[4], &ib) || !get_f64(env, a[5], &cdp) ||
+      !get_typed(env, a[6], napi_int32_array, &devs, &dl) || !get_i64(env, a[7], &pilot)) return NULL;
+  if (n < 0 || dim <= 0 || rl != (size_t)n * 4 || cl < (size_t)n * (size_t)(ib == 1 ? (dim + 7) / 8 : dim) || dl < 1) {
+    napi_throw_range_error(env, NULL, "bbq_napi: array sizes do not match n/dim"); return NULL;
+  }
+  bbq_index **box = (bbq_index **)calloc(1, sizeof *box);
+  int rc = bbq_index_create_multi((const uint8_t *)codes, (const double *)corr, n, (int32_t)dim, (int32_t)ib, cdp, (int32_t)dl,
+                                  (const int32_t *)devs, pilot, box);
   if (rc != BBQ_OK) { free(box); return throw_bbq(env, rc); }
   napi_value ext;
   if (napi_create_external(env, box, finalize_index, NULL, &ext) != napi_ok) { bbq_index_destroy(*box); free(box); napi_throw_error(env, NULL, "bbq_napi: external"); return NULL; }
@@ -472,7 +494,8 @@ static napi_value IndexExport(napi_env env, napi_callback_info info) {
   if (!get_args(env, info, 1, a)) return NULL;
   bbq_index *ix = unbox(env, a[0]);
   if (!ix) return NULL;
-  const size_t n = (size_t)bbq_index_size(ix), pb = (size_t)((bbq_index_dimension(ix) + 7) / 8);
+  const size_t dimx = (size_t)bbq_index_dimension(ix);
+  const size_t n = (size_t)bbq_index_size(ix), pb = bbq_index_bits(ix) == 1 ? (dimx + 7) / 8 : dimx;
   void *codes, *corr;
   napi_value tcodes = new_typed(env, napi_uint8_array, n * pb, 1, &codes);
   napi_value tcorr = new_typed(env, napi_float64_array, n * 4, 8, &corr);
@@ -517,6 +540,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"quantizeQueries", NULL, QuantizeQueries, NULL, NULL, NULL, napi_default, NULL},
       {"centroidDP", NULL, CentroidDP, NULL, NULL, NULL, napi_default, NULL},
       {"indexCreate", NULL, IndexCreate, NULL, NULL, NULL, napi_default, NULL},
+      {"indexCreateMulti", NULL, IndexCreateMulti, NULL, NULL, NULL, napi_default, NULL},
       {"indexBuild", NULL, IndexBuild, NULL, NULL, NULL, napi_default, NULL},
       {"indexDestroy", NULL, IndexDestroy, NULL, NULL, NULL, napi_default, NULL},
       {"searchBatch", NULL, SearchBatch, NULL, NULL, NULL, napi_default, NULL},

@@ -16,7 +16,7 @@ SIMS = {"EUCLIDEAN": 0, "COSINE": 1, "MAXIMUM_INNER_PRODUCT": 2}
 
 # every symbol include/bbq.h declares (tests/test_capi_symbols.py checks the library exports all of them)
 SYMBOLS = [
-    "bbq_last_error", "bbq_abi_version", "bbq_device_count", "bbq_index_create", "bbq_index_create_shard", "bbq_index_build",
+    "bbq_last_error", "bbq_abi_version", "bbq_device_count", "bbq_index_create", "bbq_index_create_shard", "bbq_index_create_multi", "bbq_index_shards", "bbq_index_build",
     "bbq_index_destroy", "bbq_index_size", "bbq_index_dimension", "bbq_index_bytes_per_row", "bbq_index_bits", "bbq_search",
     "bbq_search_batch", "bbq_score_rows", "bbq_shard_scan", "bbq_shard_list_cap", "bbq_replay", "bbq_replay_batch",
     "bbq_quantize_vectors", "bbq_quantize_query", "bbq_quantize_query_vector", "bbq_centroid_dp", "bbq_get_stats",
@@ -57,6 +57,9 @@ def lib():
     L.bbq_device_count.restype = C.c_int
     L.bbq_index_create.argtypes = [vp, vp, i64, i32, i32, dbl, i32, C.POINTER(vp)]
     L.bbq_index_create_shard.argtypes = [vp, vp, i64, i32, i32, dbl, i64, vp, vp, i64, i32, C.POINTER(vp)]
+    L.bbq_index_create_multi.argtypes = [vp, vp, i64, i32, i32, dbl, i32, vp, i64, C.POINTER(vp)]
+    L.bbq_index_shards.argtypes = [vp]
+    L.bbq_index_shards.restype = i32
     L.bbq_index_build.argtypes = [vp, i64, i32, i32, dbl, i32, i32, C.POINTER(vp), vp, vp, vp, vp, vp]
     L.bbq_index_destroy.argtypes = [vp]
     L.bbq_index_destroy.restype = None
@@ -185,6 +188,22 @@ class Index:
         self.dim = dim
         self.n = n
         self.index_bits = index_bits
+
+    @classmethod
+    def create_multi(cls, codes, corr, dim, cdp, devices, index_bits=1, pilot_rows=32768):
+        """one index row-sharded over `devices` (a list of HIP ordinals, one shard each; repeats allowed) behind one handle"""
+        codes = np.ascontiguousarray(codes, np.uint8)
+        corr = np.ascontiguousarray(corr, np.float64)
+        dev = np.ascontiguousarray(devices, np.int32)
+        h = C.c_void_p()
+        _chk(lib().bbq_index_create_multi(_ptr(codes), _ptr(corr), codes.shape[0], dim, index_bits, cdp, len(dev), _ptr(dev), pilot_rows, C.byref(h)))
+        self = cls.__new__(cls)
+        self._h, self.dim, self.n, self.index_bits = h, dim, codes.shape[0], index_bits
+        return self
+
+    @property
+    def shards(self):
+        return lib().bbq_index_shards(self._h)
 
     @classmethod
     def build(cls, vectors, sim, lam=0.1, iters=5, device=0, want_host_copy=True):

@@ -110,6 +110,20 @@ int bbq_index_create_shard(const uint8_t *codes, const double *corr, int64_t n_r
                            int32_t index_bits, double centroid_dp, int64_t row_base,
                            const uint8_t *pilot_codes, const double *pilot_corr, int64_t n_pilot,
                            int32_t device, bbq_index **out);
+/* ONE index row-sharded over several GPUs of this process, behind the same handle (new; SURVEY 8b/8e: the reference has no
+ * distribution).  Every entry point that takes a bbq_index - bbq_search, bbq_search_batch, bbq_score_rows, bbq_index_export,
+ * bbq_search_rerank_batch, bbq_set_option, bbq_get_stats - works on it and returns exactly what the single-device index
+ * returns: shards are contiguous row blocks (whole 512-row chunks) in ascending order, each later shard carries a pilot
+ * replica of the first pilot_rows global rows (0: none, thresholds start inside the shard), one host thread per shard
+ * sweeps it and lands its packed candidate list in pinned host memory over that device's own PCIe link, the calling thread
+ * replays the reference heap over the lists in shard order (bbq_replay_batch) while the next round of queries is swept.
+ *   n_shards     1..64
+ *   devices      [n_shards] HIP device ordinal of every shard (NULL: shard s on device s); a device may appear more than once
+ *                (several shards on one GPU: how a single-GPU box tests the path)
+ * bbq_index_save and bbq_shard_scan refuse such a handle.  Extra option: round_queries 1..65536 (512), queries per round. */
+int bbq_index_create_multi(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim, int32_t index_bits,
+                           double centroid_dp, int32_t n_shards, const int32_t *devices, int64_t pilot_rows, bbq_index **out);
+int32_t bbq_index_shards(const bbq_index *idx);    /* 1 for a single-device index */
 void bbq_index_destroy(bbq_index *idx);
 int64_t bbq_index_size(const bbq_index *idx);      /* BinarizedByteVectorValues.size()      src/types.ts:46 */
 int32_t bbq_index_dimension(const bbq_index *idx); /* BinarizedByteVectorValues.dimension() src/types.ts:34 */

@@ -20,6 +20,19 @@ def test_js_host_gpu_parity():
 
 @pytest.mark.gpu
 @pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_js_host_gpu_parity_sharded_over_devices():
+    """the same drop-in API with every index row-sharded over three shards (BBQ_DEVICES: all on GPU 0 here, one per GPU on a node):
+    searchNearestNeighbors / quickSearch / computeBatchQuantizedScores / the rerank recipe must not change by a bit"""
+    env = dict(os.environ, BBQ_DEVICES="0,0,0", BBQ_PILOT_ROWS="1024")
+    r = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "gpu_parity.js")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=900, env=env)
+    print(r.stdout[-2000:])
+    assert r.returncode == 0, r.stdout[-4000:]
+    assert "0 failures" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
 def test_js_reference_suite():
     """the reference's own test expectations (recall thresholds on its closed-form datasets, batch == single, known answers)
     through the drop-in JavaScript API"""
