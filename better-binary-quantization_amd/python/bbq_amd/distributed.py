@@ -1,14 +1,21 @@
 """Row-sharded search over torch.distributed (one process per GPU; backend "nccl" = RCCL over xGMI, or "gloo" for
 rehearsals).  Host plumbing only: the sweep runs in libbbq (bbq_shard_scan), the merge in libbbq (bbq_replay_batch).
 
-Per batch of queries every rank sweeps its shard and packs its candidates; the ranks exchange
-  1. all_gather  [total, any_flag]                       (2 int64 per rank)
-  2. all_gather  offsets  [Q+1] int64
-  3. all_gather  packed[:max total over ranks >= 1]      (the only sizeable message: ~2K entries x 8 B per query and rank)
-and rank 0 replays the reference heap over (own list, rank 1's, rank 2's, ...) in global row order.  Rank 0's own list
-(which carries the dense first segment) never travels.  A scanner thread keeps the GPU sweeping batch i+1 while the
-main thread gathers and replays batch i.  Queries some shard could not bound (flags) are scored densely by every rank, one
-by one; the rest of their batch stays on the sparse path.
+Per batch of Q queries every rank sweeps its shard and leaves its candidates packed in device memory, ordered by query.  The
+MERGE is sharded too: rank r owns the queries of block r (Qb = ceil(Q / world) consecutive queries) and replays the reference heap
+for them over every shard's list - no rank replays for the whole job.  Exchange per batch, three collectives:
+
+  1. all_to_all_single, equal splits: one fixed-size header per destination d
+         [entries I hold for block d | my any-flag | my flags of block d (Qb) | offsets of block d relative to its start (Qb+1)]
+     (one host sync afterwards: the received counts size the next step; every rank also learns here whether ANY shard flagged
+     ANY query of the batch, without a collective of its own)
+  2. all_to_all_single, uneven splits: the packed entries themselves - the slice of block d goes to rank d and nowhere else.
+     packed is ordered by query, so the slice is contiguous: no gather kernel, no padding travels
+  3. gather to rank 0: [Qb, 2k+1] int32 per rank (indices | f32 score bits | count) = the answers of the block
+
+A scanner thread keeps the GPU sweeping batch i+1 while the main thread exchanges and replays batch i.  A query some shard could not
+bound (flags: NaN scores / a flood beyond every buffer) is scored densely by every rank, one by one; the rest of its batch stays on
+the sparse path (rare; costs two extra collectives for such a batch).
 """
 import queue
 import threading
@@ -31,9 +38,11 @@ class ShardedSearcher:
         self.cdev = collective_device or device
         self._scan_fn, self._dense_fn = scan_fn, dense_fn
         self._dense_rows = int(n_local_rows)
+        self.Qb = (self.Q + self.world - 1) // self.world          # queries per owner block
+        self.hdr_len = 2 + self.Qb + self.Qb + 1
         per_query = int(index.shard_list_cap(k)) if index is not None else int(list_cap_per_query or 0)
         cap = torch.tensor([per_query * self.Q], dtype=torch.int64, device=self.cdev)
-        dist.all_reduce(cap, op=dist.ReduceOp.MAX)   # same capacity everywhere: slices of any rank fit any buffer
+        dist.all_reduce(cap, op=dist.ReduceOp.MAX)   # same capacity everywhere
         self.cap = int(cap.item())
         self.bufs = []
         for _ in range(n_buffers):
@@ -42,13 +51,13 @@ class ShardedSearcher:
                 "offsets": torch.zeros(self.Q + 1, dtype=torch.int64, device=device),
                 "flags": torch.zeros(self.Q, dtype=torch.int32, device=device),
             })
-        self.g_packed = torch.zeros(self.world * self.cap, dtype=torch.int64, device=self.cdev)
-        self.g_offsets = torch.zeros(self.world * (self.Q + 1), dtype=torch.int64, device=self.cdev)
-        self.g_meta = torch.zeros(self.world * 2, dtype=torch.int64, device=self.cdev)
-        pin = str(self.cdev).startswith("cuda")
-        # pinned landing buffers on rank 0: a pageable .cpu() of a few MB per batch would cost more than the sweep
-        self.h_packed = torch.empty(self.world * self.cap if self.rank == 0 else 1, dtype=torch.int64, pin_memory=pin)
-        self.h_own = torch.empty(self.cap if self.rank == 0 else 1, dtype=torch.int64, pin_memory=pin)
+        self._pin = str(self.cdev).startswith("cuda")
+        self.hdr_in = torch.zeros(self.world * self.hdr_len, dtype=torch.int64, device=self.cdev)
+        self.res_out = torch.zeros(self.Qb * (2 * self.k + 1), dtype=torch.int32, device=self.cdev)
+        self.res_in = [torch.zeros(self.Qb * (2 * self.k + 1), dtype=torch.int32, device=self.cdev) for _ in range(self.world)] if self.rank == 0 else None
+        self._recv = None        # grow-only landing buffer of the packed entries of my block (collective device)
+        self._h_recv = None      # its pinned host twin
+        self.last_exchange = {}  # sizes of the last batch's exchange (bench / diagnostics)
 
     # ------------------------------------------------------------------ one rank's sweep of one batch
     def _scan(self, buf, qq, qc):
@@ -64,50 +73,71 @@ class ShardedSearcher:
                                      buf["offsets"].data_ptr(), buf["flags"].data_ptr())
 
     # ------------------------------------------------------------------ exchange + replay of one batch
-    def _to_host(self, dst, src):
-        n = src.numel()
-        dst[:n].copy_(src, non_blocking=True)
-        if src.is_cuda:
-            self.torch.cuda.current_stream().synchronize()
-        return dst[:n].numpy()
+    def _grow(self, n):
+        t = self.torch
+        if self._recv is None or self._recv.numel() < n:
+            n = max(n, 1024) * 5 // 4
+            self._recv = t.empty(n, dtype=t.int64, device=self.cdev)
+            self._h_recv = t.empty(n, dtype=t.int64, pin_memory=self._pin)
+        return self._recv
 
     def _merge(self, buf, nq, total, qq, qc):
-        t, dist = self.torch, self.dist
-        any_flag = int(buf["flags"][:nq].ne(0).any().item())
-        meta = t.tensor([total, any_flag], dtype=t.int64, device=self.cdev)
-        dist.all_gather_into_tensor(self.g_meta, meta)
-        m = self.g_meta.cpu().numpy().reshape(self.world, 2)
-        flagged = []
-        if m[:, 1].any():
-            # some shard could not bound some query: find out WHICH queries (the rest of the batch stays on the sparse path)
-            gf = t.zeros(self.world * nq, dtype=t.int32, device=self.cdev)
-            dist.all_gather_into_tensor(gf, buf["flags"][:nq].to(self.cdev).contiguous())
-            flagged = np.nonzero(gf.cpu().numpy().reshape(self.world, nq).any(axis=0))[0].tolist()
-        go = self.g_offsets[:self.world * (nq + 1)]
-        dist.all_gather_into_tensor(go, buf["offsets"][:nq + 1].to(self.cdev).contiguous())
-        maxtot = int(m[1:, 0].max()) if self.world > 1 else 0
-        gp = None
-        if maxtot > 0:
-            gp = self.g_packed[:self.world * maxtot]
-            dist.all_gather_into_tensor(gp, buf["packed"][:maxtot].to(self.cdev).contiguous())
-        res = None
+        t, dist, W, Qb, k = self.torch, self.dist, self.world, self.Qb, self.k
+        # ---- 1. headers: what I hold for every owner block
+        off = buf["offsets"][:nq + 1].to(self.cdev)
+        flags = buf["flags"][:nq].to(self.cdev)
+        pad = W * Qb - nq
+        if pad:
+            off = t.cat([off, off[-1:].expand(pad)])
+            flags = t.cat([flags, t.zeros(pad, dtype=flags.dtype, device=flags.device)])
+        offm = off[:-1].view(W, Qb)
+        starts = offm[:, 0]
+        ends = off[Qb::Qb]
+        counts = ends - starts
+        anyf = flags.ne(0).any().to(t.int64).expand(W)
+        hdr_out = t.cat([counts[:, None], anyf[:, None], flags.view(W, Qb).to(t.int64), offm - starts[:, None], counts[:, None]], 1).contiguous()
+        dist.all_to_all_single(self.hdr_in, hdr_out.view(-1))
+        h = t.cat([self.hdr_in, counts]).cpu().numpy()          # the one host sync of the exchange
+        hin = h[:W * self.hdr_len].reshape(W, self.hdr_len)
+        out_counts = h[W * self.hdr_len:].tolist()
+        in_counts = hin[:, 0].tolist()
+        any_flag = bool(hin[:, 1].any())
+        # ---- 2. the packed entries of my block, from every shard
+        n_in = int(sum(in_counts))
+        recv = self._grow(n_in)[:n_in]
+        send = buf["packed"][:total].to(self.cdev)
+        dist.all_to_all_single(recv, send, output_split_sizes=in_counts, input_split_sizes=out_counts)
+        self._h_recv[:n_in].copy_(recv, non_blocking=True)
+        if recv.is_cuda:
+            t.cuda.current_stream().synchronize()
+        hp = self._h_recv[:n_in].numpy().view(np.uint64)
+        # ---- replay of my block (shard order = rank order)
+        nqb = max(0, min(Qb, nq - self.rank * Qb))
+        res = np.zeros((Qb, 2 * k + 1), np.int32)
+        if nqb > 0:
+            packed, offsets, cum = [], [], 0
+            for s in range(W):
+                packed.append(hp[cum:cum + in_counts[s]])
+                offsets.append(np.ascontiguousarray(hin[s, 2 + Qb:2 + Qb + nqb + 1]))
+                cum += in_counts[s]
+            idx, sc, cnt = capi.replay_batch(packed, offsets, nqb, self.n_total, k, self.threads)
+            res[:nqb, :k] = idx
+            res[:nqb, k:2 * k] = sc.view(np.int32)
+            res[:nqb, 2 * k] = cnt
+        self.last_exchange = {"entries_received": n_in, "entries_sent": int(total), "header_int64": int(W * self.hdr_len), "block_queries": int(nqb)}
+        # ---- 3. answers of every block to rank 0
+        self.res_out.copy_(t.from_numpy(res.reshape(-1)))
+        dist.gather(self.res_out, self.res_in, dst=0)
+        out = None
         if self.rank == 0:
-            h_off = go.cpu().numpy().reshape(self.world, nq + 1)
-            packed = [self._to_host(self.h_own, buf["packed"][:int(m[0, 0])]).view(np.uint64)]
-            offsets = [h_off[0]]
-            if self.world > 1 and maxtot > 0:
-                h_p = self._to_host(self.h_packed, gp).view(np.uint64).reshape(self.world, maxtot)
-                for r in range(1, self.world):
-                    packed.append(h_p[r, :int(m[r, 0])])
-                    offsets.append(h_off[r])
-            elif self.world > 1:
-                for r in range(1, self.world):
-                    packed.append(np.zeros(0, np.uint64))
-                    offsets.append(h_off[r])
-            res = capi.replay_batch(packed, offsets, nq, self.n_total, self.k, self.threads)
-        if flagged:   # collective: every rank takes part; rank 0 overwrites those queries' rows
-            self._merge_dense(flagged, qq, qc, res)
-        return res
+            allr = t.stack(self.res_in).cpu().numpy().reshape(W * Qb, 2 * k + 1)[:nq]
+            out = (np.ascontiguousarray(allr[:, :k]), np.ascontiguousarray(allr[:, k:2 * k]).view(np.float32), allr[:, 2 * k].astype(np.int64))
+        if any_flag:   # collective: every rank takes part; rank 0 overwrites those queries' rows
+            gf = t.zeros(W * nq, dtype=t.int32, device=self.cdev)
+            dist.all_gather_into_tensor(gf, buf["flags"][:nq].to(self.cdev).contiguous())
+            flagged = np.nonzero(gf.cpu().numpy().reshape(W, nq).any(axis=0))[0].tolist()
+            self._merge_dense(flagged, qq, qc, out)
+        return out
 
     def _merge_dense(self, which, qq, qc, res):
         """a shard could not bound these queries (NaN scores / a flood beyond every buffer): every rank scores all its rows

@@ -23,7 +23,7 @@ def _run(world, mode, tmp_path):
     return json.load(open(out))
 
 
-@pytest.mark.parametrize("world,mode", [(2, "ties"), (3, "ties"), (2, "plain"), (2, "flag")])
+@pytest.mark.parametrize("world,mode", [(2, "ties"), (3, "ties"), (2, "plain"), (2, "flag"), (4, "ties"), (4, "flag")])
 def test_sharded_search_over_gloo(world, mode, tmp_path):
     res = _run(world, mode, tmp_path)
     assert res["ok"], res
