@@ -227,11 +227,13 @@ void add_storage_segments(const bbq_index *ix, Plan &p, int storage, const Stora
   }
 }
 
-void build_plan(bbq_index *ix, int64_t k) {
+// k: the rank the device selects thresholds with; final_k > 0: k == final_k + 1 and the last finalize launch selects the answer
+void build_plan(bbq_index *ix, int64_t k, int64_t final_k = 0) {
   Plan &p = ix->plan;
-  if (p.k == k) return;
+  if (p.k == k && p.final_k == final_k) return;
   p = Plan();
   p.k = k;
+  p.final_k = final_k;
   p.s0 = std::max<int64_t>(ix->opt_s0, (4 * k + kChunkRows - 1) / kChunkRows * kChunkRows);
   p.s0 = std::min<int64_t>(p.s0, 8192);
   double expected_emit = 0, dummy = 0;
@@ -282,6 +284,13 @@ void free_slot_buffers(Slot &s) {
   if (s.h_lists) (void)hipHostFree(s.h_lists);
   if (s.d_dense0) (void)hipFree(s.d_dense0);
   if (s.d_ovf) (void)hipFree(s.d_ovf);
+  if (s.d_final) (void)hipFree(s.d_final);
+  if (s.h_final) (void)hipHostFree(s.h_final);
+  if (s.d_final_info) (void)hipFree(s.d_final_info);
+  if (s.h_final_info) (void)hipHostFree(s.h_final_info);
+  s.d_final = s.h_final = nullptr;
+  s.d_final_info = s.h_final_info = nullptr;
+  s.final_stride = 0;
   s.d_ovf = nullptr;
   s.d_ovf_counts = nullptr;
   s.d_qbuf = s.h_qbuf = nullptr;
@@ -300,7 +309,7 @@ int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
   const int64_t hprefix = std::min<int64_t>(p.list_cap, 16384);
   const bool ok = s.q_cap >= nq && s.qbuf_bytes >= qb && s.chunks_cap >= p.max_chunks && s.slots_cap >= p.max_slots &&
                   s.dense_cap >= p.s0 && s.list_cap >= p.list_cap + (own_lists ? p.flood_cap : 0) && s.k_cap >= p.k && s.hprefix >= hprefix &&
-                  s.flood_cap >= p.flood_cap &&
+                  s.flood_cap >= p.flood_cap && s.final_stride >= p.final_k &&
                   (!own_lists || s.d_lists != nullptr);
   if (ok) return BBQ_OK;
   free_slot_buffers(s);
@@ -331,6 +340,11 @@ int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
     HIPCHK(hipMalloc((void **)&s.d_lists, (size_t)(Q * s.list_cap) * 8));
     HIPCHK(hipHostMalloc((void **)&s.h_lists, (size_t)(Q * s.hprefix) * 8, hipHostMallocDefault));
   }
+  s.final_stride = std::max<int64_t>(p.final_k, 128);
+  HIPCHK(hipMalloc((void **)&s.d_final, (size_t)(Q * s.final_stride) * 8));
+  HIPCHK(hipHostMalloc((void **)&s.h_final, (size_t)(Q * s.final_stride) * 8, hipHostMallocDefault));
+  HIPCHK(hipMalloc((void **)&s.d_final_info, (size_t)Q * 8));
+  HIPCHK(hipHostMalloc((void **)&s.h_final_info, (size_t)Q * 8, hipHostMallocDefault));
   s.q_cap = Q;
   return BBQ_OK;
 }
@@ -510,6 +524,7 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
   HIPCHK(hipMemsetAsync(s.d_theta, 0, (size_t)s.q_cap * 24, st));
   if (d_counts_ext) HIPCHK(hipMemsetAsync(d_counts_ext, 0, (size_t)nq * 8, st));
 
+  const bool use_final = !d_lists_ext && p.final_k > 0 && !p.segs.empty();
   s.timed = false;
   for (const Segment &g : p.segs) {
     const Storage &sto = g.storage == 0 ? ix->pilot : ix->main;
@@ -575,12 +590,27 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
     f.flags = s.d_flags;
     f.k = (int32_t)c.k;
     f.need_theta = g.need_theta ? 1 : 0;
+    if (use_final && &g == &p.segs.back()) {
+      f.final_out = s.d_final;
+      f.final_info = s.d_final_info;
+      f.final_stride = (int32_t)s.final_stride;
+      f.final_k = (int32_t)p.final_k;
+    }
     HIPCHK(launch_finalize(f, nq, st));
   }
+  s.final_used = use_final;
   if (!d_lists_ext) {
     HIPCHK(hipMemcpyAsync(s.h_list_counts, s.d_list_counts, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpy2DAsync(s.h_lists, (size_t)s.hprefix * 8, s.d_lists, (size_t)s.list_cap * 8, (size_t)s.hprefix * 8, (size_t)nq,
-                            hipMemcpyDeviceToHost, st));
+    if (use_final) {
+      // the answer itself (k entries per query) instead of the candidate list: the list is fetched only for a query whose
+      // answer the device could not prove (ties), see begin_replay
+      HIPCHK(hipMemcpyAsync(s.h_final_info, s.d_final_info, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpy2DAsync(s.h_final, (size_t)s.final_stride * 8, s.d_final, (size_t)s.final_stride * 8, (size_t)p.final_k * 8, (size_t)nq,
+                              hipMemcpyDeviceToHost, st));
+    } else {
+      HIPCHK(hipMemcpy2DAsync(s.h_lists, (size_t)s.hprefix * 8, s.d_lists, (size_t)s.list_cap * 8, (size_t)s.hprefix * 8, (size_t)nq,
+                              hipMemcpyDeviceToHost, st));
+    }
   }
   HIPCHK(hipEventRecord(s.ev_done, st));
   s.busy = true;
@@ -662,25 +692,49 @@ int begin_replay(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score,
   const int nq = s.nq;
   s.dense_q.clear();
   s.tails.assign((size_t)nq, std::vector<uint64_t>());
+  const bool fin = s.final_used;
+  const int64_t covered = fin ? 0 : s.hprefix;  // list entries the enqueue-time copy brought over
+  int n_replay = 0;
+  struct CountReplays {  // on every exit path
+    bbq_index *ix; int &n;
+    ~CountReplays() { ix->stats.host_replays += n; }
+  } count_replays{ix, n_replay};
   for (int i = 0; i < nq; ++i) {
     const int32_t cnt = s.h_list_counts[2 * i], flags = s.h_list_counts[2 * i + 1];
     if (flags != 0) { s.dense_q.push_back(i); continue; }
-    if (cnt > s.hprefix) {  // rare: fetch what the prefix copy did not cover
-      s.tails[(size_t)i].resize((size_t)(cnt - s.hprefix));
-      HIPCHK(hipMemcpy(s.tails[(size_t)i].data(), s.d_lists + (size_t)i * s.list_cap + s.hprefix, (size_t)(cnt - s.hprefix) * 8,
+    if (fin && s.h_final_info[2 * i + 1] == 0) continue;  // answered on the device
+    ++n_replay;
+    if (cnt > covered) {  // rare: fetch what the enqueue-time copy did not cover (everything, when the device was to answer)
+      s.tails[(size_t)i].resize((size_t)(cnt - covered));
+      HIPCHK(hipMemcpy(s.tails[(size_t)i].data(), s.d_lists + (size_t)i * s.list_cap + covered, (size_t)(cnt - covered) * 8,
                        hipMemcpyDeviceToHost));
     }
   }
   const int64_t k = c.k, n_total = ix->main.row_id_base + ix->main.view.n_rows;
   Slot *sp = &s;
-  auto replay_range = [sp, k, n_total, out_idx, out_score, out_n](int lo, int hi) {
+  if (fin) {  // queries the last finalize launch answered: the sorted rows are the result
+    for (int i = 0; i < nq; ++i) {
+      if (s.h_list_counts[2 * i + 1] != 0 || s.h_final_info[2 * i + 1] != 0) continue;
+      const int64_t qi = s.q_first + i;
+      const int32_t m = s.h_final_info[2 * i];
+      const uint64_t *fo = s.h_final + (size_t)i * s.final_stride;
+      for (int32_t j = 0; j < m; ++j) {
+        const uint32_t bits = (uint32_t)fo[j];
+        out_idx[qi * k + j] = (int32_t)(uint32_t)(fo[j] >> 32);
+        memcpy(&out_score[qi * k + j], &bits, 4);
+      }
+      out_n[qi] = m;
+    }
+  }
+  auto replay_range = [sp, k, n_total, out_idx, out_score, out_n, fin, covered](int lo, int hi) {
     Slot &s = *sp;
     for (int i = lo; i < hi; ++i) {
       const int32_t cnt = s.h_list_counts[2 * i], flags = s.h_list_counts[2 * i + 1];
       if (flags != 0) continue;
+      if (fin && s.h_final_info[2 * i + 1] == 0) continue;
       HeapReplay hr(k, n_total);
       const uint64_t *l = s.h_lists + (size_t)i * s.hprefix;
-      const int64_t head = std::min<int64_t>(cnt, s.hprefix);
+      const int64_t head = std::min<int64_t>(cnt, covered);
       for (int64_t j = 0; j < head; ++j) {
         const uint32_t bits = (uint32_t)l[j];
         float sc;
@@ -697,9 +751,11 @@ int begin_replay(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score,
       out_n[qi] = hr.finish(out_idx + qi * k, out_score + qi * k);
     }
   };
-  const int T = std::min(ix->opt_replay_threads, nq);
+  const int T = std::min(ix->opt_replay_threads, n_replay);
   s.replaying = true;
-  if (T <= 1) {
+  if (n_replay == 0) {
+    // nothing to replay
+  } else if (T <= 1) {
     replay_range(0, nq);
   } else {
     ReplayPool &pool = ReplayPool::get();
@@ -737,7 +793,7 @@ int finish_replay(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score
     const int64_t qi = first + flagged[j];
     if (ix->opt_share > 1 && ix->plan.flood_cap > 0 && why[j] == kFlagOverflow) {
       BatchCtx cs = c;
-      cs.k = std::min<int64_t>(c.k, ix->n_rows);
+      cs.k = ix->plan.k;  // the rank the device runs this call with
       const int share = ix->opt_share;
       ix->opt_share = 1;
       int rc = enqueue_subbatch(cs, s, qi, 1, nullptr, 0, nullptr);
@@ -918,6 +974,7 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
   if (ix->multi) {
     ix->stats.candidates = 0;
     ix->stats.dense_fallbacks = 0;
+    ix->stats.host_replays = 0;
     if (ix->n_rows == 0) return BBQ_OK;
     return multi_search_batch(ix, n_queries, qquant, qcorr, query_bits, sim, k, out_idx, out_score, out_n);
   }
@@ -927,6 +984,7 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
   HIPCHK(hipSetDevice(ix->device));
   ix->stats.candidates = 0;
   ix->stats.dense_fallbacks = 0;
+  ix->stats.host_replays = 0;
   if (ix->n_rows == 0) return BBQ_OK;
 
   BatchCtx c{ix, qquant, qcorr, planes_of_call(ix, qquant, (int64_t)n_queries * ix->dim, query_bits == 1), query_bits == 1 ? 1 : 0, sim, k};
@@ -943,8 +1001,11 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
   // thresholds are order statistics of rank k2 = min(k, N): selecting with a larger k would be wrong.
   // cs drives the device (k2); c (the caller's k) strides the outputs and sizes the replayed heap.
   BatchCtx cs = c;
-  cs.k = keff;
-  build_plan(ix, keff);
+  // up to kFinalSelectMax the device runs with rank keff + 1 and the last finalize launch selects and sorts the answer itself
+  // (FinalizeArgs::final_out); the host replays the heap only for queries with equal scores in or at the edge of their answer
+  const int64_t final_k = (keff <= kFinalSelectMax && ix->opt_device_select) ? keff : 0;
+  cs.k = final_k > 0 ? keff + 1 : keff;
+  build_plan(ix, cs.k, final_k);
   const int Q = std::max(1, ix->opt_batch);
   const int nslots = std::min(std::max(1, ix->opt_slots), kMaxSlots);
   const int64_t nsub = ((int64_t)n_queries + Q - 1) / Q;
@@ -1142,6 +1203,7 @@ int bbq_set_option(bbq_index *ix, const char *name, int64_t v) {
   else if (n == "first_segment_rows" && v >= 1024 && v <= 8192 && v % kChunkRows == 0) { ix->opt_s0 = v; ix->plan.k = -1; }
   else if (n == "replay_threads" && v >= 1 && v <= 256) ix->opt_replay_threads = (int)v;
   else if (n == "force_dense" && (v == 0 || v == 1)) ix->opt_force_dense = (int)v;
+  else if (n == "device_select" && (v == 0 || v == 1)) ix->opt_device_select = (int)v;
   else if (n == "sweep_share" && (v == 1 || v == 4 || v == 8 || v == 32)) ix->opt_share = (int)v;
   else if (n == "flood_rows" && v >= 0 && v <= (1 << 24)) ix->opt_flood = (v + 1023) / 1024 * 1024;
   else return fail(BBQ_ERR_INVALID_ARG, "bbq_set_option: unknown option or value out of range: %s=%lld", name, (long long)v);

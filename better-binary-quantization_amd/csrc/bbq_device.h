@@ -125,7 +125,19 @@ struct FinalizeArgs {
   uint32_t *flags;             // [Q]
   int32_t k;
   int32_t need_theta;          // 0 on the last segment
+  // final selection (last segment only; null: none).  The caller runs the whole query with k = k2 + 1, so the running top keys
+  // hold the (k2 + 1) largest keys seen: the launch then knows the (k2 + 1)-th largest f32 score of the whole index exactly,
+  // gathers the k2 rows above it from the list, sorts them by score and checks that no two of them - and not the boundary -
+  // compare equal.  In that case the reference's heap (src/binaryQuantizationFormat.ts:383-411) ends up holding exactly those rows
+  // whatever its history was and pops them in ascending score order, so the answer is the descending sort: final_info = {k2, 0}.
+  // Any tie, NaN flag, list overflow, a flood beyond the key buffer or k2 > kFinalSelectMax leaves final_info = {0, 1}: the host
+  // replays the heap over the list as before.
+  uint64_t *final_out;         // [Q][final_stride] (global row << 32 | f32 score bits), descending by score
+  int32_t *final_info;         // [Q][2] {entries in final_out, 1 = replay the list on the host}
+  int32_t final_stride;
+  int32_t final_k;             // k2 = min(k, rows of the index)
 };
+constexpr int kFinalSelectMax = 1024;  // largest k2 the finalize kernel selects and sorts itself
 
 // exact rerank (bbq_rerank_kernels.hip): candidates of query q are rows[offsets[q] .. offsets[q+1])
 struct RerankArgs {

@@ -62,6 +62,7 @@ struct Plan {
   int64_t flood_cap = 0;  // per-query entries of the flood tier (overflow area + list headroom); 0: none
   int64_t max_slots = 0;  // max over sparse segments of n_chunks*cap
   int64_t max_chunks = 0;
+  int64_t final_k = 0;    // > 0: the plan runs with k = final_k + 1 and the last finalize launch selects the answer itself
 };
 
 struct Slot {
@@ -76,6 +77,11 @@ struct Slot {
   uint64_t *d_entries = nullptr, *d_lists = nullptr, *h_lists = nullptr, *d_ovf = nullptr;
   uint32_t *d_ovf_counts = nullptr;
   float *d_dense0 = nullptr;
+  // final selection on the device (FinalizeArgs::final_out): the sorted answer + {count, needs-host-replay} per query
+  uint64_t *d_final = nullptr, *h_final = nullptr;
+  int32_t *d_final_info = nullptr, *h_final_info = nullptr;
+  int64_t final_stride = 0;
+  bool final_used = false;  // the in-flight sub-batch was enqueued with the final selection (its list prefix was NOT copied to the host)
   // in-flight sub-batch: busy = device work enqueued and not yet collected; replaying = host replay jobs outstanding
   bool busy = false;
   bool replaying = false;
@@ -141,7 +147,7 @@ struct bbq_index {
   int32_t *d_shard_counts = nullptr;
   int64_t shard_q_cap = 0, shard_list_cap = 0;
   // options
-  int opt_batch = 32, opt_slots = 2, opt_growth = 8, opt_force_dense = 0, opt_share = 1;
+  int opt_batch = 32, opt_slots = 2, opt_growth = 8, opt_force_dense = 0, opt_share = 1, opt_device_select = 1;
   // host threads replaying the heaps of one sub-batch: half the cores, at most 8 (a batch of 32 answers 1.4x sooner than with 1)
   int opt_replay_threads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
   int64_t opt_s0 = 4096;

@@ -494,6 +494,48 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
   return wave_off + incl - v;
 }
 
+// k-th largest of the M keys in LDS (M >= k >= 1): 4-pass radix select, one 1024-thread workgroup; every thread returns it
+__device__ __forceinline__ uint32_t block_select_kth_largest(const uint32_t *s_keys, uint32_t M, uint32_t k, uint32_t *s_hist, uint32_t *s_misc) {
+  const int tid = threadIdx.x;
+  uint32_t prefix = 0, mask = 0, kk = k;
+  for (int pass = 3; pass >= 0; --pass) {
+    if (tid < 256) s_hist[tid] = 0;
+    __syncthreads();
+    const int sh = pass * 8;
+    for (uint32_t i = tid; i < M; i += kFinalizeThreads) {
+      const uint32_t key = s_keys[i];
+      if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> sh) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      // wave 0 finds the bin: lane l owns bins 4l..4l+3; suffix sums over lanes by shuffles (no LDS round trips)
+      const uint32_t h0 = s_hist[4 * tid], h1 = s_hist[4 * tid + 1], h2 = s_hist[4 * tid + 2], h3 = s_hist[4 * tid + 3];
+      uint32_t suf = h0 + h1 + h2 + h3;  // becomes the sum over bins >= 4*tid
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t n = __shfl_down(suf, d, 64);
+        if (tid + d < 64) suf += n;
+      }
+      const uint32_t above = suf - (h0 + h1 + h2 + h3);  // bins > 4*tid+3
+      if (suf >= kk && above < kk) {                     // exactly one lane: the k-th largest lies in its 4 bins
+        uint32_t cum = above;
+        int b = 4 * tid + 3;
+        if (cum + h3 < kk) { cum += h3; b = 4 * tid + 2;
+          if (cum + h2 < kk) { cum += h2; b = 4 * tid + 1;
+            if (cum + h1 < kk) { cum += h1; b = 4 * tid; } } }
+        s_misc[0] = (uint32_t)b;
+        s_misc[1] = kk - cum;
+      }
+    }
+    __syncthreads();
+    prefix |= s_misc[0] << sh;
+    mask |= 255u << sh;
+    kk = s_misc[1];
+    __syncthreads();
+  }
+  return prefix;
+}
+
 __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const FinalizeArgs a) {
   __shared__ uint32_t s_keys[kFinalizeKeyCap];
   __shared__ uint32_t s_hist[256];
@@ -581,44 +623,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
         for (uint32_t i = tid; i < M; i += kFinalizeThreads) tk[i] = s_keys[i];
         if (tid == 0) { a.topk_counts[q] = (int32_t)M; a.theta[q] = 0u; }
       } else {
-        // 4-pass radix select of the k-th largest key
-        uint32_t prefix = 0, mask = 0, kk = (uint32_t)a.k;
-        for (int pass = 3; pass >= 0; --pass) {
-          if (tid < 256) s_hist[tid] = 0;
-          __syncthreads();
-          const int sh = pass * 8;
-          for (uint32_t i = tid; i < M; i += kFinalizeThreads) {
-            const uint32_t key = s_keys[i];
-            if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> sh) & 255u], 1u);
-          }
-          __syncthreads();
-          if (tid < 64) {
-            // wave 0 finds the bin: lane l owns bins 4l..4l+3; suffix sums over lanes by shuffles (no LDS round trips)
-            const uint32_t h0 = s_hist[4 * tid], h1 = s_hist[4 * tid + 1], h2 = s_hist[4 * tid + 2], h3 = s_hist[4 * tid + 3];
-            uint32_t suf = h0 + h1 + h2 + h3;  // becomes the sum over bins >= 4*tid
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-              const uint32_t n = __shfl_down(suf, d, 64);
-              if (tid + d < 64) suf += n;
-            }
-            const uint32_t above = suf - (h0 + h1 + h2 + h3);  // bins > 4*tid+3
-            if (suf >= kk && above < kk) {                     // exactly one lane: the k-th largest lies in its 4 bins
-              uint32_t cum = above;
-              int b = 4 * tid + 3;
-              if (cum + h3 < kk) { cum += h3; b = 4 * tid + 2;
-                if (cum + h2 < kk) { cum += h2; b = 4 * tid + 1;
-                  if (cum + h1 < kk) { cum += h1; b = 4 * tid; } } }
-              s_misc[0] = (uint32_t)b;
-              s_misc[1] = kk - cum;
-            }
-          }
-          __syncthreads();
-          prefix |= s_misc[0] << sh;
-          mask |= 255u << sh;
-          kk = s_misc[1];
-          __syncthreads();
-        }
-        const uint32_t th = prefix;  // exactly the k-th largest key among the M keys
+        const uint32_t th = block_select_kth_largest(s_keys, M, (uint32_t)a.k, s_hist, s_misc);  // exactly the k-th largest key among the M keys
         if (tid == 0) s_misc[2] = 0;
         __syncthreads();
         for (uint32_t i = tid; i < M; i += kFinalizeThreads) {
@@ -632,10 +637,100 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
       }
     }
   }
+  const uint32_t f_all = a.flags[q] | flags;  // every thread: uniform (the flags word is only written by thread 0 below, after this read ...)
+  __syncthreads();                             // ... which this barrier orders
   if (tid == 0) {
-    const uint32_t f = a.flags[q] | flags;
-    a.flags[q] = f;
-    a.list_counts[2 * q + 1] = (int32_t)f;
+    a.flags[q] = f_all;
+    a.list_counts[2 * q + 1] = (int32_t)f_all;
+  }
+
+  if (a.final_out) {  // last segment: select and sort the answer on the device when that is provably what the heap returns
+    const int k2 = a.final_k;
+    const int64_t total = base + m_new;  // entries of the complete list
+    const uint32_t tcount = (uint32_t)a.topk_counts[q];
+    bool ok = f_all == 0 && a.emit && total <= a.list_cap && k2 >= 1 && k2 <= kFinalSelectMax && k2 <= a.final_stride &&
+              m_new <= (uint32_t)kFinalizeKeyCap - tcount;
+    uint64_t *__restrict__ s_sel = reinterpret_cast<uint64_t *>(s_jobs);  // 1536 slots; the flood jobs are done with
+    uint32_t n_sel = 0;
+    if (ok) {
+      uint32_t th1 = 0;        // rows with key > th1 are the answer
+      bool take_all = total <= (int64_t)k2;
+      if (!take_all) {
+        // the (k2 + 1)-th largest key of the whole index = the (k2 + 1)-th largest of {running top keys (the k2 + 1 largest of the
+        // earlier segments, a.k == k2 + 1) U this segment's keys}; s_keys[0, m_new) still holds the latter
+        const uint32_t *__restrict__ tk = a.topk_keys + (size_t)q * a.k;
+        for (uint32_t i = tid; i < tcount; i += kFinalizeThreads) s_keys[m_new + i] = tk[i];
+        const uint32_t M = m_new + tcount;
+        __syncthreads();
+        if (a.k != k2 + 1 || M < (uint32_t)(k2 + 1)) {
+          ok = false;  // uniform
+        } else {
+          th1 = block_select_kth_largest(s_keys, M, (uint32_t)(k2 + 1), s_hist, s_misc);
+        }
+      }
+      if (ok) {
+        if (tid == 0) s_misc[2] = 0;
+        __syncthreads();
+        for (int64_t i = tid; i < total; i += kFinalizeThreads) {
+          const uint64_t ent = list[i];
+          const uint32_t key = key_of_bits((uint32_t)ent);
+          if (take_all || key > th1) {
+            const uint32_t slot = atomicAdd(&s_misc[2], 1u);
+            if (slot < (uint32_t)kFinalSelectMax) s_sel[slot] = ((uint64_t)key << 32) | (ent >> 32);
+          }
+        }
+        __syncthreads();
+        n_sel = s_misc[2];
+        // exactly k2 rows above the boundary (fewer: the boundary value repeats; a list shorter than k2 + 1 rows holds them all)
+        ok = take_all ? (n_sel == (uint32_t)total) : (n_sel == (uint32_t)k2);
+      }
+      if (ok) {
+        // bitonic sort, descending, of n_sel (<= 1024) items padded with zeros (key 0 is below every real key)
+        uint32_t n_pad = 1;
+        while (n_pad < n_sel) n_pad <<= 1;
+        for (uint32_t i = n_sel + tid; i < n_pad; i += kFinalizeThreads) s_sel[i] = 0;
+        __syncthreads();
+        for (uint32_t size = 2; size <= n_pad; size <<= 1) {
+          for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            const uint32_t i = tid;
+            if (i < n_pad) {
+              const uint32_t j = i ^ stride;
+              if (j > i) {
+                const uint64_t x = s_sel[i], y = s_sel[j];
+                const bool desc = (i & size) == 0;
+                if (desc ? (x < y) : (x > y)) { s_sel[i] = y; s_sel[j] = x; }
+              }
+            }
+            __syncthreads();
+          }
+        }
+        // equal scores (as floats: +0 == -0) anywhere in the answer or at its boundary: the heap's history decides - host replay
+        if (tid == 0) s_misc[3] = 0;
+        __syncthreads();
+        auto bits_of = [](uint32_t key) -> uint32_t { return (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key; };
+        if ((uint32_t)tid + 1 < n_sel) {
+          const float x = __uint_as_float(bits_of((uint32_t)(s_sel[tid] >> 32))), y = __uint_as_float(bits_of((uint32_t)(s_sel[tid + 1] >> 32)));
+          if (x == y) s_misc[3] = 1;
+        }
+        if (tid == 0 && !take_all && n_sel > 0) {
+          const float x = __uint_as_float(bits_of((uint32_t)(s_sel[n_sel - 1] >> 32))), y = __uint_as_float(bits_of(th1));
+          if (x == y) s_misc[3] = 1;
+        }
+        __syncthreads();
+        ok = s_misc[3] == 0;
+        if (ok) {
+          uint64_t *__restrict__ fo = a.final_out + (size_t)q * a.final_stride;
+          if ((uint32_t)tid < n_sel) {
+            const uint64_t it = s_sel[tid];
+            fo[tid] = ((uint64_t)(uint32_t)it << 32) | bits_of((uint32_t)(it >> 32));
+          }
+        }
+      }
+    }
+    if (tid == 0) {
+      a.final_info[2 * q] = ok ? (int32_t)n_sel : 0;
+      a.final_info[2 * q + 1] = ok ? 0 : 1;
+    }
   }
 }
 

@@ -241,6 +241,7 @@ int multi_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, 
       }
     }
     if (rc_all == BBQ_OK) {
+      ix->stats.host_replays += nq;
       rc_all = bbq_replay_batch(S, packed.data(), offsets.data(), nq, ix->n_rows, k, ix->opt_replay_threads, out_idx + (int64_t)q0 * k,
                                 out_score + (int64_t)q0 * k, out_n + q0);
       if (rc_all != BBQ_OK) err_all = bbq_last_error();

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BBQ_ABI_VERSION 1
+#define BBQ_ABI_VERSION 2  /* 2: multi-bit and multi-device indexes, bbq_stats.host_replays */
 
 /* status codes */
 enum {
@@ -294,13 +294,17 @@ typedef struct {
   double total_scan_ms;       /* sum of hipEvent times of every dominant-scan launch since the last reset */
   int64_t total_scan_bytes;   /* and their algorithmic bytes */
   int64_t total_scan_launches;
+  int64_t host_replays;       /* queries of the last call whose heap was replayed on the host (equal scores in or at the edge of the
+                                 answer, k > 1024, device_select 0); the others were selected and sorted by the last finalize launch */
 } bbq_stats;
 int bbq_get_stats(bbq_index *idx, bbq_stats *out);
 int bbq_reset_stats(bbq_index *idx);
 /* tuning knobs; returns BBQ_ERR_INVALID_ARG for unknown names or values out of range (DESIGN.md "Knobs"):
  *   batch_queries 1..1024 (32)   pipeline_slots 1..4 (2)   segment_growth 2..1024 (8)   first_segment_rows 1024..8192 (4096)
  *   replay_threads 1..256 (half the host cores, at most 8)   flood_rows 0..2^24 (262144)   force_dense 0|1 (0)
- *   sweep_share 1|4|8|32 (1: every query sweeps the index itself; 32: shared sweep on the matrix cores) */
+ *   sweep_share 1|4|8|32 (1: every query sweeps the index itself; 32: shared sweep on the matrix cores)
+ *   device_select 0|1 (1: for k <= 1024 the device selects and sorts the answer itself whenever no two scores in or at the edge of it
+ *   compare equal - then the reference heap provably returns that order - and the host replays the heap only for the rest) */
 int bbq_set_option(bbq_index *idx, const char *name, int64_t value);
 
 #ifdef __cplusplus

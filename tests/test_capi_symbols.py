@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(lib, n), "libbbq.so does not export %s" % n
     assert sorted(capi.SYMBOLS) == names, "capi.py binds a different set than include/bbq.h declares"
-    assert lib.bbq_abi_version() == 1
+    assert lib.bbq_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_device():

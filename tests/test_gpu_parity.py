@@ -1086,3 +1086,64 @@ def test_fuzz_medium_sizes_vs_oracle(seed):
         assert ix.stats()["dense_fallbacks"] == 0
     finally:
         ix.close()
+
+
+# ---------------------------------------------------------------- answers selected on the device vs replayed on the host
+
+@pytest.mark.parametrize("name", ["ties_cos_qb4", "ties_16d_qb1", "big_20000x128_cos", "m_768d_cos_qb4", "edge_zero_const", "edge_n1",
+                                  "c1_1000x128_cos_qb4", "ib2_ties_cos_qb4", "big_20000x1024_cos"])
+def test_device_selected_answers_equal_host_replay(name):
+    """device_select 1 (default): the last finalize launch selects and sorts the answer when no two scores in or at the edge of it
+    compare equal; otherwise - and always with device_select 0 - the host replays the reference heap.  Same bits either way, and
+    the tie-stress fixtures really take the replay while tie-free data never does."""
+    g = O.load_golden(name)
+    sim, base, queries, codes, corr, cen, cdp = _index_from_case(g)
+    ix = _make_index(codes, corr, g["dim"], cdp, True, index_bits=g["ib"])
+    try:
+        ix.set_option("first_segment_rows", 1024)
+        ix.set_option("segment_growth", 2)
+        qs = [B.quantize_query(q, cen, sim, g["qb"], g["lambda"], g["iters"]) for q in queries]
+        qq, qc = np.stack([a for a, _ in qs]), np.stack([b for _, b in qs])
+        for k in sorted({t["k"] for t in g["queries"][0]["topk"]}):
+            res, replays = {}, {}
+            for sel in (1, 0):
+                ix.set_option("device_select", sel)
+                res[sel] = ix.search_batch(qq, qc, g["qb"], sim, k)
+                replays[sel] = ix.stats()["host_replays"]
+            np.testing.assert_array_equal(res[1][0], res[0][0])
+            np.testing.assert_array_equal(canon32(res[1][1]), canon32(res[0][1]))
+            np.testing.assert_array_equal(res[1][2], res[0][2])
+            for qi in range(len(queries)):
+                tk = [t for t in g["queries"][qi]["topk"] if t["k"] == k][0]
+                np.testing.assert_array_equal(res[1][0][qi, :res[1][2][qi]], O.dec(tk["idx_i32"], "<i4"))
+            nan_case = np.isnan(res[0][1]).any()
+            assert replays[0] + ix.stats()["dense_fallbacks"] >= len(queries) - (len(queries) if nan_case else 0)
+            if name.startswith(("ties_", "ib2_ties")) and k >= 7:
+                assert replays[1] > 0, "tie-stress fixture answered without a replay"
+            if name.startswith("big_"):
+                assert replays[1] == 0, "tie-free data needed a host replay"
+    finally:
+        ix.close()
+
+
+def test_device_select_boundary_ties_and_duplicates():
+    """duplicate rows straddling the k-th place, +0 / -0, k = N, k = N - 1, k = 1024 / 1025: the device either proves its answer or
+    hands the query to the host replay; the oracle's heap decides what is right"""
+    rng = np.random.default_rng(31)
+    n, dim, sim = 5000, 64, 1
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    base[100:140] = base[7]            # 41 equal rows: ties inside and at the edge of small answers
+    base[4000] = base[3000]
+    codes, corr, cen = B.quantize_vectors(base, sim)
+    cdp = B.centroid_dp(cen)
+    qq, qc = B.quantize_query(base[7] + 0.01 * rng.standard_normal(dim).astype(np.float32), cen, sim, 4)
+    _, _, s32 = O.score_all(codes, corr, dim, qq, qc, 4, sim, cdp)
+    ix = B.Index(codes, corr, dim, cdp)
+    try:
+        for k in (1, 5, 41, 42, 100, 1024, 1025, n - 1, n, n + 5):
+            idx, sc = ix.search(qq, qc, 4, sim, k)
+            oi, osc = O.heap_topk(s32, k)
+            np.testing.assert_array_equal(idx, oi, err_msg="k=%d" % k)
+            np.testing.assert_array_equal(canon32(sc), canon32(osc))
+    finally:
+        ix.close()
