@@ -93,38 +93,55 @@ def synth_queries(seed, nq, dim, qb=4):
 
 def recall_probe(B, device, n=1_000_000, dim=768, nq=32, k=100):
     """real fp32 vectors -> quantizeVectors on the device -> GPU search, recall@k against an fp32 brute force (torch, same GPU).
-    SURVEY 8(d): a 1 M x 768 fp32 run; --recall-rows 10000000 repeats it at the headline size (30.7 GB of fp32)."""
+    SURVEY 8(d) asks for a 1 M x 768 fp32 run; the default is the headline size, 10 M x 768 (30.7 GB of fp32).
+    The vectors are generated ON THE DEVICE block by block (seeded per block, so the brute force regenerates them instead of
+    reading them back); the host copy exists only because bbq_index_build / bbq_vectors_create take host arrays, as the
+    reference's API does."""
     import torch
-    rng = np.random.default_rng(99)
+    dev = "cuda:%d" % device
+    BLOCK = 500_000
     # embedding-like data: 64 latent factors + isotropic noise (uniform random vectors have no neighbour structure to recall,
     # tight clusters larger than k make every member an equally good neighbour).  Neighbour distances form a continuum.
-    W = rng.standard_normal((64, dim), dtype=np.float32)
+    g0 = torch.Generator(device=dev)
+    g0.manual_seed(99)
+    W = torch.randn(64, dim, generator=g0, device=dev)
+    queries_d = torch.randn(nq, 64, generator=g0, device=dev) @ W + 0.8 * torch.randn(nq, dim, generator=g0, device=dev)
+
+    def block(i0):
+        m = min(BLOCK, n - i0)
+        g = torch.Generator(device=dev)
+        g.manual_seed(1000 + i0)
+        return torch.randn(m, 64, generator=g, device=dev) @ W + 0.8 * torch.randn(m, dim, generator=g, device=dev)
+
+    t_gen = time.perf_counter()
     base = np.empty((n, dim), np.float32)
-    for i in range(0, n, 250000):
-        m = min(250000, n - i)
-        base[i:i + m] = rng.standard_normal((m, 64), dtype=np.float32) @ W + 0.8 * rng.standard_normal((m, dim), dtype=np.float32)
-    queries = rng.standard_normal((nq, 64), dtype=np.float32) @ W + 0.8 * rng.standard_normal((nq, dim), dtype=np.float32)
+    for i in range(0, n, BLOCK):
+        b = block(i)
+        base[i:i + b.shape[0]] = b.cpu().numpy()
+        del b
+    queries = queries_d.cpu().numpy()
+    t_gen = time.perf_counter() - t_gen
     sim = 1
+    t_build = time.perf_counter()
     ix, _, _, cen = B.Index.build(base, sim, device=device, want_host_copy=False)
-    qs = [B.quantize_query(q, cen, sim, 4) for q in queries]
-    qq, qc = np.stack([a for a, _ in qs]), np.stack([b for _, b in qs])
+    t_build = time.perf_counter() - t_build
+    qq, qc = B.quantize_queries(queries, cen, sim, 4)
     idx, sc, cnt = ix.search_batch(qq, qc, 4, sim, k)
     # the reference's recall recipe (src/topKSelector.ts:29-79): oversample x3, exact cosine rerank on the device
     dv = B.Vectors(base, device)
+    del base
     B.search_rerank_batch(ix, dv, queries, qq, qc, 4, sim, k, 3, 0, 1)
     t0 = time.perf_counter()
     ridx, _, _, _ = B.search_rerank_batch(ix, dv, queries, qq, qc, 4, sim, k, 3, 0, 1)
     rerank_ms = (time.perf_counter() - t0) * 1e3 / nq
     dv.close()
     ix.close()
-    # fp32 brute force, in row blocks so that the normalised copy never doubles the footprint
-    dev = "cuda:%d" % device
-    tq = torch.from_numpy(queries).to(dev)
-    tq = tq / tq.norm(dim=1, keepdim=True)
+    # fp32 brute force over the regenerated blocks
+    tq = queries_d / queries_d.norm(dim=1, keepdim=True)
     best_s = torch.full((nq, k), -2.0, device=dev)
     best_i = torch.zeros((nq, k), dtype=torch.int64, device=dev)
-    for i in range(0, n, 1_000_000):
-        tb = torch.from_numpy(base[i:i + 1_000_000]).to(dev)
+    for i in range(0, n, BLOCK):
+        tb = block(i)
         tb = tb / tb.norm(dim=1, keepdim=True)
         s_blk, i_blk = (tq @ tb.T).topk(min(k, tb.shape[0]), dim=1)
         cat_s, cat_i = torch.cat([best_s, s_blk], 1), torch.cat([best_i, i_blk + i], 1)
@@ -134,8 +151,9 @@ def recall_probe(B, device, n=1_000_000, dim=768, nq=32, k=100):
     truth = best_i.cpu().numpy()
     rec = np.mean([len(set(truth[i].tolist()) & set(idx[i].tolist())) / float(k) for i in range(nq)])
     rec3 = np.mean([len(set(truth[i].tolist()) & set(ridx[i].tolist())) / float(k) for i in range(nq)])
-    return float(rec), {"n": n, "dim": dim, "queries": nq, "data": "64 latent gaussian factors x random 64x768 map + 0.8 sigma isotropic noise",
-                        "recall_at_100_oversample3_rerank": float(rec3), "oversample3_rerank_ms_per_query": round(rerank_ms, 3)}
+    return float(rec), {"n": n, "dim": dim, "queries": nq, "data": "64 latent gaussian factors x random 64x768 map + 0.8 sigma isotropic noise (generated on the device)",
+                        "recall_at_100_oversample3_rerank": float(rec3), "oversample3_rerank_ms_per_query": round(rerank_ms, 3),
+                        "generate_s": round(t_gen, 1), "build_s": round(t_build, 1)}
 
 
 def oracle_scores(O, codes, corr, dim, qq, qc, qb, sim, cdp, ib):
@@ -148,23 +166,35 @@ def oracle_scores(O, codes, corr, dim, qq, qc, qb, sim, cdp, ib):
     return O.score_all_multibit_ext(codes, corr, dim, qq, qc, qb, sim, cdp)[2]
 
 
-def cpu_baseline(dim, k, codes, corr, qq, qc, cdp, qb, sim, ib=1, budget_s=20.0):
-    """the oracle (CPU restatement of the reference loops, 1 thread) on a bounded sample of the same workload"""
+def host_cpu():
+    """model name and logical cores of the box the CPU baseline runs on"""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count()
+
+
+def cpu_baseline(dim, k, codes, corr, qq, qc, cdp, qb, sim, ib=1, budget_s=16.0):
+    """the oracle (CPU restatement of the reference loops, 1 thread) over the WHOLE index of the timed workload - no
+    extrapolation over rows - for as many of the timed queries as fit the budget (at least one)"""
     import orclib as O
     n = codes.shape[0]
-    rows = min(n, 2_000_000 if ib == 1 else 1_000_000)
-    c, r = np.ascontiguousarray(codes[:rows]), np.ascontiguousarray(corr[:rows])
+    c, r = np.ascontiguousarray(codes), np.ascontiguousarray(corr)
     t0 = time.perf_counter()
     done = 0
     while True:
         s32 = oracle_scores(O, c, r, dim, qq[done % len(qq)], qc[done % len(qq)], qb, sim, cdp, ib)
         O.heap_topk(s32, k)
         done += 1
-        if time.perf_counter() - t0 > budget_s / 2 or done >= 8:
+        if time.perf_counter() - t0 > budget_s or done >= 8:
             break
     dt = time.perf_counter() - t0
-    us_per_row = dt / (done * rows) * 1e6
-    return us_per_row, done, rows, dt
+    return done / dt, done, n, dt
 
 
 def self_launch(args):
@@ -251,7 +281,8 @@ def main():
     ap.add_argument("--replay-threads", type=int, default=16, help="host threads replaying the reference heap")
     ap.add_argument("--pilot", type=int, default=32768, help="replicated pilot rows per non-root shard (multi-GPU)")
     ap.add_argument("--no-recall", action="store_true")
-    ap.add_argument("--recall-rows", type=int, default=1_000_000, help="rows of the fp32 recall probe (10000000 = the headline size)")
+    ap.add_argument("--recall-rows", type=int, default=0, help="rows of the fp32 recall probe (0 = the rows of the timed index, at most 10 M: the headline size)")
+    ap.add_argument("--latency-calls", type=int, default=300, help="single-query calls timed for the latency object (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size oracle check of one timed query")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value")
@@ -394,19 +425,45 @@ def main():
                    "index_stream_GBps": lb / (lms * 1e-3) / 1e9 if lms > 0 else None}
         ix.set_option("sweep_share", 1)
 
+    latency = None
+    if dist is None and args.latency_calls > 0:
+        # the reference's own call shape: ONE synchronous query per call (searchNearestNeighbors), through bbq_search
+        lq, lc = synth_queries(3, 64, dim, QB)
+        for i in range(20):
+            ix.search(lq[i % 64], lc[i % 64], QB, SIM, k)
+        ts = []
+        for i in range(args.latency_calls):
+            t1 = time.perf_counter()
+            ix.search(lq[i % 64], lc[i % 64], QB, SIM, k)
+            ts.append((time.perf_counter() - t1) * 1e3)
+        ts = np.sort(np.array(ts))
+        latency = {"queries_per_call": 1, "calls": len(ts), "p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[min(len(ts) - 1, int(len(ts) * 0.99))]),
+                   "min_ms": float(ts[0]), "one_sweep_at_peak_ms": N * bytes_per_row / (HBM_PEAK_GBS * 1e9) * 1e3,
+                   "path": "bbq_search (ctypes): quantized query in, top-k out; host replays per call: %d" % ix.stats()["host_replays"]}
+
     if rank == 0:
         qps = args.steps * Q / dt
         launch_bytes = st["total_scan_bytes"] / max(st["total_scan_launches"], 1)
         launch_ms = st["total_scan_ms"] / max(st["total_scan_launches"], 1)
         achieved = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_per_row.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj["hbm_bytes_per_row"] * (launch_bytes / bytes_per_row)
-            except Exception:
-                traffic = None
+        # committed rocprofv3 evidence for THIS kernel and layout (profiles/dominant_kernel.json, scripts/summarize_profiles.py): the
+        # PMC traffic per row and the kernel-trace average; anything measured on another layout / width is not quoted
+        traffic, traffic_src, frac_rocprof, rocprof_src = None, None, None, None
+        try:
+            reg = json.load(open(os.path.join(ROOT, "profiles", "dominant_kernel.json")))
+            for e in reg["entries"]:
+                if (e["dim"], e["index_bits"], e["query_bits"], e["bytes_per_row"]) == (dim, IB, QB, bytes_per_row):
+                    if e.get("hbm_bytes_per_row") is not None:
+                        traffic = e["hbm_bytes_per_row"] * (launch_bytes / bytes_per_row)
+                        traffic_src = {"file": "profiles/dominant_kernel.json", "hbm_bytes_per_row": e["hbm_bytes_per_row"], "kernel": e["kernel"],
+                                       "bytes_per_row": e["bytes_per_row"], "collected": e["collected"], "how": e["pmc_how"]}
+                    if e.get("trace_avg_GBps") is not None:
+                        frac_rocprof = e["trace_avg_GBps"] / HBM_PEAK_GBS
+                        rocprof_src = {"file": "profiles/dominant_kernel.json", "trace_avg_us": e["trace_avg_us"], "launches": e["trace_launches"],
+                                       "bytes_per_launch": e["trace_bytes_per_launch"], "collected": e["collected"]}
+                    break
+        except Exception:
+            pass
         out = {
             # BASELINE.json's metric string for the headline configuration; a descriptive one for the other configs
             "metric": ("queries/sec + recall@100 vs fp32 brute-force, 10M\u00d7768 1-bit index, k=100"
@@ -420,33 +477,43 @@ def main():
                        "queries_per_step": Q, "queries_per_launch": min(args.sub_batch, Q), "sweeps_per_query": 1,
                        "pipeline_slots": args.slots, "replay_threads": args.replay_threads, "bytes_per_row": bytes_per_row,
                        "parallelism": "row-shard x%d" % world},
+            # frac / frac_hipevent: this run, HIP events on the kernel's own stream; frac_rocprof_avg: the committed kernel-trace
+            # average of the same kernel on the same layout (a different box and run: the pool has faster and slower boxes)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "bbq_scan_kernel (largest segment launch)",
+                         "frac_hipevent": achieved / HBM_PEAK_GBS, "frac_rocprof_avg": frac_rocprof, "rocprof_source": rocprof_src,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "bbq_scan_kernel (largest segment launch)",
                          "bytes_per_launch": launch_bytes, "avg_launch_ms": launch_ms, "launches_timed": st["total_scan_launches"]},
             "ranks": dist.get_world_size() if dist is not None else 1, "backend": (dist.get_backend() if dist is not None else None),
             "end_to_end_hbm_frac": (qps * (N / world) * bytes_per_row / 1e9) / HBM_PEAK_GBS,
             "candidates_per_query": st["candidates"] / float(Q) if dist is None else None,
             "dense_fallbacks": st["dense_fallbacks"],
         }
+        if latency is not None:
+            out["latency"] = latency
         if batched is not None:
             out["batched"] = batched
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed at N=1 only
-            us_row, done, rows, secs = cpu_baseline(dim, k, codes, corr, qq_all, qc_all, cdp, QB, SIM, IB)
-            out["cpu_baseline"] = {"value": 1e6 / (us_row * N), "unit": "queries/s", "cores": 1, "kind": "port",
-                                   "sample": "%d queries x %d rows of the same synthetic index in %.1fs (%.3f us/row), linearly extrapolated to %d rows"
-                                             % (done, rows, secs, us_row, N)}
+            cqps, done, rows, secs = cpu_baseline(dim, k, codes, corr, qq_all, qc_all, cdp, QB, SIM, IB)
+            model, ncpu = host_cpu()
+            out["cpu_baseline"] = {"value": cqps, "unit": "queries/s", "cores": 1, "kind": "port",
+                                   "sample": "%d of the timed queries x all %d rows of the same index in %.1fs (%.3f us/row), one thread; nothing extrapolated"
+                                             % (done, rows, secs, secs / (done * rows) * 1e6),
+                                   "host_cpu": model, "host_logical_cores": ncpu}
             # the same loops restated in JS, under node on this box's host, 1 core
             import shutil
             import subprocess
             if shutil.which("node") and IB == 1:
                 try:
-                    r = subprocess.run(["node", os.path.join(ROOT, "oracle", "bbq_oracle_js_baseline.js"), "300000", str(dim), str(k), "3"],
-                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
+                    js_rows = min(N, 1_000_000)   # the reference's per-row object layout cannot hold 10 M rows in Node
+                    r = subprocess.run(["node", os.path.join(ROOT, "oracle", "bbq_oracle_js_baseline.js"), str(js_rows), str(dim), str(k), "3"],
+                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=180)
                     js = json.loads(r.stdout.strip().splitlines()[-1])
                     out["cpu_baseline_js"] = {"value": 1e6 / (js["us_per_row"] * N), "unit": "queries/s", "cores": 1,
                                               "kind": "port (JavaScript restatement of the reference loops, node %s)" % js["node"],
-                                              "sample": "%d queries x %d rows in %.1fs (%.3f us/row), linearly extrapolated to %d rows"
-                                                        % (js["queries"], js["rows"], js["seconds"], js["us_per_row"], N)}
+                                              "sample": "%d queries x %d rows in %.1fs (%.3f us/row)%s"
+                                                        % (js["queries"], js["rows"], js["seconds"], js["us_per_row"],
+                                                           "" if js["rows"] == N else ", per-row cost scaled to %d rows (Node cannot hold the reference's per-row objects for that many)" % N),
+                                              "host_cpu": model, "host_logical_cores": ncpu}
                 except Exception as e:  # the baseline is informational: never fail the bench for it
                     out["cpu_baseline_js"] = {"error": str(e)[:200]}
         if not args.no_parity:
@@ -464,7 +531,8 @@ def main():
             out["parity_note"] = ("the reference throws for queryBits=%d on an indexBits=%d index (src/binaryQuantizedScorer.ts:95-97): the integer dot "
                                   "product is pinned by fixtures of computeQuantizedDotProduct, the float score is its per-row 4-bit form - parity unpinned" % (QB, IB))
         if not args.no_recall and IB == 1:
-            rec, desc = recall_probe(B, device, n=args.recall_rows)
+            ix.close()   # the probe needs the memory (30.7 GB of fp32 at the headline size, twice on the device while the index is built)
+            rec, desc = recall_probe(B, device, n=args.recall_rows if args.recall_rows > 0 else min(N, 10_000_000), dim=dim)
             out["recall_at_100"] = rec
             out["recall_config"] = desc
         print(json.dumps(out), flush=True)

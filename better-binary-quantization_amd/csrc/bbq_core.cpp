@@ -217,7 +217,7 @@ void add_storage_segments(const bbq_index *ix, Plan &p, int storage, const Stora
     // segments); the next boundary multiplies that count by `growth`, so every segment emits ~k*(growth-1) candidates
     const int64_t before = rows_before + b;
     int64_t e = R;
-    const int64_t nb = (before * ix->opt_growth - rows_before) / kChunkRows * kChunkRows;
+    const int64_t nb = (before * p.growth - rows_before) / kChunkRows * kChunkRows;
     if (before > 0 && nb > b && nb <= R / 2) e = nb;
     const int cap = cap_for(p.k, before);
     const int64_t rows = e - b;
@@ -228,12 +228,14 @@ void add_storage_segments(const bbq_index *ix, Plan &p, int storage, const Stora
 }
 
 // k: the rank the device selects thresholds with; final_k > 0: k == final_k + 1 and the last finalize launch selects the answer
-void build_plan(bbq_index *ix, int64_t k, int64_t final_k = 0) {
+void build_plan(bbq_index *ix, int64_t k, int64_t final_k = 0, int growth = 0) {
   Plan &p = ix->plan;
-  if (p.k == k && p.final_k == final_k) return;
+  if (growth <= 0) growth = ix->opt_growth;
+  if (p.k == k && p.final_k == final_k && p.growth == growth) return;
   p = Plan();
   p.k = k;
   p.final_k = final_k;
+  p.growth = growth;
   p.s0 = std::max<int64_t>(ix->opt_s0, (4 * k + kChunkRows - 1) / kChunkRows * kChunkRows);
   p.s0 = std::min<int64_t>(p.s0, 8192);
   double expected_emit = 0, dummy = 0;
@@ -273,9 +275,9 @@ void build_plan(bbq_index *ix, int64_t k, int64_t final_k = 0) {
 // ------------------------------------------------------------------------------------------------ slots
 
 void free_slot_buffers(Slot &s) {
-  if (s.d_qbuf) (void)hipFree(s.d_qbuf);
-  if (s.h_qbuf) (void)hipHostFree(s.h_qbuf);
-  if (s.d_theta) (void)hipFree(s.d_theta);
+  if (s.d_block) (void)hipFree(s.d_block);
+  if (s.h_block) (void)hipHostFree(s.h_block);
+  s.d_block = s.h_block = nullptr;
   if (s.d_counts) (void)hipFree(s.d_counts);
   if (s.d_topk) (void)hipFree(s.d_topk);
   if (s.h_list_counts) (void)hipHostFree(s.h_list_counts);
@@ -286,10 +288,7 @@ void free_slot_buffers(Slot &s) {
   if (s.d_ovf) (void)hipFree(s.d_ovf);
   if (s.d_final) (void)hipFree(s.d_final);
   if (s.h_final) (void)hipHostFree(s.h_final);
-  if (s.d_final_info) (void)hipFree(s.d_final_info);
-  if (s.h_final_info) (void)hipHostFree(s.h_final_info);
   s.d_final = s.h_final = nullptr;
-  s.d_final_info = s.h_final_info = nullptr;
   s.final_stride = 0;
   s.d_ovf = nullptr;
   s.d_ovf_counts = nullptr;
@@ -309,7 +308,7 @@ int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
   const int64_t hprefix = std::min<int64_t>(p.list_cap, 16384);
   const bool ok = s.q_cap >= nq && s.qbuf_bytes >= qb && s.chunks_cap >= p.max_chunks && s.slots_cap >= p.max_slots &&
                   s.dense_cap >= p.s0 && s.list_cap >= p.list_cap + (own_lists ? p.flood_cap : 0) && s.k_cap >= p.k && s.hprefix >= hprefix &&
-                  s.flood_cap >= p.flood_cap && s.final_stride >= p.final_k &&
+                  s.flood_cap >= p.flood_cap && s.final_stride >= p.final_k + 2 &&
                   (!own_lists || s.d_lists != nullptr);
   if (ok) return BBQ_OK;
   free_slot_buffers(s);
@@ -322,10 +321,15 @@ int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
   s.flood_cap = p.flood_cap;
   s.k_cap = std::max<int64_t>(p.k, 1);
   s.hprefix = hprefix;
-  HIPCHK(hipMalloc((void **)&s.d_qbuf, (size_t)(Q * qb)));
-  HIPCHK(hipHostMalloc((void **)&s.h_qbuf, (size_t)(Q * qb), hipHostMallocDefault));
-  // theta | flags | topk_counts | list_counts | ovf_counts live in one control block so that one memset resets a sub-batch
-  HIPCHK(hipMalloc((void **)&s.d_theta, (size_t)Q * 24));
+  // theta | flags | topk_counts | list_counts | ovf_counts live in one control block in front of the staged queries: the copy that
+  // brings a sub-batch's queries also resets them (the host twin's control part stays zero)
+  s.ctrl_bytes = ((int64_t)Q * 24 + 255) / 256 * 256;
+  HIPCHK(hipMalloc((void **)&s.d_block, (size_t)(s.ctrl_bytes + Q * qb)));
+  HIPCHK(hipHostMalloc((void **)&s.h_block, (size_t)(s.ctrl_bytes + Q * qb), hipHostMallocDefault));
+  memset(s.h_block, 0, (size_t)s.ctrl_bytes);
+  s.d_qbuf = s.d_block + s.ctrl_bytes;
+  s.h_qbuf = s.h_block + s.ctrl_bytes;
+  s.d_theta = reinterpret_cast<uint32_t *>(s.d_block);
   s.d_flags = s.d_theta + Q;
   s.d_topk_counts = reinterpret_cast<int32_t *>(s.d_theta + 2 * (size_t)Q);
   s.d_list_counts = reinterpret_cast<int32_t *>(s.d_theta + 3 * (size_t)Q);
@@ -340,11 +344,9 @@ int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
     HIPCHK(hipMalloc((void **)&s.d_lists, (size_t)(Q * s.list_cap) * 8));
     HIPCHK(hipHostMalloc((void **)&s.h_lists, (size_t)(Q * s.hprefix) * 8, hipHostMallocDefault));
   }
-  s.final_stride = std::max<int64_t>(p.final_k, 128);
+  s.final_stride = std::max<int64_t>(p.final_k, 126) + 2;
   HIPCHK(hipMalloc((void **)&s.d_final, (size_t)(Q * s.final_stride) * 8));
   HIPCHK(hipHostMalloc((void **)&s.h_final, (size_t)(Q * s.final_stride) * 8, hipHostMallocDefault));
-  HIPCHK(hipMalloc((void **)&s.d_final_info, (size_t)Q * 8));
-  HIPCHK(hipHostMalloc((void **)&s.h_final_info, (size_t)Q * 8, hipHostMallocDefault));
   s.q_cap = Q;
   return BBQ_OK;
 }
@@ -517,11 +519,10 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
     }
   }
   hipStream_t st = s.stream;
-  HIPCHK(hipMemcpyAsync(s.d_qbuf, s.h_qbuf, bytes, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(s.d_block, s.h_block, (size_t)s.ctrl_bytes + bytes, hipMemcpyHostToDevice, st));  // control words := 0, queries
   uint64_t *d_lists = d_lists_ext ? d_lists_ext : s.d_lists;
   const int64_t list_cap = d_lists_ext ? list_cap_ext : s.list_cap;
   int32_t *d_list_counts = d_counts_ext ? d_counts_ext : s.d_list_counts;
-  HIPCHK(hipMemsetAsync(s.d_theta, 0, (size_t)s.q_cap * 24, st));
   if (d_counts_ext) HIPCHK(hipMemsetAsync(d_counts_ext, 0, (size_t)nq * 8, st));
 
   const bool use_final = !d_lists_ext && p.final_k > 0 && !p.segs.empty();
@@ -592,7 +593,6 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
     f.need_theta = g.need_theta ? 1 : 0;
     if (use_final && &g == &p.segs.back()) {
       f.final_out = s.d_final;
-      f.final_info = s.d_final_info;
       f.final_stride = (int32_t)s.final_stride;
       f.final_k = (int32_t)p.final_k;
     }
@@ -600,14 +600,16 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
   }
   s.final_used = use_final;
   if (!d_lists_ext) {
-    HIPCHK(hipMemcpyAsync(s.h_list_counts, s.d_list_counts, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
     if (use_final) {
-      // the answer itself (k entries per query) instead of the candidate list: the list is fetched only for a query whose
-      // answer the device could not prove (ties), see begin_replay
-      HIPCHK(hipMemcpyAsync(s.h_final_info, s.d_final_info, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipMemcpy2DAsync(s.h_final, (size_t)s.final_stride * 8, s.d_final, (size_t)s.final_stride * 8, (size_t)p.final_k * 8, (size_t)nq,
-                              hipMemcpyDeviceToHost, st));
+      // the answer itself (header + k entries per query, one copy) instead of the candidate list: the list is fetched only for a
+      // query whose answer the device could not prove (ties), see begin_replay
+      if (nq == 1 || p.final_k + 2 == s.final_stride)
+        HIPCHK(hipMemcpyAsync(s.h_final, s.d_final, ((size_t)(nq - 1) * s.final_stride + (size_t)p.final_k + 2) * 8, hipMemcpyDeviceToHost, st));
+      else
+        HIPCHK(hipMemcpy2DAsync(s.h_final, (size_t)s.final_stride * 8, s.d_final, (size_t)s.final_stride * 8, (size_t)(p.final_k + 2) * 8, (size_t)nq,
+                                hipMemcpyDeviceToHost, st));
     } else {
+      HIPCHK(hipMemcpyAsync(s.h_list_counts, s.d_list_counts, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
       HIPCHK(hipMemcpy2DAsync(s.h_lists, (size_t)s.hprefix * 8, s.d_lists, (size_t)s.list_cap * 8, (size_t)s.hprefix * 8, (size_t)nq,
                               hipMemcpyDeviceToHost, st));
     }
@@ -693,6 +695,14 @@ int begin_replay(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score,
   s.dense_q.clear();
   s.tails.assign((size_t)nq, std::vector<uint64_t>());
   const bool fin = s.final_used;
+  if (fin)  // the header slots of the answer block carry what the two small copies used to bring
+    for (int i = 0; i < nq; ++i) {
+      const uint64_t *hdr = s.h_final + (size_t)i * s.final_stride;
+      s.h_list_counts[2 * i] = (int32_t)(uint32_t)hdr[0];
+      s.h_list_counts[2 * i + 1] = (int32_t)(uint32_t)(hdr[0] >> 32);
+    }
+  auto final_cnt = [&s](int i) { return (int32_t)(uint32_t)s.h_final[(size_t)i * s.final_stride + 1]; };
+  auto final_replay = [&s](int i) { return (uint32_t)(s.h_final[(size_t)i * s.final_stride + 1] >> 32) != 0; };
   const int64_t covered = fin ? 0 : s.hprefix;  // list entries the enqueue-time copy brought over
   int n_replay = 0;
   struct CountReplays {  // on every exit path
@@ -702,7 +712,7 @@ int begin_replay(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score,
   for (int i = 0; i < nq; ++i) {
     const int32_t cnt = s.h_list_counts[2 * i], flags = s.h_list_counts[2 * i + 1];
     if (flags != 0) { s.dense_q.push_back(i); continue; }
-    if (fin && s.h_final_info[2 * i + 1] == 0) continue;  // answered on the device
+    if (fin && !final_replay(i)) continue;  // answered on the device
     ++n_replay;
     if (cnt > covered) {  // rare: fetch what the enqueue-time copy did not cover (everything, when the device was to answer)
       s.tails[(size_t)i].resize((size_t)(cnt - covered));
@@ -714,10 +724,10 @@ int begin_replay(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score,
   Slot *sp = &s;
   if (fin) {  // queries the last finalize launch answered: the sorted rows are the result
     for (int i = 0; i < nq; ++i) {
-      if (s.h_list_counts[2 * i + 1] != 0 || s.h_final_info[2 * i + 1] != 0) continue;
+      if (s.h_list_counts[2 * i + 1] != 0 || final_replay(i)) continue;
       const int64_t qi = s.q_first + i;
-      const int32_t m = s.h_final_info[2 * i];
-      const uint64_t *fo = s.h_final + (size_t)i * s.final_stride;
+      const int32_t m = final_cnt(i);
+      const uint64_t *fo = s.h_final + (size_t)i * s.final_stride + 2;
       for (int32_t j = 0; j < m; ++j) {
         const uint32_t bits = (uint32_t)fo[j];
         out_idx[qi * k + j] = (int32_t)(uint32_t)(fo[j] >> 32);
@@ -731,7 +741,7 @@ int begin_replay(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score,
     for (int i = lo; i < hi; ++i) {
       const int32_t cnt = s.h_list_counts[2 * i], flags = s.h_list_counts[2 * i + 1];
       if (flags != 0) continue;
-      if (fin && s.h_final_info[2 * i + 1] == 0) continue;
+      if (fin && (uint32_t)(s.h_final[(size_t)i * s.final_stride + 1] >> 32) == 0) continue;
       HeapReplay hr(k, n_total);
       const uint64_t *l = s.h_lists + (size_t)i * s.hprefix;
       const int64_t head = std::min<int64_t>(cnt, covered);
@@ -1005,7 +1015,7 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
   // (FinalizeArgs::final_out); the host replays the heap only for queries with equal scores in or at the edge of their answer
   const int64_t final_k = (keff <= kFinalSelectMax && ix->opt_device_select) ? keff : 0;
   cs.k = final_k > 0 ? keff + 1 : keff;
-  build_plan(ix, cs.k, final_k);
+  build_plan(ix, cs.k, final_k, (final_k > 0 && n_queries <= ix->opt_latency_queries) ? ix->opt_latency_growth : 0);
   const int Q = std::max(1, ix->opt_batch);
   const int nslots = std::min(std::max(1, ix->opt_slots), kMaxSlots);
   const int64_t nsub = ((int64_t)n_queries + Q - 1) / Q;
@@ -1204,6 +1214,8 @@ int bbq_set_option(bbq_index *ix, const char *name, int64_t v) {
   else if (n == "replay_threads" && v >= 1 && v <= 256) ix->opt_replay_threads = (int)v;
   else if (n == "force_dense" && (v == 0 || v == 1)) ix->opt_force_dense = (int)v;
   else if (n == "device_select" && (v == 0 || v == 1)) ix->opt_device_select = (int)v;
+  else if (n == "latency_queries" && v >= 0 && v <= 1024) ix->opt_latency_queries = (int)v;
+  else if (n == "latency_growth" && v >= 2 && v <= 4096) ix->opt_latency_growth = (int)v;
   else if (n == "sweep_share" && (v == 1 || v == 4 || v == 8 || v == 32)) ix->opt_share = (int)v;
   else if (n == "flood_rows" && v >= 0 && v <= (1 << 24)) ix->opt_flood = (v + 1023) / 1024 * 1024;
   else return fail(BBQ_ERR_INVALID_ARG, "bbq_set_option: unknown option or value out of range: %s=%lld", name, (long long)v);

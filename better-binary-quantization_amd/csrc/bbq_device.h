@@ -129,12 +129,14 @@ struct FinalizeArgs {
   // hold the (k2 + 1) largest keys seen: the launch then knows the (k2 + 1)-th largest f32 score of the whole index exactly,
   // gathers the k2 rows above it from the list, sorts them by score and checks that no two of them - and not the boundary -
   // compare equal.  In that case the reference's heap (src/binaryQuantizationFormat.ts:383-411) ends up holding exactly those rows
-  // whatever its history was and pops them in ascending score order, so the answer is the descending sort: final_info = {k2, 0}.
-  // Any tie, NaN flag, list overflow, a flood beyond the key buffer or k2 > kFinalSelectMax leaves final_info = {0, 1}: the host
+  // whatever its history was and pops them in ascending score order, so the answer is the descending sort (header slot 1 = {k2, 0}).
+  // Any tie, NaN flag, list overflow, a flood beyond the key buffer or k2 > kFinalSelectMax leaves {0, 1} there: the host
   // replays the heap over the list as before.
-  uint64_t *final_out;         // [Q][final_stride] (global row << 32 | f32 score bits), descending by score
-  int32_t *final_info;         // [Q][2] {entries in final_out, 1 = replay the list on the host}
-  int32_t final_stride;
+  // final_out [Q][final_stride]: slot 0 = {list count, flags} (a copy of list_counts), slot 1 = {entries that follow, 1 = replay
+  // the list on the host}, then the answer (global row << 32 | f32 score bits) descending by score: ONE device-to-host copy
+  // brings everything the host needs
+  uint64_t *final_out;
+  int32_t final_stride;        // >= final_k + 2
   int32_t final_k;             // k2 = min(k, rows of the index)
 };
 constexpr int kFinalSelectMax = 1024;  // largest k2 the finalize kernel selects and sorts itself

@@ -63,6 +63,7 @@ struct Plan {
   int64_t max_slots = 0;  // max over sparse segments of n_chunks*cap
   int64_t max_chunks = 0;
   int64_t final_k = 0;    // > 0: the plan runs with k = final_k + 1 and the last finalize launch selects the answer itself
+  int growth = 0;         // segment growth the plan was built with
 };
 
 struct Slot {
@@ -71,6 +72,10 @@ struct Slot {
   // capacities the buffers below were allocated for
   int q_cap = 0;
   int64_t qbuf_bytes = 0, chunks_cap = 0, slots_cap = 0, dense_cap = 0, list_cap = 0, k_cap = 0, hprefix = 0, flood_cap = 0;
+  // one device block [control words of the sub-batch | staged queries] and its pinned host twin whose control part stays zero: ONE
+  // host-to-device copy resets the thresholds / counters and brings the queries (d_theta.. and d_qbuf point into it)
+  uint8_t *d_block = nullptr, *h_block = nullptr;
+  int64_t ctrl_bytes = 0;
   uint8_t *d_qbuf = nullptr, *h_qbuf = nullptr;
   uint32_t *d_theta = nullptr, *d_flags = nullptr, *d_counts = nullptr, *d_topk = nullptr;
   int32_t *d_topk_counts = nullptr, *d_list_counts = nullptr, *h_list_counts = nullptr;
@@ -78,8 +83,7 @@ struct Slot {
   uint32_t *d_ovf_counts = nullptr;
   float *d_dense0 = nullptr;
   // final selection on the device (FinalizeArgs::final_out): the sorted answer + {count, needs-host-replay} per query
-  uint64_t *d_final = nullptr, *h_final = nullptr;
-  int32_t *d_final_info = nullptr, *h_final_info = nullptr;
+  uint64_t *d_final = nullptr, *h_final = nullptr;  // [q_cap][final_stride]: 2 header slots + the answer per query
   int64_t final_stride = 0;
   bool final_used = false;  // the in-flight sub-batch was enqueued with the final selection (its list prefix was NOT copied to the host)
   // in-flight sub-batch: busy = device work enqueued and not yet collected; replaying = host replay jobs outstanding
@@ -148,6 +152,9 @@ struct bbq_index {
   int64_t shard_q_cap = 0, shard_list_cap = 0;
   // options
   int opt_batch = 32, opt_slots = 2, opt_growth = 8, opt_force_dense = 0, opt_share = 1, opt_device_select = 1;
+  // a call with few queries is latency-bound: every segment costs a dependent scan + finalize launch pair (~15-20 us), so such calls
+  // walk the index in fewer, faster-growing segments (more candidates per query - the device selects the answer itself anyway)
+  int opt_latency_queries = 4, opt_latency_growth = 64;
   // host threads replaying the heaps of one sub-batch: half the cores, at most 8 (a batch of 32 answers 1.4x sooner than with 1)
   int opt_replay_threads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
   int64_t opt_s0 = 4096;

@@ -497,14 +497,48 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
 // k-th largest of the M keys in LDS (M >= k >= 1): 4-pass radix select, one 1024-thread workgroup; every thread returns it
 __device__ __forceinline__ uint32_t block_select_kth_largest(const uint32_t *s_keys, uint32_t M, uint32_t k, uint32_t *s_hist, uint32_t *s_misc) {
   const int tid = threadIdx.x;
+  // Scores of one query live in a narrow range: the upper bytes of their keys are the same for (nearly) all of them, and a
+  // histogram pass over such a byte is thousands of atomic adds on ONE LDS word (measured: 10 us per pass at 6 K keys).
+  // Bytes that are constant over all keys are therefore skipped: they belong to the answer as they are.
+  uint32_t vary = 0;
+  {
+    const uint32_t key0 = s_keys[0];
+    for (uint32_t i = tid; i < M; i += kFinalizeThreads) vary |= s_keys[i] ^ key0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) vary |= __shfl_xor(vary, d, 64);
+    if (tid == 0) s_misc[0] = 0;
+    __syncthreads();
+    if ((tid & 63) == 0 && vary) atomicOr(&s_misc[0], vary);
+    __syncthreads();
+    vary = s_misc[0];
+    __syncthreads();
+  }
   uint32_t prefix = 0, mask = 0, kk = k;
   for (int pass = 3; pass >= 0; --pass) {
+    const int sh = pass * 8;
+    if (((vary >> sh) & 255u) == 0u) {  // uniform: every key has the same byte here
+      prefix |= s_keys[0] & (255u << sh);
+      mask |= 255u << sh;
+      continue;
+    }
     if (tid < 256) s_hist[tid] = 0;
     __syncthreads();
-    const int sh = pass * 8;
-    for (uint32_t i = tid; i < M; i += kFinalizeThreads) {
-      const uint32_t key = s_keys[i];
-      if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> sh) & 255u], 1u);
+    for (uint32_t i0 = 0; i0 < M; i0 += kFinalizeThreads) {  // whole waves iterate together (ballots below)
+      const uint32_t i = i0 + tid;
+      const bool in = i < M && (s_keys[i < M ? i : 0] & mask) == prefix;
+      const uint32_t bin = in ? (s_keys[i] >> sh) & 255u : 256u;
+      // a byte with few distinct values would still pile the adds on a few words: the lanes that share the first active lane's
+      // bin add once for all of them
+      const unsigned long long act = __ballot(in);
+      if (act) {
+        const uint32_t b0 = __shfl(bin, __ffsll((long long)act) - 1, 64);
+        const unsigned long long same = __ballot(in && bin == b0);
+        if (in && bin == b0) {
+          if ((tid & 63) == __ffsll((long long)same) - 1) atomicAdd(&s_hist[b0], (uint32_t)__popcll(same));
+        } else if (in) {
+          atomicAdd(&s_hist[bin], 1u);
+        }
+      }
     }
     __syncthreads();
     if (tid < 64) {
@@ -537,11 +571,11 @@ __device__ __forceinline__ uint32_t block_select_kth_largest(const uint32_t *s_k
 }
 
 __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const FinalizeArgs a) {
-  __shared__ uint32_t s_keys[kFinalizeKeyCap];
+  __shared__ __attribute__((aligned(16))) uint32_t s_keys[kFinalizeKeyCap];
   __shared__ uint32_t s_hist[256];
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_misc[4];
-  __shared__ uint32_t s_jobs[3 * kFinalizeFloodJobs];  // flood blocks of this launch: {source offset, list offset, entries}
+  __shared__ __attribute__((aligned(16))) uint32_t s_jobs[3 * kFinalizeFloodJobs];  // flood blocks of this launch: {source offset, list offset, entries}
   const int q = blockIdx.x;
   const int tid = threadIdx.x;
   uint32_t flags = 0;
@@ -648,88 +682,85 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
     const int k2 = a.final_k;
     const int64_t total = base + m_new;  // entries of the complete list
     const uint32_t tcount = (uint32_t)a.topk_counts[q];
-    bool ok = f_all == 0 && a.emit && total <= a.list_cap && k2 >= 1 && k2 <= kFinalSelectMax && k2 <= a.final_stride &&
+    bool ok = f_all == 0 && a.emit && total <= a.list_cap && k2 >= 1 && k2 <= kFinalSelectMax && k2 + 2 <= a.final_stride &&
               m_new <= (uint32_t)kFinalizeKeyCap - tcount;
     uint64_t *__restrict__ s_sel = reinterpret_cast<uint64_t *>(s_jobs);  // 1536 slots; the flood jobs are done with
-    uint32_t n_sel = 0;
-    if (ok) {
-      uint32_t th1 = 0;        // rows with key > th1 are the answer
-      bool take_all = total <= (int64_t)k2;
-      if (!take_all) {
-        // the (k2 + 1)-th largest key of the whole index = the (k2 + 1)-th largest of {running top keys (the k2 + 1 largest of the
-        // earlier segments, a.k == k2 + 1) U this segment's keys}; s_keys[0, m_new) still holds the latter
-        const uint32_t *__restrict__ tk = a.topk_keys + (size_t)q * a.k;
-        for (uint32_t i = tid; i < tcount; i += kFinalizeThreads) s_keys[m_new + i] = tk[i];
-        const uint32_t M = m_new + tcount;
+    auto bits_of = [](uint32_t key) -> uint32_t { return (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key; };
+    uint32_t n_sel = 0, th1 = 0;  // rows with key > th1 are the answer
+    const bool take_all = total <= (int64_t)k2;
+    if (ok && !take_all) {
+      // the (k2 + 1)-th largest key of the whole index = the (k2 + 1)-th largest of {running top keys (the k2 + 1 largest of the
+      // earlier segments, a.k == k2 + 1) U this segment's keys}; s_keys[0, m_new) still holds the latter
+      const uint32_t *__restrict__ tk = a.topk_keys + (size_t)q * a.k;
+      for (uint32_t i = tid; i < tcount; i += kFinalizeThreads) s_keys[m_new + i] = tk[i];
+      const uint32_t M = m_new + tcount;
+      const uint32_t M4 = (M + 3u) & ~3u;
+      if (tid < (int)(M4 - M)) s_keys[M + tid] = 0u;  // key 0 is below every key of a finite score
+      __syncthreads();
+      if (a.k != k2 + 1 || M < (uint32_t)(k2 + 1)) {
+        ok = false;  // uniform
+      } else if (M <= 2048u) {
+        // few keys: the wanted key X is the one with  #(keys > X) <= k2 < #(keys >= X)  - counted per key, two barriers in all
+        if (tid == 0) s_misc[0] = 0;
         __syncthreads();
-        if (a.k != k2 + 1 || M < (uint32_t)(k2 + 1)) {
-          ok = false;  // uniform
-        } else {
-          th1 = block_select_kth_largest(s_keys, M, (uint32_t)(k2 + 1), s_hist, s_misc);
-        }
-      }
-      if (ok) {
-        if (tid == 0) s_misc[2] = 0;
-        __syncthreads();
-        for (int64_t i = tid; i < total; i += kFinalizeThreads) {
-          const uint64_t ent = list[i];
-          const uint32_t key = key_of_bits((uint32_t)ent);
-          if (take_all || key > th1) {
-            const uint32_t slot = atomicAdd(&s_misc[2], 1u);
-            if (slot < (uint32_t)kFinalSelectMax) s_sel[slot] = ((uint64_t)key << 32) | (ent >> 32);
+        const u32x4 *__restrict__ k4 = reinterpret_cast<const u32x4 *>(s_keys);
+        for (uint32_t i = tid; i < M; i += kFinalizeThreads) {
+          const uint32_t key = s_keys[i];
+          uint32_t gt = 0, ge = 0;
+          for (uint32_t j = 0; j < M4 / 4; ++j) {
+            const u32x4 v = k4[j];
+            gt += (v.x > key) + (v.y > key) + (v.z > key) + (v.w > key);
+            ge += (v.x >= key) + (v.y >= key) + (v.z >= key) + (v.w >= key);
           }
+          if (gt <= (uint32_t)k2 && (uint32_t)k2 < ge) s_misc[0] = key;  // every writer writes the same value
         }
         __syncthreads();
-        n_sel = s_misc[2];
-        // exactly k2 rows above the boundary (fewer: the boundary value repeats; a list shorter than k2 + 1 rows holds them all)
-        ok = take_all ? (n_sel == (uint32_t)total) : (n_sel == (uint32_t)k2);
-      }
-      if (ok) {
-        // bitonic sort, descending, of n_sel (<= 1024) items padded with zeros (key 0 is below every real key)
-        uint32_t n_pad = 1;
-        while (n_pad < n_sel) n_pad <<= 1;
-        for (uint32_t i = n_sel + tid; i < n_pad; i += kFinalizeThreads) s_sel[i] = 0;
-        __syncthreads();
-        for (uint32_t size = 2; size <= n_pad; size <<= 1) {
-          for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            const uint32_t i = tid;
-            if (i < n_pad) {
-              const uint32_t j = i ^ stride;
-              if (j > i) {
-                const uint64_t x = s_sel[i], y = s_sel[j];
-                const bool desc = (i & size) == 0;
-                if (desc ? (x < y) : (x > y)) { s_sel[i] = y; s_sel[j] = x; }
-              }
-            }
-            __syncthreads();
-          }
-        }
-        // equal scores (as floats: +0 == -0) anywhere in the answer or at its boundary: the heap's history decides - host replay
-        if (tid == 0) s_misc[3] = 0;
-        __syncthreads();
-        auto bits_of = [](uint32_t key) -> uint32_t { return (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key; };
-        if ((uint32_t)tid + 1 < n_sel) {
-          const float x = __uint_as_float(bits_of((uint32_t)(s_sel[tid] >> 32))), y = __uint_as_float(bits_of((uint32_t)(s_sel[tid + 1] >> 32)));
-          if (x == y) s_misc[3] = 1;
-        }
-        if (tid == 0 && !take_all && n_sel > 0) {
-          const float x = __uint_as_float(bits_of((uint32_t)(s_sel[n_sel - 1] >> 32))), y = __uint_as_float(bits_of(th1));
-          if (x == y) s_misc[3] = 1;
-        }
-        __syncthreads();
-        ok = s_misc[3] == 0;
-        if (ok) {
-          uint64_t *__restrict__ fo = a.final_out + (size_t)q * a.final_stride;
-          if ((uint32_t)tid < n_sel) {
-            const uint64_t it = s_sel[tid];
-            fo[tid] = ((uint64_t)(uint32_t)it << 32) | bits_of((uint32_t)(it >> 32));
-          }
-        }
+        th1 = s_misc[0];
+      } else {
+        th1 = block_select_kth_largest(s_keys, M, (uint32_t)(k2 + 1), s_hist, s_misc);
       }
     }
+    if (ok) {
+      if (tid == 0) { s_misc[2] = 0; s_misc[3] = 0; }
+      __syncthreads();
+      for (int64_t i = tid; i < total; i += kFinalizeThreads) {
+        const uint64_t ent = list[i];
+        const uint32_t key = key_of_bits((uint32_t)ent);
+        if (take_all || key > th1) {
+          const uint32_t slot = atomicAdd(&s_misc[2], 1u);
+          if (slot < (uint32_t)kFinalSelectMax) s_sel[slot] = ((uint64_t)key << 32) | (ent >> 32);
+        }
+      }
+      __syncthreads();
+      n_sel = s_misc[2];
+      // exactly k2 rows above the boundary (fewer: the boundary value repeats; a list shorter than k2 + 1 rows holds them all)
+      ok = take_all ? (n_sel == (uint32_t)total) : (n_sel == (uint32_t)k2);
+    }
+    if (ok) {
+      // sort by counting (no barriers): the place of a row = the number of rows above it.  Equal scores (as floats: +0 == -0)
+      // anywhere in the answer or at its boundary mean that the heap's history decides: flagged, the host replays
+      uint64_t *__restrict__ fo = a.final_out + (size_t)q * a.final_stride + 2;
+      const float fth = __uint_as_float(bits_of(th1));
+      for (uint32_t i = tid; i < n_sel; i += kFinalizeThreads) {
+        const uint64_t x = s_sel[i];
+        const float fx = __uint_as_float(bits_of((uint32_t)(x >> 32)));
+        uint32_t rank = 0, same = 0;
+        for (uint32_t j = 0; j < n_sel; ++j) {
+          const uint64_t y = s_sel[j];
+          rank += y > x ? 1u : 0u;
+          same += __uint_as_float(bits_of((uint32_t)(y >> 32))) == fx ? 1u : 0u;
+        }
+        if (same > 1u || (!take_all && fx == fth)) s_misc[3] = 1;
+        fo[rank] = ((uint64_t)(uint32_t)x << 32) | bits_of((uint32_t)(x >> 32));
+      }
+      __syncthreads();
+      ok = s_misc[3] == 0;
+    }
     if (tid == 0) {
-      a.final_info[2 * q] = ok ? (int32_t)n_sel : 0;
-      a.final_info[2 * q + 1] = ok ? 0 : 1;
+      uint64_t *__restrict__ hdr = a.final_out + (size_t)q * a.final_stride;
+      const uint32_t listed = a.emit ? (uint32_t)min((int64_t)(base + m_new), a.list_cap) : 0u;
+      hdr[0] = (uint64_t)listed | ((uint64_t)f_all << 32);
+      hdr[1] = (uint64_t)(ok ? n_sel : 0u) | ((uint64_t)(ok ? 0u : 1u) << 32);
     }
   }
 }

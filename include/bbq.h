@@ -304,7 +304,9 @@ int bbq_reset_stats(bbq_index *idx);
  *   replay_threads 1..256 (half the host cores, at most 8)   flood_rows 0..2^24 (262144)   force_dense 0|1 (0)
  *   sweep_share 1|4|8|32 (1: every query sweeps the index itself; 32: shared sweep on the matrix cores)
  *   device_select 0|1 (1: for k <= 1024 the device selects and sorts the answer itself whenever no two scores in or at the edge of it
- *   compare equal - then the reference heap provably returns that order - and the host replays the heap only for the rest) */
+ *   compare equal - then the reference heap provably returns that order - and the host replays the heap only for the rest)
+ *   latency_queries 0..1024 (4), latency_growth 2..4096 (64): calls with at most latency_queries queries walk the index in
+ *   segments that grow by latency_growth instead of segment_growth (fewer dependent launches, more candidates per query) */
 int bbq_set_option(bbq_index *idx, const char *name, int64_t value);
 
 #ifdef __cplusplus

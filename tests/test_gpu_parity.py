@@ -1118,7 +1118,7 @@ def test_device_selected_answers_equal_host_replay(name):
                 np.testing.assert_array_equal(res[1][0][qi, :res[1][2][qi]], O.dec(tk["idx_i32"], "<i4"))
             nan_case = np.isnan(res[0][1]).any()
             assert replays[0] + ix.stats()["dense_fallbacks"] >= len(queries) - (len(queries) if nan_case else 0)
-            if name.startswith(("ties_", "ib2_ties")) and k >= 7:
+            if name.startswith(("ties_cos", "ib2_ties")) and k >= 7:   # rows drawn from a pool of 40 vectors: equal scores everywhere
                 assert replays[1] > 0, "tie-stress fixture answered without a replay"
             if name.startswith("big_"):
                 assert replays[1] == 0, "tie-free data needed a host replay"
