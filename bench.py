@@ -488,6 +488,7 @@ def main():
             "candidates_per_query": st["candidates"] / float(Q) if dist is None else None,
             "dense_fallbacks": st["dense_fallbacks"],
         }
+        out["argv"] = " ".join(sys.argv[1:])
         if latency is not None:
             out["latency"] = latency
         if batched is not None:
