@@ -86,3 +86,31 @@ export declare function quickQuantize(vectors: Float32Array[], similarityFunctio
 export declare function quickSearch(queryVector: Float32Array, targetVectors: Float32Array[], k: number, similarityFunction?: VectorSimilarityFunction): Array<{ index: number; score: number }>;
 export declare const VERSION: string;
 export declare function deviceCount(): number;
+
+// helpers and constants the reference re-exports from its root (src/index.ts:20-37)
+export declare const NUMERICAL_CONSTANTS: { readonly CONVERGENCE_THRESHOLD: 1e-8; readonly MIN_DETERMINANT: 1e-12; readonly EPSILON: 1e-8 };
+export declare const FILE_EXTENSIONS: { readonly VECTOR_DATA: 'veb'; readonly META: 'vemb' };
+export declare const COMPONENT_NAMES: { readonly BINARIZED_VECTOR: 'BVEC' };
+export declare const MINIMUM_MSE_GRID: number[][];
+export declare const BIT_COUNT_LOOKUP_TABLE: Uint8Array;
+export declare function computeL2Norm(vector: Float32Array): number;
+export declare function computeMean(vector: Float32Array): number;
+export declare function computeStd(vector: Float32Array, mean: number): number;
+export declare function clamp(x: number, min: number, max: number): number;
+export declare function bitCount(n: number): number;
+export declare function bitCountBytes(bytes: Uint8Array): number;
+export declare function bitCountBytesOptimized(bytes: Uint8Array): number;
+export declare function getBitCount(byte: number): number;
+export declare function isNearZero(value: number, threshold?: number): boolean;
+export declare function isNearEqual(a: number, b: number, epsilon?: number): boolean;
+export declare function scaleMaxInnerProductScore(score: number): number;
+export declare function addVectors(a: Float32Array, b: Float32Array): Float32Array;
+export declare function subtractVectors(a: Float32Array, b: Float32Array): Float32Array;
+export declare function scaleVector(vector: Float32Array, scalar: number): Float32Array;
+export declare function centerVector(vector: Float32Array, centroid: Float32Array): Float32Array;
+export declare function copyVector(vector: Float32Array): Float32Array;
+export declare function computeVectorMagnitude(vector: Float32Array): number;
+export declare function createRandomVector(dimension: number, min?: number, max?: number): Float32Array;
+export declare function createZeroVector(dimension: number): Float32Array;
+/** out of scope (accuracy statistics): throws */
+export declare function computeAccuracy(originalVectors: Float32Array[], queryVectors: Float32Array[], similarityFunction?: VectorSimilarityFunction): never;

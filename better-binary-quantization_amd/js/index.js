@@ -693,7 +693,17 @@ function quickSearch(queryVector, targetVectors, k, similarityFunction) {
   }
 }
 
-module.exports = {
+/**
+ * computeAccuracy (src/index.ts:118-134) drives computeQuantizationAccuracy, the reference's accuracy-statistics report: outside the
+ * scan path this package replaces (SURVEY section 2 / DESIGN.md "Out of scope").  Exported so that the import resolves; calling it
+ * says so instead of failing with "not a function".
+ */
+function computeAccuracy() {
+  throw new Error('computeAccuracy is not part of the MI355X search-path build (accuracy statistics are out of scope): use getOversampledTopKWithHeap / a brute force for recall');
+}
+
+module.exports = Object.assign({}, require('./helpers'), {
+  computeAccuracy,
   VectorSimilarityFunction, DEFAULT_CONFIG, VERSION: '1.0.0',
   QUERY_BITS, INDEX_BITS, FOUR_BIT_SCALE, DEFAULT_LAMBDA, DEFAULT_ITERS,
   BinaryQuantizationFormat, OptimizedScalarQuantizer, BinaryQuantizedScorer, MinHeap,
@@ -704,4 +714,4 @@ module.exports = {
   computeSimilarity, computeQuantizedDotProduct, computeInt4BitDotProduct: computeQuantizedDotProduct, computeInt1BitDotProduct: computeQuantizedDotProduct,
   deviceCount: native.deviceCount,
   _native: native,
-};
+});

@@ -311,6 +311,33 @@ function runApiBehaviour() {
   attempt('index dimension', function () { return idx.dimension(); });
   attempt('index size', function () { return idx.size(); });
   attempt('getConfig', function () { return f.getConfig(); });
+  // the small helpers / constants the package root re-exports (src/index.ts:20-37): values on fixed inputs
+  const U = require(path.join(ERASED, 'utils')), VO = require(path.join(ERASED, 'vectorOperations')), VU = require(path.join(ERASED, 'vectorUtils'));
+  const CN = require(path.join(ERASED, 'constants'));
+  const va = new Float32Array([0.5, -1.25, 3, 0.1, -7.5]), vb = new Float32Array([2, 0.75, -0.3, 1e-3, 4]);
+  const arr = function (t) { return Array.from(t); };
+  out.helpers = { inputs: { a: arr(va), b: arr(vb) }, values: {}, errors: {} };
+  const H = out.helpers.values;
+  H.computeL2Norm = U.computeL2Norm(va); H.computeMean = U.computeMean(va); H.computeStd = U.computeStd(va, U.computeMean(va));
+  H.clamp = [U.clamp(5, 0, 1), U.clamp(-5, 0, 1), U.clamp(0.25, 0, 1), U.clamp(NaN, 0, 1)].map(String);
+  H.bitCount = [0, 1, 255, 0xF0F0F0F0, -1, 0x80000000].map(function (n) { return U.bitCount(n); });
+  H.bitCountBytes = U.bitCountBytes(new Uint8Array([0, 255, 170, 1])); H.bitCountBytesOptimized = U.bitCountBytesOptimized(new Uint8Array([0, 255, 170, 1]));
+  H.getBitCount = [0, 7, 255, 256 + 3].map(function (n) { return U.getBitCount(n); });
+  H.BIT_COUNT_LOOKUP_TABLE_sha256 = sha(U.BIT_COUNT_LOOKUP_TABLE);
+  H.isNearZero = [U.isNearZero(1e-9), U.isNearZero(1e-7), U.isNearZero(0.5, 1)];
+  H.isNearEqual = [U.isNearEqual(1, 1 + 1e-9), U.isNearEqual(1, 1.1), U.isNearEqual(1, 1.1, 0.5)];
+  H.scaleMaxInnerProductScore = [U.scaleMaxInnerProductScore(-3), U.scaleMaxInnerProductScore(0), U.scaleMaxInnerProductScore(2.5)];
+  H.addVectors = arr(VO.addVectors(va, vb)); H.subtractVectors = arr(VO.subtractVectors(va, vb)); H.scaleVector = arr(VO.scaleVector(va, 0.3));
+  H.centerVector = arr(VO.centerVector(va, vb)); H.copyVector = arr(VO.copyVector(va));
+  H.computeVectorMagnitude = VU.computeVectorMagnitude(vb); H.createZeroVector = arr(VU.createZeroVector(3));
+  H.createRandomVector_length = VU.createRandomVector(7, 2, 3).length;
+  H.MINIMUM_MSE_GRID = CN.MINIMUM_MSE_GRID; H.FILE_EXTENSIONS = CN.FILE_EXTENSIONS; H.COMPONENT_NAMES = CN.COMPONENT_NAMES;
+  H.NUMERICAL_CONSTANTS = CN.NUMERICAL_CONSTANTS;
+  H.constants = { QUERY_BITS: CN.QUERY_BITS, INDEX_BITS: CN.INDEX_BITS, FOUR_BIT_SCALE: CN.FOUR_BIT_SCALE, DEFAULT_LAMBDA: CN.DEFAULT_LAMBDA, DEFAULT_ITERS: CN.DEFAULT_ITERS };
+  [['addVectors', function () { VO.addVectors(va, new Float32Array(2)); }], ['subtractVectors', function () { VO.subtractVectors(va, new Float32Array(2)); }],
+    ['centerVector', function () { VO.centerVector(va, new Float32Array(2)); }]].forEach(function (p) {
+    try { p[1](); out.helpers.errors[p[0]] = null; } catch (e) { out.helpers.errors[p[0]] = String(e.message); }
+  });
   fs.writeFileSync(path.join(OUT, 'api_behaviour.json'), JSON.stringify(out, null, 1));
   console.log('api_behaviour ok');
 }

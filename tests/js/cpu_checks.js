@@ -156,4 +156,38 @@ T.check(packed[0] === 0xAA, 'packAsBinary');
   try { bbq.computeDotProduct(new Float32Array(2), new Float32Array(3)); } catch (e) { msg = e.message; }
   T.check(msg === '向量维度不匹配', 'computeDotProduct dimension message');
 })();
+// --- the helpers / constants the package root re-exports (src/index.ts:20-37), against values the reference returned
+(function () {
+  const h = api.helpers, va = Float32Array.from(h.inputs.a), vb = Float32Array.from(h.inputs.b), W = h.values;
+  const same = function (got, want, label) { T.check(JSON.stringify(got) === JSON.stringify(want), 'helper ' + label + ': ' + JSON.stringify(got) + ' vs ' + JSON.stringify(want)); };
+  same(bbq.computeL2Norm(va), W.computeL2Norm, 'computeL2Norm'); same(bbq.computeMean(va), W.computeMean, 'computeMean');
+  same(bbq.computeStd(va, bbq.computeMean(va)), W.computeStd, 'computeStd');
+  same([bbq.clamp(5, 0, 1), bbq.clamp(-5, 0, 1), bbq.clamp(0.25, 0, 1), bbq.clamp(NaN, 0, 1)].map(String), W.clamp, 'clamp');
+  same([0, 1, 255, 0xF0F0F0F0, -1, 0x80000000].map(function (n) { return bbq.bitCount(n); }), W.bitCount, 'bitCount');
+  same(bbq.bitCountBytes(new Uint8Array([0, 255, 170, 1])), W.bitCountBytes, 'bitCountBytes');
+  same(bbq.bitCountBytesOptimized(new Uint8Array([0, 255, 170, 1])), W.bitCountBytesOptimized, 'bitCountBytesOptimized');
+  same([0, 7, 255, 256 + 3].map(function (n) { return bbq.getBitCount(n); }), W.getBitCount, 'getBitCount');
+  same(T.sha(bbq.BIT_COUNT_LOOKUP_TABLE), W.BIT_COUNT_LOOKUP_TABLE_sha256, 'BIT_COUNT_LOOKUP_TABLE');
+  same([bbq.isNearZero(1e-9), bbq.isNearZero(1e-7), bbq.isNearZero(0.5, 1)], W.isNearZero, 'isNearZero');
+  same([bbq.isNearEqual(1, 1 + 1e-9), bbq.isNearEqual(1, 1.1), bbq.isNearEqual(1, 1.1, 0.5)], W.isNearEqual, 'isNearEqual');
+  same([bbq.scaleMaxInnerProductScore(-3), bbq.scaleMaxInnerProductScore(0), bbq.scaleMaxInnerProductScore(2.5)], W.scaleMaxInnerProductScore, 'scaleMaxInnerProductScore');
+  same(Array.from(bbq.addVectors(va, vb)), W.addVectors, 'addVectors'); same(Array.from(bbq.subtractVectors(va, vb)), W.subtractVectors, 'subtractVectors');
+  same(Array.from(bbq.scaleVector(va, 0.3)), W.scaleVector, 'scaleVector'); same(Array.from(bbq.centerVector(va, vb)), W.centerVector, 'centerVector');
+  same(Array.from(bbq.copyVector(va)), W.copyVector, 'copyVector'); same(bbq.computeVectorMagnitude(vb), W.computeVectorMagnitude, 'computeVectorMagnitude');
+  same(Array.from(bbq.createZeroVector(3)), W.createZeroVector, 'createZeroVector');
+  const rv = bbq.createRandomVector(7, 2, 3);
+  T.check(rv.length === W.createRandomVector_length && rv.every(function (x) { return x >= 2 && x <= 3; }), 'helper createRandomVector');
+  same(bbq.MINIMUM_MSE_GRID, W.MINIMUM_MSE_GRID, 'MINIMUM_MSE_GRID'); same(bbq.FILE_EXTENSIONS, W.FILE_EXTENSIONS, 'FILE_EXTENSIONS');
+  same(bbq.COMPONENT_NAMES, W.COMPONENT_NAMES, 'COMPONENT_NAMES'); same(bbq.NUMERICAL_CONSTANTS, W.NUMERICAL_CONSTANTS, 'NUMERICAL_CONSTANTS');
+  same({ QUERY_BITS: bbq.QUERY_BITS, INDEX_BITS: bbq.INDEX_BITS, FOUR_BIT_SCALE: bbq.FOUR_BIT_SCALE, DEFAULT_LAMBDA: bbq.DEFAULT_LAMBDA, DEFAULT_ITERS: bbq.DEFAULT_ITERS }, W.constants, 'constants');
+  Object.keys(h.errors).forEach(function (name) {
+    let msg = null;
+    try { bbq[name](va, new Float32Array(2)); } catch (e) { msg = String(e.message); }
+    T.check(msg === h.errors[name], 'helper ' + name + ' dimension error: ' + msg);
+  });
+  let threw = false;
+  try { bbq.computeAccuracy([], []); } catch (e) { threw = /out of scope/.test(e.message); }
+  T.check(threw, 'computeAccuracy says it is out of scope');
+})();
+
 T.finish('js cpu_checks');
