@@ -228,14 +228,15 @@ void add_storage_segments(const bbq_index *ix, Plan &p, int storage, const Stora
 }
 
 // k: the rank the device selects thresholds with; final_k > 0: k == final_k + 1 and the last finalize launch selects the answer
-void build_plan(bbq_index *ix, int64_t k, int64_t final_k = 0, int growth = 0) {
+void build_plan(bbq_index *ix, int64_t k, int64_t final_k = 0, bool latency = false) {
   Plan &p = ix->plan;
-  if (growth <= 0) growth = ix->opt_growth;
-  if (p.k == k && p.final_k == final_k && p.growth == growth) return;
+  const int growth = latency ? ix->opt_latency_growth : ix->opt_growth;
+  if (p.k == k && p.final_k == final_k && p.growth == growth && p.latency == latency) return;
   p = Plan();
   p.k = k;
   p.final_k = final_k;
   p.growth = growth;
+  p.latency = latency;
   p.s0 = std::max<int64_t>(ix->opt_s0, (4 * k + kChunkRows - 1) / kChunkRows * kChunkRows);
   p.s0 = std::min<int64_t>(p.s0, 8192);
   double expected_emit = 0, dummy = 0;
@@ -321,9 +322,9 @@ int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
   s.flood_cap = p.flood_cap;
   s.k_cap = std::max<int64_t>(p.k, 1);
   s.hprefix = hprefix;
-  // theta | flags | topk_counts | list_counts | ovf_counts live in one control block in front of the staged queries: the copy that
+  // theta | flags | topk_counts | list_counts | ovf_counts | append_counts live in one control block in front of the staged queries: the copy that
   // brings a sub-batch's queries also resets them (the host twin's control part stays zero)
-  s.ctrl_bytes = ((int64_t)Q * 24 + 255) / 256 * 256;
+  s.ctrl_bytes = ((int64_t)Q * 28 + 255) / 256 * 256;
   HIPCHK(hipMalloc((void **)&s.d_block, (size_t)(s.ctrl_bytes + Q * qb)));
   HIPCHK(hipHostMalloc((void **)&s.h_block, (size_t)(s.ctrl_bytes + Q * qb), hipHostMallocDefault));
   memset(s.h_block, 0, (size_t)s.ctrl_bytes);
@@ -334,6 +335,7 @@ int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
   s.d_topk_counts = reinterpret_cast<int32_t *>(s.d_theta + 2 * (size_t)Q);
   s.d_list_counts = reinterpret_cast<int32_t *>(s.d_theta + 3 * (size_t)Q);
   s.d_ovf_counts = s.d_theta + 5 * (size_t)Q;
+  s.d_append_counts = s.d_theta + 6 * (size_t)Q;
   if (s.flood_cap > 0) HIPCHK(hipMalloc((void **)&s.d_ovf, (size_t)(Q * s.flood_cap) * 8));
   HIPCHK(hipMalloc((void **)&s.d_counts, (size_t)(Q * s.chunks_cap) * 4));
   HIPCHK(hipMalloc((void **)&s.d_topk, (size_t)(Q * s.k_cap) * 4));
@@ -526,6 +528,9 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
   if (d_counts_ext) HIPCHK(hipMemsetAsync(d_counts_ext, 0, (size_t)nq * 8, st));
 
   const bool use_final = !d_lists_ext && p.final_k > 0 && !p.segs.empty();
+  // few queries: the sparse launches append their candidates to the list themselves (ScanArgs::append_lists)
+  const bool append = use_final && p.latency && !ix->has_pilot && ix->opt_share == 1;
+  s.appended = append;
   s.timed = false;
   for (const Segment &g : p.segs) {
     const Storage &sto = g.storage == 0 ? ix->pilot : ix->main;
@@ -547,6 +552,13 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
     a.ovf_cap = (int32_t)p.flood_cap;
     a.dense_score32 = g.dense ? s.d_dense0 : nullptr;
     a.dense_stride = s.dense_cap;
+    const bool append_here = append && !g.dense && (ix->opt_append_last || &g != &p.segs.back());
+    if (append_here) {
+      a.append_lists = d_lists;
+      a.append_base = d_list_counts;
+      a.append_counts = s.d_append_counts;
+      a.append_cap = list_cap;
+    }
     const int my_slot = (int)(&s - ix->slots);
     if (g.big && ix->ctx->last_big_slot >= 0 && ix->ctx->last_big_slot != my_slot)
       HIPCHK(hipStreamWaitEvent(st, ix->slots[ix->ctx->last_big_slot].ev_big, 0));  // one big sweep at a time on the device
@@ -581,6 +593,7 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
     f.cap = g.cap;
     f.ovf = a.ovf;
     f.ovf_cap = a.ovf_cap;
+    f.append_counts = append_here ? s.d_append_counts : nullptr;
     f.lists = d_lists;
     f.list_counts = d_list_counts;
     f.list_cap = list_cap;
@@ -718,6 +731,8 @@ int begin_replay(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score,
       s.tails[(size_t)i].resize((size_t)(cnt - covered));
       HIPCHK(hipMemcpy(s.tails[(size_t)i].data(), s.d_lists + (size_t)i * s.list_cap + covered, (size_t)(cnt - covered) * 8,
                        hipMemcpyDeviceToHost));
+      // append mode leaves the entries of a segment in arrival order: the reference loop wants them by row (row << 32 | score bits)
+      if (s.appended) std::sort(s.tails[(size_t)i].begin(), s.tails[(size_t)i].end());
     }
   }
   const int64_t k = c.k, n_total = ix->main.row_id_base + ix->main.view.n_rows;
@@ -1015,7 +1030,7 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
   // (FinalizeArgs::final_out); the host replays the heap only for queries with equal scores in or at the edge of their answer
   const int64_t final_k = (keff <= kFinalSelectMax && ix->opt_device_select) ? keff : 0;
   cs.k = final_k > 0 ? keff + 1 : keff;
-  build_plan(ix, cs.k, final_k, (final_k > 0 && n_queries <= ix->opt_latency_queries) ? ix->opt_latency_growth : 0);
+  build_plan(ix, cs.k, final_k, final_k > 0 && n_queries <= ix->opt_latency_queries);
   const int Q = std::max(1, ix->opt_batch);
   const int nslots = std::min(std::max(1, ix->opt_slots), kMaxSlots);
   const int64_t nsub = ((int64_t)n_queries + Q - 1) / Q;
@@ -1215,6 +1230,7 @@ int bbq_set_option(bbq_index *ix, const char *name, int64_t v) {
   else if (n == "force_dense" && (v == 0 || v == 1)) ix->opt_force_dense = (int)v;
   else if (n == "device_select" && (v == 0 || v == 1)) ix->opt_device_select = (int)v;
   else if (n == "latency_queries" && v >= 0 && v <= 1024) ix->opt_latency_queries = (int)v;
+  else if (n == "append_last" && (v == 0 || v == 1)) ix->opt_append_last = (int)v;
   else if (n == "latency_growth" && v >= 2 && v <= 4096) ix->opt_latency_growth = (int)v;
   else if (n == "sweep_share" && (v == 1 || v == 4 || v == 8 || v == 32)) ix->opt_share = (int)v;
   else if (n == "flood_rows" && v >= 0 && v <= (1 << 24)) ix->opt_flood = (v + 1023) / 1024 * 1024;

@@ -94,6 +94,14 @@ struct ScanArgs {
   uint64_t *ovf;               // [Q][ovf_cap]
   uint32_t *ovf_counts;        // [Q] entries handed out so far
   int32_t ovf_cap;
+  // append mode (calls with few queries; null: chunk slots as above): a workgroup reserves room for its candidates right in the
+  // query's list with ONE atomic and writes them there, unordered inside the segment - the finalize launch then has nothing to
+  // compact (walking 19 K chunk counters cost it 20-30 us of a 250 us call).  The answer is selected on the device and does not
+  // care about the order; the rare host replay (equal scores) sorts the list by row first.
+  uint64_t *append_lists;      // [Q][append_cap]
+  const int32_t *append_base;  // [Q][2]: entries the list holds from the earlier segments (list_counts)
+  uint32_t *append_counts;     // [Q] entries this launch has reserved so far
+  int64_t append_cap;
   // dense output (every row), indexed by row - chunk_begin*1024
   float *dense_score32;        // [Q][dense_stride] or null
   int32_t *dense_qcdist;       // or null
@@ -113,6 +121,8 @@ struct FinalizeArgs {
   int32_t cap;
   const uint64_t *ovf;         // flood tier of the scan launch (null: none)
   int32_t ovf_cap;
+  uint32_t *append_counts;     // [Q] non-null: the scan launch appended its candidates to the list itself (ScanArgs::append_lists);
+                               // counts / entries are unused, the launch only takes the keys from list[base, base + count) and resets the counter
   // candidate list being built, ascending by global row
   uint64_t *lists;             // [Q][list_cap]
   int32_t *list_counts;        // [Q][2] {count, flags}
@@ -154,8 +164,9 @@ struct RerankArgs {
 };
 
 constexpr int kFinalizeThreads = 1024;
-constexpr int kFinalizeFloodJobs = 1024;  // flood blocks one finalize launch copies cooperatively (more: thread by thread)
+constexpr int kFinalizeJobs = 4096;      // non-empty chunks one finalize launch copies entry-parallel (more: thread by thread)
 constexpr int kFinalizeKeyCap = 12288;   // LDS key buffer of the finalize kernel (new keys + running top-k)
+constexpr int kFinalizeLdsBytes = (kFinalizeKeyCap + 3 * kFinalizeJobs + 512 + 16 + 16) * 4;  // 98 KB of the CU's 160 KB
 
 __host__ __device__ inline uint32_t key_of_bits(uint32_t b) { return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) 
   u32x4 *s_planes = reinterpret_cast<u32x4 *>(smem);
   uint64_t *s_ent = reinterpret_cast<uint64_t *>(smem + (size_t)w16 * QU * 16);
   // with a flood tier every passing row of the chunk is staged (it may have to move to the overflow area as a whole)
-  const uint32_t stage_cap = DENSE ? 0u : (a.ovf ? (uint32_t)kChunkRows : (uint32_t)a.cap);
+  const uint32_t stage_cap = DENSE ? 0u : ((a.ovf || a.append_lists) ? (uint32_t)kChunkRows : (uint32_t)a.cap);
   uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_ent + stage_cap);
 
   const int q = blockIdx.y;
@@ -306,6 +306,21 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) 
 
   if constexpr (!DENSE) {
     __syncthreads();
+    if (a.append_lists) {  // workgroup-uniform
+      const uint32_t cnt = *s_cnt;
+      if (cnt == 0) return;
+      __syncthreads();  // everyone has read *s_cnt
+      if (tid == 0) *s_cnt = atomicAdd(a.append_counts + q, cnt);
+      __syncthreads();
+      const int64_t at = (int64_t)a.append_base[2 * q] + *s_cnt;
+      if (at + cnt > a.append_cap) {
+        if (tid == 0) atomicOr(a.flags + q, kFlagOverflow);
+        return;
+      }
+      uint64_t *__restrict__ dst = a.append_lists + (size_t)q * a.append_cap + at;
+      for (uint32_t i = tid; i < cnt; i += NT) dst[i] = s_ent[i];
+      return;
+    }
     uint32_t cnt = *s_cnt;
     uint64_t *__restrict__ slot0 = a.entries + ((size_t)q * a.n_chunks + blockIdx.x) * (size_t)a.cap;
     uint64_t *__restrict__ out = slot0;
@@ -494,8 +509,12 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
   return wave_off + incl - v;
 }
 
-// k-th largest of the M keys in LDS (M >= k >= 1): 4-pass radix select, one 1024-thread workgroup; every thread returns it
-__device__ __forceinline__ uint32_t block_select_kth_largest(const uint32_t *s_keys, uint32_t M, uint32_t k, uint32_t *s_hist, uint32_t *s_misc) {
+// k-th largest of the M keys in LDS (M >= k >= 1): radix select over the key bytes that actually vary, one 1024-thread workgroup;
+// every thread returns it.  s_hist: 2 x 256 words, s_wave: 16 words, s_scr: 8 words of scratch owned by this function.
+// Barriers are what this costs (16 waves: ~0.4 us each), so there are two per pass: the histogram of a pass is built in one of two
+// buffers while the other is being cleared, and every pass leaves its result in words of its own.
+__device__ __forceinline__ uint32_t block_select_kth_largest(const uint32_t *s_keys, uint32_t M, uint32_t k, uint32_t *s_hist, uint32_t *s_wave,
+                                                             uint32_t *s_scr) {
   const int tid = threadIdx.x;
   // Scores of one query live in a narrow range: the upper bytes of their keys are the same for (nearly) all of them, and a
   // histogram pass over such a byte is thousands of atomic adds on ONE LDS word (measured: 10 us per pass at 6 K keys).
@@ -506,14 +525,15 @@ __device__ __forceinline__ uint32_t block_select_kth_largest(const uint32_t *s_k
     for (uint32_t i = tid; i < M; i += kFinalizeThreads) vary |= s_keys[i] ^ key0;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) vary |= __shfl_xor(vary, d, 64);
-    if (tid == 0) s_misc[0] = 0;
+    if ((tid & 63) == 0) s_wave[tid >> 6] = vary;
+    if (tid < 512) s_hist[tid] = 0;
     __syncthreads();
-    if ((tid & 63) == 0 && vary) atomicOr(&s_misc[0], vary);
-    __syncthreads();
-    vary = s_misc[0];
-    __syncthreads();
+    vary = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) vary |= s_wave[w];
   }
   uint32_t prefix = 0, mask = 0, kk = k;
+  int buf = 0;
   for (int pass = 3; pass >= 0; --pass) {
     const int sh = pass * 8;
     if (((vary >> sh) & 255u) == 0u) {  // uniform: every key has the same byte here
@@ -521,8 +541,7 @@ __device__ __forceinline__ uint32_t block_select_kth_largest(const uint32_t *s_k
       mask |= 255u << sh;
       continue;
     }
-    if (tid < 256) s_hist[tid] = 0;
-    __syncthreads();
+    uint32_t *__restrict__ hist = s_hist + 256 * buf;
     for (uint32_t i0 = 0; i0 < M; i0 += kFinalizeThreads) {  // whole waves iterate together (ballots below)
       const uint32_t i = i0 + tid;
       const bool in = i < M && (s_keys[i < M ? i : 0] & mask) == prefix;
@@ -534,16 +553,16 @@ __device__ __forceinline__ uint32_t block_select_kth_largest(const uint32_t *s_k
         const uint32_t b0 = __shfl(bin, __ffsll((long long)act) - 1, 64);
         const unsigned long long same = __ballot(in && bin == b0);
         if (in && bin == b0) {
-          if ((tid & 63) == __ffsll((long long)same) - 1) atomicAdd(&s_hist[b0], (uint32_t)__popcll(same));
+          if ((tid & 63) == __ffsll((long long)same) - 1) atomicAdd(&hist[b0], (uint32_t)__popcll(same));
         } else if (in) {
-          atomicAdd(&s_hist[bin], 1u);
+          atomicAdd(&hist[bin], 1u);
         }
       }
     }
     __syncthreads();
     if (tid < 64) {
       // wave 0 finds the bin: lane l owns bins 4l..4l+3; suffix sums over lanes by shuffles (no LDS round trips)
-      const uint32_t h0 = s_hist[4 * tid], h1 = s_hist[4 * tid + 1], h2 = s_hist[4 * tid + 2], h3 = s_hist[4 * tid + 3];
+      const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
       uint32_t suf = h0 + h1 + h2 + h3;  // becomes the sum over bins >= 4*tid
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -557,25 +576,30 @@ __device__ __forceinline__ uint32_t block_select_kth_largest(const uint32_t *s_k
         if (cum + h3 < kk) { cum += h3; b = 4 * tid + 2;
           if (cum + h2 < kk) { cum += h2; b = 4 * tid + 1;
             if (cum + h1 < kk) { cum += h1; b = 4 * tid; } } }
-        s_misc[0] = (uint32_t)b;
-        s_misc[1] = kk - cum;
+        s_scr[2 * pass] = (uint32_t)b;
+        s_scr[2 * pass + 1] = kk - cum;
       }
+    } else if (tid >= 256 && tid < 512) {
+      s_hist[256 * (buf ^ 1) + (tid - 256)] = 0;  // the other buffer, for the next pass
     }
     __syncthreads();
-    prefix |= s_misc[0] << sh;
+    prefix |= s_scr[2 * pass] << sh;
     mask |= 255u << sh;
-    kk = s_misc[1];
-    __syncthreads();
+    kk = s_scr[2 * pass + 1];
+    buf ^= 1;
   }
+  __syncthreads();  // the caller may reuse the scratch words and the keys
   return prefix;
 }
 
 __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const FinalizeArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_keys[kFinalizeKeyCap];
-  __shared__ uint32_t s_hist[256];
-  __shared__ uint32_t s_wave[16];
-  __shared__ uint32_t s_misc[4];
-  __shared__ __attribute__((aligned(16))) uint32_t s_jobs[3 * kFinalizeFloodJobs];  // flood blocks of this launch: {source offset, list offset, entries}
+  // dynamic LDS (kFinalizeLdsBytes, above the 64 KB a kernel gets without asking): keys | copy jobs | histogram | scratch
+  extern __shared__ __attribute__((aligned(16))) unsigned char fin_smem[];
+  uint32_t *s_keys = reinterpret_cast<uint32_t *>(fin_smem);                      // [kFinalizeKeyCap]
+  uint32_t *s_jobs = s_keys + kFinalizeKeyCap;                                      // [3 * kFinalizeJobs] {chunk | redirect, list offset, source offset}
+  uint32_t *s_hist = s_jobs + 3 * kFinalizeJobs;                                    // [2][256]
+  uint32_t *s_wave = s_hist + 512;                                                  // [16]
+  uint32_t *s_misc = s_wave + 16;                                                   // [16]: 0..7 this kernel's, 8..15 the key selection's
   const int q = blockIdx.x;
   const int tid = threadIdx.x;
   uint32_t flags = 0;
@@ -592,48 +616,75 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
       if (i < (uint32_t)kFinalizeKeyCap) s_keys[i] = key_of_bits(bits);
       if (a.emit && base + i < a.list_cap) list[base + i] = ((uint64_t)(uint32_t)(a.dense_row_id_base + i) << 32) | bits;
     }
+  } else if (a.append_counts) {
+    // the scan launch appended its candidates to the list itself: only their keys are needed here
+    m_new = a.append_counts[q];
+    __syncthreads();  // every thread has the count before thread 0 resets it for the next segment
+    if (tid == 0) a.append_counts[q] = 0u;
+    if (base + m_new > a.list_cap) m_new = 0;  // the workgroups that did not fit have flagged the query: it takes the dense path
+    for (uint32_t j = tid; j < m_new && j < (uint32_t)kFinalizeKeyCap; j += kFinalizeThreads) s_keys[j] = key_of_bits((uint32_t)list[base + j]);
+    __syncthreads();
   } else {
+    // Compaction of the chunk slots into the row-ordered list.  Thread t owns cpt consecutive chunks; two block scans give it
+    // its first list offset and its first JOB number (a job = one non-empty chunk), the jobs land in LDS in chunk order, and then
+    // the ENTRIES are dealt to the threads one by one (binary search of the entry's job): every global load of the copy is
+    // independent of every other, where a thread walking its chunks one after the other paid one memory latency per chunk
+    // (31 us for the 19 K chunks of a 10 M-row segment, 5 us this way).
     const int cpt = (a.n_chunks + kFinalizeThreads - 1) / kFinalizeThreads;
     const int c0 = min(tid * cpt, a.n_chunks), c1 = min(c0 + cpt, a.n_chunks);
     const uint32_t *__restrict__ cnts = a.counts + (size_t)q * a.n_chunks;
-    uint32_t sum = 0;
-    for (int c = c0; c < c1; ++c) sum += cnts[c] & ~kCountRedirect;
-    uint32_t total;
-    uint32_t off = block_exclusive_scan_1024(sum, s_wave, total);
-    m_new = total;
-    if (tid == 0) s_misc[3] = 0;
-    __syncthreads();
+    uint32_t sum = 0, nz = 0;
+#pragma unroll 8
     for (int c = c0; c < c1; ++c) {
-      const uint32_t cw = cnts[c], n = cw & ~kCountRedirect;
-      const uint64_t *__restrict__ e = a.entries + ((size_t)q * a.n_chunks + c) * (size_t)a.cap;
-      if (cw & kCountRedirect) {
-        // the chunk's block in the flood tier (up to 512 entries): queued for a cooperative copy below
-        const uint32_t src = (uint32_t)e[0];
-        const uint32_t w = atomicAdd(&s_misc[3], 1u);
-        if (w < (uint32_t)kFinalizeFloodJobs) {
-          s_jobs[3 * w] = src; s_jobs[3 * w + 1] = off; s_jobs[3 * w + 2] = n;
-          off += n;
-          continue;
-        }
-        e = a.ovf + (size_t)q * a.ovf_cap + src;  // job table full: this thread copies the block itself
+      const uint32_t n = cnts[c] & ~kCountRedirect;
+      sum += n;
+      nz += n ? 1u : 0u;
+    }
+    uint32_t total, total_jobs;
+    uint32_t off = block_exclusive_scan_1024(sum, s_wave, total);
+    uint32_t job = block_exclusive_scan_1024(nz, s_wave, total_jobs);
+    m_new = total;
+    if (total_jobs <= (uint32_t)kFinalizeJobs) {
+      for (int c = c0; c < c1; ++c) {
+        const uint32_t cw = cnts[c], n = cw & ~kCountRedirect;
+        if (!n) continue;
+        // a redirected chunk (flood tier) keeps its entries in a block of the query's overflow area; slot 0 says where
+        const uint32_t src = (cw & kCountRedirect) ? (uint32_t)a.entries[((size_t)q * a.n_chunks + c) * (size_t)a.cap] : 0u;
+        s_jobs[3 * job] = (uint32_t)c | (cw & kCountRedirect);
+        s_jobs[3 * job + 1] = off;
+        s_jobs[3 * job + 2] = src;
+        off += n;
+        ++job;
       }
-      for (uint32_t i = 0; i < n; ++i, ++off) {
+      __syncthreads();
+      for (uint32_t j = tid; j < total; j += kFinalizeThreads) {
+        uint32_t lo = 0, hi = total_jobs;  // the last job whose list offset is <= j
+        while (hi - lo > 1u) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_jobs[3 * mid + 1] <= j) lo = mid; else hi = mid;
+        }
+        const uint32_t cw = s_jobs[3 * lo], i = j - s_jobs[3 * lo + 1];
+        const uint64_t *__restrict__ e = (cw & kCountRedirect)
+                                             ? a.ovf + (size_t)q * a.ovf_cap + s_jobs[3 * lo + 2]
+                                             : a.entries + ((size_t)q * a.n_chunks + (cw & ~kCountRedirect)) * (size_t)a.cap;
         const uint64_t ent = e[i];
-        if (a.emit && base + off < a.list_cap) list[base + off] = ent;
-        if (off < (uint32_t)kFinalizeKeyCap) s_keys[off] = key_of_bits((uint32_t)ent);
+        if (a.emit && base + j < a.list_cap) list[base + j] = ent;
+        if (j < (uint32_t)kFinalizeKeyCap) s_keys[j] = key_of_bits((uint32_t)ent);
+      }
+    } else {
+      // more non-empty chunks than the job table holds (very long segments, floods): every thread copies its own chunks
+      for (int c = c0; c < c1; ++c) {
+        const uint32_t cw = cnts[c], n = cw & ~kCountRedirect;
+        const uint64_t *__restrict__ e = a.entries + ((size_t)q * a.n_chunks + c) * (size_t)a.cap;
+        if (cw & kCountRedirect) e = a.ovf + (size_t)q * a.ovf_cap + (uint32_t)e[0];
+        for (uint32_t i = 0; i < n; ++i, ++off) {
+          const uint64_t ent = e[i];
+          if (a.emit && base + off < a.list_cap) list[base + off] = ent;
+          if (off < (uint32_t)kFinalizeKeyCap) s_keys[off] = key_of_bits((uint32_t)ent);
+        }
       }
     }
     __syncthreads();
-    const uint32_t n_jobs = min(s_misc[3], (uint32_t)kFinalizeFloodJobs);
-    for (uint32_t j = 0; j < n_jobs; ++j) {
-      const uint64_t *__restrict__ e = a.ovf + (size_t)q * a.ovf_cap + s_jobs[3 * j];
-      const uint32_t o0 = s_jobs[3 * j + 1], n = s_jobs[3 * j + 2];
-      for (uint32_t i = tid; i < n; i += kFinalizeThreads) {
-        const uint64_t ent = e[i];
-        if (a.emit && base + o0 + i < a.list_cap) list[base + o0 + i] = ent;
-        if (o0 + i < (uint32_t)kFinalizeKeyCap) s_keys[o0 + i] = key_of_bits((uint32_t)ent);
-      }
-    }
   }
   if (a.emit) {
     if (base + m_new > a.list_cap) flags |= kFlagOverflow;
@@ -657,7 +708,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
         for (uint32_t i = tid; i < M; i += kFinalizeThreads) tk[i] = s_keys[i];
         if (tid == 0) { a.topk_counts[q] = (int32_t)M; a.theta[q] = 0u; }
       } else {
-        const uint32_t th = block_select_kth_largest(s_keys, M, (uint32_t)a.k, s_hist, s_misc);  // exactly the k-th largest key among the M keys
+        const uint32_t th = block_select_kth_largest(s_keys, M, (uint32_t)a.k, s_hist, s_wave, s_misc + 8);  // exactly the k-th largest key among the M keys
         if (tid == 0) s_misc[2] = 0;
         __syncthreads();
         for (uint32_t i = tid; i < M; i += kFinalizeThreads) {
@@ -684,7 +735,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
     const uint32_t tcount = (uint32_t)a.topk_counts[q];
     bool ok = f_all == 0 && a.emit && total <= a.list_cap && k2 >= 1 && k2 <= kFinalSelectMax && k2 + 2 <= a.final_stride &&
               m_new <= (uint32_t)kFinalizeKeyCap - tcount;
-    uint64_t *__restrict__ s_sel = reinterpret_cast<uint64_t *>(s_jobs);  // 1536 slots; the flood jobs are done with
+    uint64_t *__restrict__ s_sel = reinterpret_cast<uint64_t *>(s_jobs);  // the copy jobs are done with
     auto bits_of = [](uint32_t key) -> uint32_t { return (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key; };
     uint32_t n_sel = 0, th1 = 0;  // rows with key > th1 are the answer
     const bool take_all = total <= (int64_t)k2;
@@ -717,7 +768,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
         __syncthreads();
         th1 = s_misc[0];
       } else {
-        th1 = block_select_kth_largest(s_keys, M, (uint32_t)(k2 + 1), s_hist, s_misc);
+        th1 = block_select_kth_largest(s_keys, M, (uint32_t)(k2 + 1), s_hist, s_wave, s_misc + 8);
       }
     }
     if (ok) {
@@ -963,7 +1014,7 @@ __global__ __launch_bounds__(256) void bbq_pack_copy_kernel(const uint64_t *__re
 template <int QB, int W, int MODE, int SB = 1>
 static hipError_t launch_scan_t(const ScanArgs &a, int n_queries, int n_chunks, hipStream_t s) {
   const int w16 = W > 0 ? W : a.idx.w16;
-  const size_t smem = (size_t)w16 * query_units_per_chunk(QB, SB) * 16 + ((MODE & 1) ? 0 : (size_t)(a.ovf ? kChunkRows : a.cap) * 8) + 16;
+  const size_t smem = (size_t)w16 * query_units_per_chunk(QB, SB) * 16 + ((MODE & 1) ? 0 : (size_t)((a.ovf || a.append_lists) ? kChunkRows : a.cap) * 8) + 16;
   dim3 grid((unsigned)n_chunks, (unsigned)n_queries, 1), block(kChunkRows, 1, 1);
   hipLaunchKernelGGL((bbq_scan_kernel<QB, W, MODE, SB>), grid, block, smem, s, a);
   return hipGetLastError();
@@ -1069,7 +1120,10 @@ hipError_t launch_scan(const ScanArgs &a, int planes, bool dense, int n_queries,
 }
 
 hipError_t launch_finalize(const FinalizeArgs &a, int n_queries, hipStream_t s) {
-  hipLaunchKernelGGL(bbq_finalize_kernel, dim3((unsigned)n_queries), dim3(kFinalizeThreads), 0, s, a);
+  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(bbq_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               kFinalizeLdsBytes);  // once per process: more than the 64 KB a launch gets by default
+  if (attr != hipSuccess) return attr;
+  hipLaunchKernelGGL(bbq_finalize_kernel, dim3((unsigned)n_queries), dim3(kFinalizeThreads), kFinalizeLdsBytes, s, a);
   return hipGetLastError();
 }
 

@@ -306,7 +306,8 @@ int bbq_reset_stats(bbq_index *idx);
  *   device_select 0|1 (1: for k <= 1024 the device selects and sorts the answer itself whenever no two scores in or at the edge of it
  *   compare equal - then the reference heap provably returns that order - and the host replays the heap only for the rest)
  *   latency_queries 0..1024 (4), latency_growth 2..4096 (64): calls with at most latency_queries queries walk the index in
- *   segments that grow by latency_growth instead of segment_growth (fewer dependent launches, more candidates per query) */
+ *   segments that grow by latency_growth instead of segment_growth (fewer dependent launches, more candidates per query) and their
+ *   sweeps append the candidates to the query's list themselves (one atomic per workgroup; append_last 0|1 (1): also the last segment) */
 int bbq_set_option(bbq_index *idx, const char *name, int64_t value);
 
 #ifdef __cplusplus

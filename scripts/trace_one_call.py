@@ -5,15 +5,23 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda e: e[0])
-# a call = the kernels between two idle gaps of more than 100 us
-calls, cur = [], []
-for e in ev:
-    if cur and e[0] - cur[-1][1] > 100_000:
-        calls.append(cur)
-        cur = []
-    cur.append(e)
-calls.append(cur)
-call = calls[-2] if len(calls) > 1 else calls[-1]
+# a call starts with its dense first-segment sweep (scan kernel MODE 1 / 3) and the host-to-device copy right before it
+def is_dense(name):
+    if "bbq_scan_kernel<" not in name:
+        return False
+    mode = name.split("bbq_scan_kernel<")[1].split(">")[0].split(",")[2].strip()
+    return mode in ("1", "3")
+
+
+starts = [i for i, e in enumerate(ev) if is_dense(e[2])]
+if len(starts) < 3:
+    raise SystemExit("fewer than three calls in the trace")
+a, b = starts[-2], starts[-1]
+while a > 0 and "copyBuffer" in ev[a - 1][2] and ev[a][0] - ev[a - 1][1] < 30_000:
+    a -= 1
+while b > a and "copyBuffer" in ev[b - 1][2] and ev[b][0] - ev[b - 1][1] < 30_000:
+    b -= 1
+call = ev[a:b]
 t0 = call[0][0]
 prev_end = t0
 busy = 0

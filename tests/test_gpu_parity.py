@@ -209,12 +209,19 @@ def test_adversarial_increasing_scores_falls_back_and_stays_exact():
     ix = B.Index(codes, corr, dim, cdp)
     try:
         oi, os_ = _oracle_topk(codes, corr, dim, qq, qc, 4, sim, cdp, k)
+        ix.set_option("latency_queries", 0)     # the chunk-slot path (calls with few queries append to the list instead: below)
         for flood_rows, dense in ((262144, 0), (0, 1)):
             ix.set_option("flood_rows", flood_rows)
             idx, sc = ix.search(qq, qc, 4, sim, k)
             np.testing.assert_array_equal(idx, oi)
             np.testing.assert_array_equal(sc.view(np.uint32), os_.view(np.uint32))
             assert ix.stats()["dense_fallbacks"] == dense
+        ix.set_option("latency_queries", 4)     # append mode: every row is a candidate, the list takes them or the query goes dense
+        for flood_rows in (262144, 0):
+            ix.set_option("flood_rows", flood_rows)
+            idx, sc = ix.search(qq, qc, 4, sim, k)
+            np.testing.assert_array_equal(idx, oi)
+            np.testing.assert_array_equal(sc.view(np.uint32), os_.view(np.uint32))
     finally:
         ix.close()
 
