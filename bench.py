@@ -307,6 +307,12 @@ def main():
     if args.dry_run:
         raise SystemExit(dry_run(args))
 
+    # stdout carries ONE JSON line and nothing else: libraries that print to file descriptor 1 (RCCL's version banner, gloo's connection
+    # report) are sent to stderr for the rest of the run; the line itself is written to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import bbq_amd as B
 
@@ -536,7 +542,7 @@ def main():
             rec, desc = recall_probe(B, device, n=args.recall_rows if args.recall_rows > 0 else min(N, 10_000_000), dim=dim)
             out["recall_at_100"] = rec
             out["recall_config"] = desc
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ix.close()
     if dist is not None:
         dist.barrier()
