@@ -3,6 +3,8 @@ against the reference's computeQuantizedDotProduct fixtures, the scores and top-
 an index (per-row fallback, src/binaryQuantizedScorer.ts:403-419) where it returns anything (queryBits 1 and 4), and against
 the oracle's restatement of the same formula where the reference throws (every other queryBits: "parity unpinned" beyond the
 integer dot product)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -68,7 +70,7 @@ def test_integer_dot_fixtures_through_score_rows(name):
             ix.close()
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BBQ_FUZZ_MULTIBIT_SEEDS", "16"))))   # BBQ_FUZZ_MULTIBIT_SEEDS=300 for a soak
 def test_multibit_randomized_vs_oracle(seed):
     """random (n, dim, indexBits, queryBits, similarity, layout, segment plan): index bytes from the product's quantizer equal the
     oracle's, integers / f64 / f32 scores and the replayed top-k equal the oracle's multi-bit path"""

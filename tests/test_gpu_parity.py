@@ -944,6 +944,13 @@ def test_fuzz_shapes_options_vs_oracle(seed):
         np.testing.assert_array_equal(gd, d)
         np.testing.assert_array_equal(canon64(g64), canon64(s64))
         np.testing.assert_array_equal(canon32(g32), canon32(s32))
+        # the single-query call shape (latency plan: few fast-growing segments, candidates appended by the sweeps)
+        ix.set_option("latency_growth", int(rng.choice([2, 64, 4096])))
+        ix.set_option("append_last", int(rng.integers(0, 2)))
+        i1, s1 = ix.search(qq[0], qc[0], qb, sim, k)
+        oi, osc = O.heap_topk(s32, k)
+        np.testing.assert_array_equal(i1, oi)
+        np.testing.assert_array_equal(canon32(s1), canon32(osc))
     finally:
         ix.close()
 
@@ -1091,6 +1098,12 @@ def test_fuzz_medium_sizes_vs_oracle(seed):
             np.testing.assert_array_equal(idx[i, :cnt[i]], oi)
             np.testing.assert_array_equal(canon32(sc[i, :cnt[i]]), canon32(osc))
         assert ix.stats()["dense_fallbacks"] == 0
+        for i in range(min(nq, 3)):     # and one query per call (latency plan, append mode)
+            d, s64, s32 = O.score_all(codes, corr, dim, qq[i], qc[i], qb, sim, cdp)
+            oi, osc = O.heap_topk(s32, k)
+            i1, s1 = ix.search(qq[i], qc[i], qb, sim, k)
+            np.testing.assert_array_equal(i1, oi)
+            np.testing.assert_array_equal(canon32(s1), canon32(osc))
     finally:
         ix.close()
 
