@@ -458,7 +458,7 @@ def main():
         try:
             reg = json.load(open(os.path.join(ROOT, "profiles", "dominant_kernel.json")))
             for e in reg["entries"]:
-                if (e["dim"], e["index_bits"], e["query_bits"], e["bytes_per_row"]) == (dim, IB, QB, bytes_per_row):
+                if (e["rows"], e["dim"], e["index_bits"], e["query_bits"], e["bytes_per_row"]) == (N, dim, IB, QB, bytes_per_row) and world == 1:
                     if e.get("hbm_bytes_per_row") is not None:
                         traffic = e["hbm_bytes_per_row"] * (launch_bytes / bytes_per_row)
                         traffic_src = {"file": "profiles/dominant_kernel.json", "hbm_bytes_per_row": e["hbm_bytes_per_row"], "kernel": e["kernel"],

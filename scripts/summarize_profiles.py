@@ -2,7 +2,7 @@
 
   profiles/rNN_<tag>_dominant_launch.json   the dominant scan launches picked out of the kernel trace (average / min / max, GB/s)
                                             next to bench.py's own hipEvent average of the same profiled run
-  profiles/dominant_kernel.json             registry bench.py reads: per (dim, indexBits, queryBits, bytes/row) the kernel-trace
+  profiles/dominant_kernel.json             registry bench.py reads: per (rows, dim, indexBits, queryBits, bytes/row) the kernel-trace
                                             average and the PMC traffic per row, with where and how they were collected.  bench.py
                                             quotes an entry only for the kernel and layout it is actually running.
 
@@ -47,11 +47,12 @@ def main():
         "trace_avg_GBps": bpl / (sum(us) / len(us) * 1e-6) / 1e9, "trace_min_us_GBps": bpl / (min(us) * 1e-6) / 1e9,
         "hipEvent_avg_ms_same_profiled_run": roof["avg_launch_ms"], "hipEvent_GBps_same_profiled_run": roof["achieved"],
     }
-    entry = {"dim": None, "index_bits": None, "query_bits": None, "bytes_per_row": bench["config"]["bytes_per_row"], "kernel": dom[0]["Kernel_Name"],
+    entry = {"rows": None, "dim": None, "index_bits": None, "query_bits": None, "bytes_per_row": bench["config"]["bytes_per_row"], "kernel": dom[0]["Kernel_Name"],
              "collected": "%s, %s" % (rnd, tag), "trace_avg_us": out["trace_avg_us"], "trace_launches": len(us), "trace_bytes_per_launch": bpl,
              "trace_avg_GBps": out["trace_avg_GBps"], "hbm_bytes_per_row": None, "pmc_how": None}
     # "<rows>x<dim>-dim <ib>-bit index, queryBits=<qb>, ..."
     w = bench["config"]["workload"]
+    entry["rows"] = int(w.split("x")[0])
     entry["dim"] = int(w.split("x")[1].split("-")[0])
     entry["index_bits"] = int(w.split("-dim ")[1].split("-bit")[0])
     entry["query_bits"] = int(w.split("queryBits=")[1].split(",")[0])
@@ -76,8 +77,8 @@ def main():
     json.dump(out, open(os.path.join(ROOT, "profiles", "%s_%s_dominant_launch.json" % (rnd, tag)), "w"), indent=1)
     regp = os.path.join(ROOT, "profiles", "dominant_kernel.json")
     reg = json.load(open(regp)) if os.path.exists(regp) else {"entries": []}
-    key = (entry["dim"], entry["index_bits"], entry["query_bits"], entry["bytes_per_row"])
-    reg["entries"] = [e for e in reg["entries"] if (e["dim"], e["index_bits"], e["query_bits"], e["bytes_per_row"]) != key] + [entry]
+    key = (entry["rows"], entry["dim"], entry["index_bits"], entry["query_bits"], entry["bytes_per_row"])
+    reg["entries"] = [e for e in reg["entries"] if (e.get("rows"), e["dim"], e["index_bits"], e["query_bits"], e["bytes_per_row"]) != key] + [entry]
     json.dump(reg, open(regp, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
