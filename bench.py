@@ -230,6 +230,7 @@ def self_launch(args):
     log("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)))
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")   # RCCL's kernels must get in between sweeps that keep every CU busy
     env.setdefault("OMP_NUM_THREADS", "1")
     # the ranks' stdout is filtered: the JSON line goes to stdout, library chatter (gloo prints its connection report there) to stderr
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
@@ -333,6 +334,7 @@ def main():
             local %= ndev   # a launcher that narrows the visible devices per rank leaves each rank with device 0
         torch.cuda.set_device(local)
         if args.backend == "nccl":
+            os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")   # the collectives' kernels share the GPU with sweeps that keep every CU busy
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(args.backend)
@@ -400,6 +402,8 @@ def main():
 
     run(batches[:args.warmup])
     ix.reset_stats()
+    if dist is not None:
+        searcher.phases_ms()   # forget the warm-up
     barrier()
     t0 = time.perf_counter()
     run(batches[args.warmup:])
@@ -410,6 +414,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = ix.stats()
+    sharded = None
+    if dist is not None:
+        # where a batch's time goes on every rank (scan on the scanner thread, the rest next to it on the main thread): max over ranks
+        mine = searcher.phases_ms()
+        keys = ["scan", "headers", "payload", "to_host", "replay", "answers"]
+        tt = torch.tensor([mine[k_] for k_ in keys], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        sharded = {"max_over_ranks_ms_per_batch": {k_: round(float(v), 3) for k_, v in zip(keys, tt.tolist())}, "rank0": mine}
     batched = None
     if dist is None and args.shared_sweep in (4, 8, 32) and IB == 1:
         # API extension, reported separately: `shared_sweep` queries share one sweep of the index
@@ -495,6 +507,8 @@ def main():
             "dense_fallbacks": st["dense_fallbacks"],
         }
         out["argv"] = " ".join(sys.argv[1:])
+        if sharded is not None:
+            out["sharded_phases"] = sharded
         if latency is not None:
             out["latency"] = latency
         if batched is not None:

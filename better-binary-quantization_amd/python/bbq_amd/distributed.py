@@ -19,6 +19,7 @@ the sparse path (rare; costs two extra collectives for such a batch).
 """
 import queue
 import threading
+import time
 
 import numpy as np
 
@@ -52,15 +53,27 @@ class ShardedSearcher:
                 "flags": torch.zeros(self.Q, dtype=torch.int32, device=device),
             })
         self._pin = str(self.cdev).startswith("cuda")
+        # the exchange's small device operations (header arithmetic, copies, the collectives' kernels) share the GPU with sweeps that
+        # keep every CU busy: on a stream of normal priority each of them waited for up to a whole sweep (3 ms at 10 M rows per rank).
+        # They run on a high-priority stream instead (TORCH_NCCL_HIGH_PRIORITY does the same for RCCL's own stream, set by bench.py)
+        self._stream = torch.cuda.Stream(priority=-1) if self._pin else None
         self.hdr_in = torch.zeros(self.world * self.hdr_len, dtype=torch.int64, device=self.cdev)
         self.res_out = torch.zeros(self.Qb * (2 * self.k + 1), dtype=torch.int32, device=self.cdev)
         self.res_in = [torch.zeros(self.Qb * (2 * self.k + 1), dtype=torch.int32, device=self.cdev) for _ in range(self.world)] if self.rank == 0 else None
         self._recv = None        # grow-only landing buffer of the packed entries of my block (collective device)
         self._h_recv = None      # its pinned host twin
         self.last_exchange = {}  # sizes of the last batch's exchange (bench / diagnostics)
+        self.phase_s = {"scan": 0.0, "headers": 0.0, "payload": 0.0, "to_host": 0.0, "replay": 0.0, "answers": 0.0, "batches": 0}  # this rank's wall time per phase
 
     # ------------------------------------------------------------------ one rank's sweep of one batch
     def _scan(self, buf, qq, qc):
+        t0 = time.perf_counter()
+        try:
+            return self._scan_inner(buf, qq, qc)
+        finally:
+            self.phase_s["scan"] += time.perf_counter() - t0
+
+    def _scan_inner(self, buf, qq, qc):
         nq = qq.shape[0]
         if self._scan_fn is not None:  # tests without a GPU inject (packed, offsets, flags) numpy arrays
             packed, offsets, flags = self._scan_fn(qq, qc)
@@ -82,7 +95,15 @@ class ShardedSearcher:
         return self._recv
 
     def _merge(self, buf, nq, total, qq, qc):
+        if self._stream is None:
+            return self._merge_on_stream(buf, nq, total, qq, qc)
+        with self.torch.cuda.stream(self._stream):
+            return self._merge_on_stream(buf, nq, total, qq, qc)
+
+    def _merge_on_stream(self, buf, nq, total, qq, qc):
         t, dist, W, Qb, k = self.torch, self.dist, self.world, self.Qb, self.k
+        ph, clock = self.phase_s, time.perf_counter
+        t0 = clock()
         # ---- 1. headers: what I hold for every owner block
         off = buf["offsets"][:nq + 1].to(self.cdev)
         flags = buf["flags"][:nq].to(self.cdev)
@@ -102,15 +123,23 @@ class ShardedSearcher:
         out_counts = h[W * self.hdr_len:].tolist()
         in_counts = hin[:, 0].tolist()
         any_flag = bool(hin[:, 1].any())
+        t1 = clock()
+        ph["headers"] += t1 - t0
         # ---- 2. the packed entries of my block, from every shard
         n_in = int(sum(in_counts))
         recv = self._grow(n_in)[:n_in]
         send = buf["packed"][:total].to(self.cdev)
         dist.all_to_all_single(recv, send, output_split_sizes=in_counts, input_split_sizes=out_counts)
+        if recv.is_cuda:
+            t.cuda.current_stream().synchronize()
+        t2 = clock()
+        ph["payload"] += t2 - t1
         self._h_recv[:n_in].copy_(recv, non_blocking=True)
         if recv.is_cuda:
             t.cuda.current_stream().synchronize()
         hp = self._h_recv[:n_in].numpy().view(np.uint64)
+        t3 = clock()
+        ph["to_host"] += t3 - t2
         # ---- replay of my block (shard order = rank order)
         nqb = max(0, min(Qb, nq - self.rank * Qb))
         res = np.zeros((Qb, 2 * k + 1), np.int32)
@@ -124,6 +153,8 @@ class ShardedSearcher:
             res[:nqb, :k] = idx
             res[:nqb, k:2 * k] = sc.view(np.int32)
             res[:nqb, 2 * k] = cnt
+        t4 = clock()
+        ph["replay"] += t4 - t3
         self.last_exchange = {"entries_received": n_in, "entries_sent": int(total), "header_int64": int(W * self.hdr_len), "block_queries": int(nqb)}
         # ---- 3. answers of every block to rank 0
         self.res_out.copy_(t.from_numpy(res.reshape(-1)))
@@ -132,6 +163,8 @@ class ShardedSearcher:
         if self.rank == 0:
             allr = t.stack(self.res_in).cpu().numpy().reshape(W * Qb, 2 * k + 1)[:nq]
             out = (np.ascontiguousarray(allr[:, :k]), np.ascontiguousarray(allr[:, k:2 * k]).view(np.float32), allr[:, 2 * k].astype(np.int64))
+        ph["answers"] += clock() - t4
+        ph["batches"] += 1
         if any_flag:   # collective: every rank takes part; rank 0 overwrites those queries' rows
             gf = t.zeros(W * nq, dtype=t.int32, device=self.cdev)
             dist.all_gather_into_tensor(gf, buf["flags"][:nq].to(self.cdev).contiguous())
@@ -164,6 +197,17 @@ class ShardedSearcher:
                 ent = (np.arange(len(s_all), dtype=np.uint64) << np.uint64(32)) | s_all.view(np.uint32).astype(np.uint64)
                 i1, s1 = capi.replay([ent], self.n_total, self.k)
                 idx[q, :len(i1)], sc[q, :len(i1)], cnt[q] = i1, s1, len(i1)
+
+    def phases_ms(self, reset=True):
+        """this rank's average wall time per batch and phase (scan runs on the scanner thread, next to the others)"""
+        n = max(self.phase_s["batches"], 1)
+        out = {k_: round(v / n * 1e3, 3) for k_, v in self.phase_s.items() if k_ != "batches"}
+        out["batches"] = self.phase_s["batches"]
+        out.update(self.last_exchange)
+        if reset:
+            for k_ in self.phase_s:
+                self.phase_s[k_] = 0 if k_ == "batches" else 0.0
+        return out
 
     # ------------------------------------------------------------------ public
     def search(self, qq, qc):
