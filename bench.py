@@ -14,6 +14,7 @@ real fp32 -> quantize -> search run provides recall@100 against an fp32 brute fo
 Prints ONE JSON line (rank 0) with the driver's contract plus "roofline" and "cpu_baseline".
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -335,9 +336,10 @@ def main():
         torch.cuda.set_device(local)
         if args.backend == "nccl":
             os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")   # the collectives' kernels share the GPU with sweeps that keep every CU busy
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            # a rank that fails must not leave the others waiting in a collective for the default ten minutes
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=datetime.timedelta(seconds=300))
     if world != args.gpus:   # self_launch() has already refused this; kept as a guard for callers that bypass main()
         raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     device = local if world > 1 else 0
