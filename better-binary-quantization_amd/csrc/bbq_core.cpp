@@ -529,7 +529,7 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
 
   const bool use_final = !d_lists_ext && p.final_k > 0 && !p.segs.empty();
   // few queries: the sparse launches append their candidates to the list themselves (ScanArgs::append_lists)
-  const bool append = use_final && p.latency && !ix->has_pilot && ix->opt_share == 1;
+  const bool append = use_final && p.latency && ix->opt_latency_append && !ix->has_pilot && ix->opt_share == 1;
   s.appended = append;
   s.timed = false;
   for (const Segment &g : p.segs) {
@@ -1231,6 +1231,7 @@ int bbq_set_option(bbq_index *ix, const char *name, int64_t v) {
   else if (n == "device_select" && (v == 0 || v == 1)) ix->opt_device_select = (int)v;
   else if (n == "latency_queries" && v >= 0 && v <= 1024) ix->opt_latency_queries = (int)v;
   else if (n == "append_last" && (v == 0 || v == 1)) ix->opt_append_last = (int)v;
+  else if (n == "latency_append" && (v == 0 || v == 1)) ix->opt_latency_append = (int)v;
   else if (n == "latency_growth" && v >= 2 && v <= 4096) ix->opt_latency_growth = (int)v;
   else if (n == "sweep_share" && (v == 1 || v == 4 || v == 8 || v == 32)) ix->opt_share = (int)v;
   else if (n == "flood_rows" && v >= 0 && v <= (1 << 24)) ix->opt_flood = (v + 1023) / 1024 * 1024;

@@ -157,6 +157,7 @@ struct bbq_index {
   // a call with few queries is latency-bound: every segment costs a dependent scan + finalize launch pair (~15-20 us), so such calls
   // walk the index in fewer, faster-growing segments (more candidates per query - the device selects the answer itself anyway)
   int opt_latency_queries = 4, opt_latency_growth = 64;
+  int opt_latency_append = 1;  // 0: calls with few queries keep the chunk slots (and the finalize launches their compaction)
   int opt_append_last = 1;  // append mode also for the last (largest) segment: its finalize launch gets cheaper, its sweep slower (one
                             // atomic per workgroup with candidates); measured at 10 M x 768: 0.250 ms per call with, 0.263 without
   // host threads replaying the heaps of one sub-batch: half the cores, at most 8 (a batch of 32 answers 1.4x sooner than with 1)

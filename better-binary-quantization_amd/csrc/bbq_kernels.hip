@@ -600,6 +600,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
   uint32_t *s_hist = s_jobs + 3 * kFinalizeJobs;                                    // [2][256]
   uint32_t *s_wave = s_hist + 512;                                                  // [16]
   uint32_t *s_misc = s_wave + 16;                                                   // [16]: 0..7 this kernel's, 8..15 the key selection's
+  uint16_t *s_counts = reinterpret_cast<uint16_t *>(s_misc + 16);                   // [kFinalizeCountCap] chunk counters of the launch, 16 bits each
   const int q = blockIdx.x;
   const int tid = threadIdx.x;
   uint32_t flags = 0;
@@ -632,11 +633,26 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
     // (31 us for the 19 K chunks of a 10 M-row segment, 5 us this way).
     const int cpt = (a.n_chunks + kFinalizeThreads - 1) / kFinalizeThreads;
     const int c0 = min(tid * cpt, a.n_chunks), c1 = min(c0 + cpt, a.n_chunks);
-    const uint32_t *__restrict__ cnts = a.counts + (size_t)q * a.n_chunks;
+    const uint32_t *__restrict__ gcnts = a.counts + (size_t)q * a.n_chunks;
+    // the chunk counters are read twice in chunk order by their owner; staged through LDS they are read from memory ONCE, coalesced
+    // (a thread reading its 19 consecutive words from global memory, twice, was most of what was left of the compaction)
+    const bool staged = a.n_chunks <= kFinalizeCountCap;
+    if (staged) {  // 16 bits per counter: at most 512 candidates per chunk, bit 15 = the redirect flag
+      for (int c = tid; c < a.n_chunks; c += kFinalizeThreads) {
+        const uint32_t cw = gcnts[c];
+        s_counts[c] = (uint16_t)((cw & 0x7fffu) | ((cw & kCountRedirect) ? 0x8000u : 0u));
+      }
+      __syncthreads();
+    }
+    auto count_word = [&](int c) -> uint32_t {
+      if (!staged) return gcnts[c];
+      const uint32_t h = s_counts[c];
+      return (h & 0x7fffu) | ((h & 0x8000u) ? kCountRedirect : 0u);
+    };
     uint32_t sum = 0, nz = 0;
 #pragma unroll 8
     for (int c = c0; c < c1; ++c) {
-      const uint32_t n = cnts[c] & ~kCountRedirect;
+      const uint32_t n = count_word(c) & ~kCountRedirect;
       sum += n;
       nz += n ? 1u : 0u;
     }
@@ -646,7 +662,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
     m_new = total;
     if (total_jobs <= (uint32_t)kFinalizeJobs) {
       for (int c = c0; c < c1; ++c) {
-        const uint32_t cw = cnts[c], n = cw & ~kCountRedirect;
+        const uint32_t cw = count_word(c), n = cw & ~kCountRedirect;
         if (!n) continue;
         // a redirected chunk (flood tier) keeps its entries in a block of the query's overflow area; slot 0 says where
         const uint32_t src = (cw & kCountRedirect) ? (uint32_t)a.entries[((size_t)q * a.n_chunks + c) * (size_t)a.cap] : 0u;
@@ -674,7 +690,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
     } else {
       // more non-empty chunks than the job table holds (very long segments, floods): every thread copies its own chunks
       for (int c = c0; c < c1; ++c) {
-        const uint32_t cw = cnts[c], n = cw & ~kCountRedirect;
+        const uint32_t cw = count_word(c), n = cw & ~kCountRedirect;
         const uint64_t *__restrict__ e = a.entries + ((size_t)q * a.n_chunks + c) * (size_t)a.cap;
         if (cw & kCountRedirect) e = a.ovf + (size_t)q * a.ovf_cap + (uint32_t)e[0];
         for (uint32_t i = 0; i < n; ++i, ++off) {
