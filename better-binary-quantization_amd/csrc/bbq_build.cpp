@@ -11,12 +11,19 @@ using namespace bbq;
 
 extern "C" {
 
-// quantizeVectors on the device + index in place (bbq_build_kernels.hip)
 int bbq_index_build(const float *vectors, int64_t n, int32_t dim, int32_t sim, double lambda, int32_t iters, int32_t device,
                     bbq_index **out, float *centroid, uint8_t *codes, double *corr, int64_t *bad_row, int32_t *bad_col) {
+  return bbq_index_build_bits(vectors, n, dim, sim, 1, lambda, iters, device, out, centroid, codes, corr, bad_row, bad_col);
+}
+
+// quantizeVectors on the device + index in place (bbq_build_kernels.hip)
+int bbq_index_build_bits(const float *vectors, int64_t n, int32_t dim, int32_t sim, int32_t index_bits, double lambda, int32_t iters,
+                         int32_t device, bbq_index **out, float *centroid, uint8_t *codes, double *corr, int64_t *bad_row, int32_t *bad_col) {
   clear_error();
   if (!out) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_build: out is null");
   *out = nullptr;
+  if (index_bits < 1 || index_bits > 8) return fail(BBQ_ERR_INVALID_ARG, "indexBits必须在1-8之间");
+  if ((int64_t)dim * 255 * 255 > 0x7fffffffll) return fail(BBQ_ERR_UNSUPPORTED, "dimension %d: the integer dot product would not fit 31 bits", dim);
   if (n == 0) return fail(BBQ_ERR_EMPTY, "向量集合不能为空");
   if (n < 0 || dim <= 0 || !vectors || !centroid) return fail(BBQ_ERR_INVALID_ARG, "输入向量不能为空");
   if (sim < 0 || sim > 2) return fail(BBQ_ERR_INVALID_ARG, "不支持的相似性函数: %d", sim);
@@ -93,13 +100,34 @@ int bbq_index_build(const float *vectors, int64_t n, int32_t dim, int32_t sim, d
   ix->aux_stream = ctx->aux_stream;
   ix->d_aux_flags = ctx->d_aux_flags;
   ix->dim = dim;
-  ix->pb = (dim + 7) / 8;
+  ix->index_bits = index_bits;
+  ix->store_bits = dim == 1 ? 1 : store_bits_of(index_bits);
+  ix->pb = row_bytes_of(dim, ix->store_bits);
   ix->w16 = (ix->pb + 15) / 16;
   ix->n_rows = n;
   ix->row_base = 0;
   {
     const char *e = getenv("BBQ_COMPACT_CORRECTIONS");
     ix->want_compact = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (index_bits > 1) {
+    // more than one bit: the kernel leaves what the reference keeps for such an index - one byte per dimension - and the corrections
+    // in device memory; the tile records are built from there exactly as bbq_index_create builds them from host rows
+    BCHK(hipMalloc((void **)&d_codes, (size_t)n * dim));
+    BCHK(hipMalloc((void **)&d_corr, (size_t)n * 32));
+    BCHK(launch_build_quantize_bits(d_vT4, n, dim, npad, d_cen, sim, lambda, iters, index_bits, d_codes, d_corr, st));  // :221-249
+    BCHK(hipStreamSynchronize(st));
+    BCHK(hipFree(d_vT4));
+    d_vT4 = nullptr;
+    ix->centroid_dp = bbq_centroid_dp(centroid, dim);
+    rc = storage_from_device_rows(ix.get(), ix->main, d_codes, d_corr, n, 0, true);
+    if (rc == BBQ_OK && corr && hipMemcpy(corr, d_corr, (size_t)n * 32, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(BBQ_ERR_HIP, "bbq_index_build: copy of the corrections failed");
+    if (rc == BBQ_OK && codes && hipMemcpy(codes, d_codes, (size_t)n * dim, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(BBQ_ERR_HIP, "bbq_index_build: copy of the codes failed");
+    if (rc == BBQ_OK) rc = ensure_aux_qbuf(ctx, qbuf_bytes_per_query_w(ix->w16));
+    cleanup();
+    if (rc != BBQ_OK) { destroy_unlocked(ix.release()); return rc; }
+    *out = ix.release();
+    return BBQ_OK;
   }
   ix->has_x1 = 0;  // a freshly quantized 1-bit row's component sum IS its popcount
   ix->layout = ix->want_compact ? kLayoutCompact : kLayoutInline;

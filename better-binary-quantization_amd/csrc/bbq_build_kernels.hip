@@ -1,5 +1,5 @@
 // bbq_build_kernels.hip - index build on the device (gfx950): BinaryQuantizationFormat.quantizeVectors
-// (reference src/binaryQuantizationFormat.ts:165-263) for indexBits == 1, bit-exact.
+// (reference src/binaryQuantizationFormat.ts:165-263) for every indexBits, bit-exact.
 //
 //   transpose_in   [n][dim] f32 (as uploaded)  ->  vT4[dim/4][npad] float4   (lane = vector => every later access is coalesced)
 //   normalize      COSINE: normalizeVector (src/vectorOperations.ts:11-34), one thread per vector, f64 sum in index order
@@ -179,14 +179,15 @@ __global__ __launch_bounds__(64) void bbq_centroid_kernel(const f32x4 *__restric
 struct BuildOut {
   uint8_t *tiles;      // scan layout (bbq_device.h)
   double *exact;       // kLayoutCompact side array, or null
-  double *corr_rm;     // [n][4] row-major corrections for the host, or null
+  double *corr_rm;     // [n][4] row-major corrections for the host, or null (bits > 1: required)
+  uint8_t *codes_rm;   // bits > 1: [n][dim] one byte per dimension
   int32_t w16, tile_stride, layout;
 };
 
-// one pass of computeLoss over the vector (src/optimizedScalarQuantizer.ts:373-407), points == 2
+// one pass of computeLoss over the vector (src/optimizedScalarQuantizer.ts:373-407); pm1 = points - 1 = 2^bits - 1
 __device__ __forceinline__ double loss_pass(const f32x4 *__restrict__ col, int64_t npad, const float *__restrict__ s_cen, int dim,
-                                            int dim4, double a, double b, double norm2, double lambda) {
-  const double step = (b - a) / 1.0;
+                                            int dim4, double a, double b, double norm2, double lambda, double pm1) {
+  const double step = (b - a) / pm1;
   const double step_inv = 1.0 / step;
   double xe = 0.0, e = 0.0;
   for (int i4 = 0; i4 < dim4; ++i4) {
@@ -207,9 +208,11 @@ __device__ __forceinline__ double loss_pass(const f32x4 *__restrict__ col, int64
   return (1.0 - lambda) * xe * xe / norm2 + lambda * e;
 }
 
+// bits == 1 packs the row straight into the scan layout; bits > 1 writes what the reference keeps for such an index - one byte per
+// dimension (src/binaryQuantizationFormat.ts:241-245) - to out.codes_rm, and the caller builds the tile records from that
 __global__ __launch_bounds__(256) void bbq_quantize1_kernel(const f32x4 *__restrict__ vT4, int64_t n, int32_t dim, int32_t dim4,
                                                            int64_t npad, const float *__restrict__ centroid, int32_t sim,
-                                                           double lambda, int32_t iters, BuildOut out) {
+                                                           double lambda, int32_t iters, int32_t bits, BuildOut out) {
   extern __shared__ float s_cen[];
   for (int i = threadIdx.x; i < dim4 * 4; i += 256) s_cen[i] = i < dim ? centroid[i] : 0.f;
   __syncthreads();
@@ -260,19 +263,21 @@ __global__ __launch_bounds__(256) void bbq_quantize1_kernel(const f32x4 *__restr
   }
   const double sd = sqrt(var / ddim);
   const double norm2 = sqrt(n2);
-  const double g = 0.798;  // MINIMUM_MSE_GRID[0], src/constants.ts:39
+  const double kGrid[8] = {0.798, 1.493, 2.051, 2.514, 2.916, 3.278, 3.611, 3.922};  // MINIMUM_MSE_GRID, src/constants.ts:38-47
+  const double g = kGrid[bits - 1];
+  const double pm1 = (double)((1 << bits) - 1);  // points - 1
   double iv0 = jclamp(-g * sd + mean, mn, mx), iv1 = jclamp(g * sd + mean, mn, mx);
 
-  // optimizeIntervals (:280-353), points == 2
+  // optimizeIntervals (:280-353)
   {
-    double best = valid ? loss_pass(col, npad, s_cen, dim, dim4, iv0, iv1, norm2, lambda) : 0.0;
+    double best = valid ? loss_pass(col, npad, s_cen, dim, dim4, iv0, iv1, norm2, lambda, pm1) : 0.0;
     const double scale = (1.0 - lambda) / norm2;
     bool active = valid && (fabs(scale) <= DBL_MAX);  // isFinite(scale)
     for (int it = 0; it < iters; ++it) {
       if (!__any(active)) break;
       if (active) {
         const double a = iv0, b = iv1;
-        const double step_inv = 1.0 / (b - a);  // (points - 1) / (b - a)
+        const double step_inv = pm1 / (b - a);  // (points - 1) / (b - a)
         double daa = 0, dab = 0, dbb = 0, dax = 0, dbx = 0;
         for (int i4 = 0; i4 < dim4; ++i4) {
           const f32x4 v = col[(int64_t)i4 * npad];
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(256) void bbq_quantize1_kernel(const f32x4 *__restr
             if (d < dim) {
               const double xi = (double)(float)((double)vv[k] - (double)s_cen[d]);
               const double kq = jround((jclamp(xi, a, b) - a) * step_inv);
-              const double s = kq / 1.0;
+              const double s = kq / pm1;
               daa += (1.0 - s) * (1.0 - s);
               dab += (1.0 - s) * s;
               dbb += s * s;
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(256) void bbq_quantize1_kernel(const f32x4 *__restr
           if (fabs(iv0 - a_opt) < 1e-8 && fabs(iv1 - b_opt) < 1e-8) {
             active = false;
           } else {
-            const double nl = loss_pass(col, npad, s_cen, dim, dim4, a_opt, b_opt, norm2, lambda);
+            const double nl = loss_pass(col, npad, s_cen, dim, dim4, a_opt, b_opt, norm2, lambda, pm1);
             if (nl > best) {
               active = false;
             } else {
@@ -316,6 +321,37 @@ __global__ __launch_bounds__(256) void bbq_quantize1_kernel(const f32x4 *__restr
         }
       }
     }
+  }
+
+  if (bits > 1) {
+    // final pass (:192-216) for more than one bit: assignment = round((clamp(x) - a) * stepInv), dest = min(assignment, nSteps), the
+    // component sum adds the assignment as it is
+    const double a = iv0, b = iv1;
+    const double step = (b - a) / pm1;
+    const double step_inv = step > 0 ? 1.0 / step : 0.0;
+    double qsum = 0;
+    if (valid) {
+      uint8_t *__restrict__ dst = out.codes_rm + vec * (int64_t)dim;
+      for (int i4 = 0; i4 < dim4; ++i4) {
+        const f32x4 v = col[(int64_t)i4 * npad];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int d = 4 * i4 + k;
+          if (d < dim) {
+            const double xi = (double)(float)((double)vv[k] - (double)s_cen[d]);
+            const double assignment = jround((jclamp(xi, a, b) - a) * step_inv);
+            qsum += assignment;
+            const double capped = jmin(assignment, pm1);
+            // Uint8Array store of a double: ToUint8 (NaN -> 0, otherwise modulo 256 of the truncated value)
+            dst[d] = (capped != capped) ? (uint8_t)0 : (uint8_t)(unsigned int)(long long)capped;
+          }
+        }
+      }
+      double *cm = out.corr_rm + vec * 4;
+      cm[0] = iv0; cm[1] = iv1; cm[2] = (sim == 0) ? norm2 : cdot; cm[3] = qsum;
+    }
+    return;
   }
 
   // final pass (:192-216): 1-bit threshold at the interval midpoint, packed MSB-first (packAsBinary :420-446) straight into
@@ -422,9 +458,17 @@ hipError_t launch_build_quantize1(const float *vT4, int64_t n, int32_t dim, int6
                                   double lambda, int32_t iters, uint8_t *tiles, double *exact, double *corr_rm, int32_t w16,
                                   int32_t tile_stride, int32_t layout, hipStream_t s) {
   const int dim4 = (dim + 3) / 4;
-  BuildOut o{tiles, exact, corr_rm, w16, tile_stride, layout};
+  BuildOut o{tiles, exact, corr_rm, nullptr, w16, tile_stride, layout};
   hipLaunchKernelGGL(bbq_quantize1_kernel, dim3((unsigned)(npad / 256 + (npad % 256 ? 1 : 0))), dim3(256), (size_t)dim4 * 16, s,
-                     reinterpret_cast<const f32x4 *>(vT4), n, dim, dim4, npad, centroid, sim, lambda, iters, o);
+                     reinterpret_cast<const f32x4 *>(vT4), n, dim, dim4, npad, centroid, sim, lambda, iters, 1, o);
+  return hipGetLastError();
+}
+hipError_t launch_build_quantize_bits(const float *vT4, int64_t n, int32_t dim, int64_t npad, const float *centroid, int32_t sim,
+                                      double lambda, int32_t iters, int32_t bits, uint8_t *codes_rm, double *corr_rm, hipStream_t s) {
+  const int dim4 = (dim + 3) / 4;
+  BuildOut o{nullptr, nullptr, corr_rm, codes_rm, 0, 0, 0};
+  hipLaunchKernelGGL(bbq_quantize1_kernel, dim3((unsigned)(npad / 256 + (npad % 256 ? 1 : 0))), dim3(256), (size_t)dim4 * 16, s,
+                     reinterpret_cast<const f32x4 *>(vT4), n, dim, dim4, npad, centroid, sim, lambda, iters, bits, o);
   return hipGetLastError();
 }
 hipError_t launch_build_untile(const uint8_t *tiles, int64_t n, int32_t pb, int32_t w16, int32_t tile_stride, uint8_t *codes_rm,

@@ -125,10 +125,8 @@ namespace {
 
 int make_storage(bbq_index *ix, Storage &st, const uint8_t *codes, const double *corr, int64_t n_rows, int64_t row_id_base,
                  bool check_x1) {
-  const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
-  const bool multibit = ix->store_bits > 1;
-  const int64_t pb = multibit ? ix->dim : ix->pb;  // bytes per row as the caller hands them over (multi-bit: one byte per dimension)
-  DevMem m_codes, m_corr, m_mis;
+  const int64_t pb = ix->store_bits > 1 ? ix->dim : ix->pb;  // bytes per row as the caller hands them over (multi-bit: one byte per dimension)
+  DevMem m_codes, m_corr;
   hipStream_t s = ix->aux_stream;
   if (n_rows > 0) {
     HIPCHK(m_codes.alloc((size_t)(n_rows * pb)));
@@ -136,8 +134,22 @@ int make_storage(bbq_index *ix, Storage &st, const uint8_t *codes, const double 
     HIPCHK(hipMemcpyAsync(m_codes.p, codes, (size_t)(n_rows * pb), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(m_corr.p, corr, (size_t)n_rows * 32, hipMemcpyHostToDevice, s));
   }
-  uint8_t *d_codes = m_codes.as<uint8_t>();
-  double *d_corr = m_corr.as<double>();
+  return storage_from_device_rows(ix, st, m_codes.as<uint8_t>(), m_corr.as<double>(), n_rows, row_id_base, check_x1);  // synchronises before the scratch rows go
+}
+
+}  // namespace
+
+namespace bbq {
+
+// rows already in device memory (codes in the caller's shape, corrections [n][4]) -> tile records of `st`; decides the layout of
+// the index on the way (check_x1).  Returns after the device work has completed.
+int storage_from_device_rows(bbq_index *ix, Storage &st, const uint8_t *d_codes, const double *d_corr, int64_t n_rows, int64_t row_id_base,
+                             bool check_x1) {
+  const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
+  const bool multibit = ix->store_bits > 1;
+  const int64_t pb = multibit ? ix->dim : ix->pb;
+  DevMem m_mis;
+  hipStream_t s = ix->aux_stream;
   if (check_x1) {
     // quantizedComponentSum of a 1-bit row is its popcount (src/optimizedScalarQuantizer.ts:204-209); if that
     // holds for every row the 8 bytes need not be stored or read.  Decided once per index, over all storages.
@@ -187,6 +199,10 @@ int make_storage(bbq_index *ix, Storage &st, const uint8_t *codes, const double 
   HIPCHK(hipStreamSynchronize(s));  // the scratch rows are released on return
   return BBQ_OK;
 }
+
+}  // namespace bbq
+
+namespace {
 
 // ------------------------------------------------------------------------------------------------ plan
 

@@ -172,6 +172,10 @@ struct bbq_index {
 namespace bbq {
 // frees what the index owns; the device context (streams, workspace) stays.  Call with the context mutex held.
 void destroy_unlocked(bbq_index *ix);
+// rows already in device memory (codes in the caller's shape: packed bits, or one byte per dimension for a multi-bit index;
+// corrections [n][4]) -> tile records of `st`, deciding the index's layout on the way.  Context mutex held by the caller.
+int storage_from_device_rows(bbq_index *ix, Storage &st, const uint8_t *d_codes, const double *d_corr, int64_t n_rows, int64_t row_id_base,
+                             bool check_x1);
 // every f32 score of one query on this (single-device) index, to host memory [n_rows]
 int dense_scores_host(bbq_index *ix, const uint8_t *qquant, const double *qcorr, int32_t query_bits, int32_t sim, float *out);
 // multi-device index (bbq_multi.cpp): what the entry points of a handle with ix->multi != nullptr dispatch to

@@ -37,6 +37,9 @@ hipError_t launch_build_centroid(const float *vT4, int64_t n, int32_t dim, int64
 hipError_t launch_build_quantize1(const float *vT4, int64_t n, int32_t dim, int64_t npad, const float *centroid, int32_t sim,
                                   double lambda, int32_t iters, uint8_t *tiles, double *exact, double *corr_rm, int32_t w16,
                                   int32_t tile_stride, int32_t layout, hipStream_t s);
+// indexBits > 1: unpacked codes [n][dim] (one byte per dimension) + row-major corrections [n][4], both in device memory
+hipError_t launch_build_quantize_bits(const float *vT4, int64_t n, int32_t dim, int64_t npad, const float *centroid, int32_t sim,
+                                      double lambda, int32_t iters, int32_t bits, uint8_t *codes_rm, double *corr_rm, hipStream_t s);
 hipError_t launch_build_untile(const uint8_t *tiles, int64_t n, int32_t pb, int32_t w16, int32_t tile_stride, uint8_t *codes_rm,
                                hipStream_t s);
 

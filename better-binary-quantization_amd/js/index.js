@@ -294,11 +294,11 @@ class BinaryQuantizationFormat {
     }
     const q = this.quantizer;
     let values;
-    if (this.config.indexBits === 1 && process.env.BBQ_HOST_QUANTIZER !== '1' && native.deviceCount() > 0) {
-      // quantizeVectors as HIP kernels; the device index is ready when this returns (no second upload on first search)
+    if (process.env.BBQ_HOST_QUANTIZER !== '1' && native.deviceCount() > 0) {
+      // quantizeVectors as HIP kernels (any indexBits); the device index is ready when this returns (no second upload on first search)
       const r = native.indexBuild(flatten(vectors, dim), vectors.length, dim, simOrdinal(q.similarityFunction), q.lambda, q.iters,
-        Number(process.env.BBQ_DEVICE || 0));
-      values = new BinarizedByteVectorValuesImpl(r.codes, r.corr, r.centroid, 1, vectors.length);
+        Number(process.env.BBQ_DEVICE || 0), this.config.indexBits);
+      values = new BinarizedByteVectorValuesImpl(r.codes, r.corr, r.centroid, this.config.indexBits, vectors.length);
       if (shardDevices(vectors.length).length > 1) native.indexDestroy(r.handle);  // the sharded index is created from the rows on first search
       else values._device = r.handle;
     } else {

@@ -200,24 +200,25 @@ static napi_value IndexCreateMulti(napi_env env, napi_callback_info info) {
   return ext;
 }
 
-/* indexBuild(flat Float32Array, n, dim, sim, lambda, iters, device) -> {handle, codes, corr, centroid}
- * quantizeVectors on the device (bbq_index_build); the handle is the ready device index */
+/* indexBuild(flat Float32Array, n, dim, sim, lambda, iters, device, indexBits) -> {handle, codes, corr, centroid}
+ * quantizeVectors on the device (bbq_index_build_bits); the handle is the ready device index */
 static napi_value IndexBuild(napi_env env, napi_callback_info info) {
-  napi_value a[7];
-  if (!get_args(env, info, 7, a)) return NULL;
+  napi_value a[8];
+  if (!get_args(env, info, 8, a)) return NULL;
   void *vec; size_t vlen;
-  int64_t n, dim, sim, iters, dev; double lambda;
+  int64_t n, dim, sim, iters, dev, ib; double lambda;
   if (!get_typed(env, a[0], napi_float32_array, &vec, &vlen) || !get_i64(env, a[1], &n) || !get_i64(env, a[2], &dim) ||
-      !get_i64(env, a[3], &sim) || !get_f64(env, a[4], &lambda) || !get_i64(env, a[5], &iters) || !get_i64(env, a[6], &dev)) return NULL;
+      !get_i64(env, a[3], &sim) || !get_f64(env, a[4], &lambda) || !get_i64(env, a[5], &iters) || !get_i64(env, a[6], &dev) ||
+      !get_i64(env, a[7], &ib)) return NULL;
   if (n < 0 || dim <= 0 || (size_t)(n * dim) != vlen) { napi_throw_range_error(env, NULL, "bbq_napi: n*dim does not match the array"); return NULL; }
   void *codes, *corr, *cen;
-  napi_value tcodes = new_typed(env, napi_uint8_array, (size_t)n * (size_t)((dim + 7) / 8), 1, &codes);
+  napi_value tcodes = new_typed(env, napi_uint8_array, (size_t)n * (size_t)(ib == 1 ? (dim + 7) / 8 : dim), 1, &codes);
   napi_value tcorr = new_typed(env, napi_float64_array, (size_t)n * 4, 8, &corr);
   napi_value tcen = new_typed(env, napi_float32_array, (size_t)dim, 4, &cen);
   if (!tcodes || !tcorr || !tcen) { napi_throw_error(env, NULL, "bbq_napi: allocation failed"); return NULL; }
   bbq_index **box = (bbq_index **)calloc(1, sizeof *box);
-  int rc = bbq_index_build((const float *)vec, n, (int32_t)dim, (int32_t)sim, lambda, (int32_t)iters, (int32_t)dev, box, (float *)cen,
-                           (uint8_t *)codes, (double *)corr, NULL, NULL);
+  int rc = bbq_index_build_bits((const float *)vec, n, (int32_t)dim, (int32_t)sim, (int32_t)ib, lambda, (int32_t)iters, (int32_t)dev, box,
+                                (float *)cen, (uint8_t *)codes, (double *)corr, NULL, NULL);
   if (rc != BBQ_OK) { free(box); return throw_bbq(env, rc); }
   napi_value ext, o;
   if (napi_create_external(env, box, finalize_index, NULL, &ext) != napi_ok) { bbq_index_destroy(*box); free(box); napi_throw_error(env, NULL, "bbq_napi: external"); return NULL; }

@@ -85,10 +85,11 @@ class BinaryQuantizationFormat:
             if len(v) != dim:
                 raise Exception("向量 %d 维度 %d 与第一个向量维度 %d 不匹配" % (i, len(v), dim))
         try:
-            if self._config["indexBits"] == 1 and capi.device_count() > 0:
+            if capi.device_count() > 0:
                 # quantizeVectors as HIP kernels; the device index is ready when this returns
-                ix, codes, corr, cen = capi.Index.build(np.asarray(vectors, np.float32), capi.SIMS[self._sim], self._lambda, self._iters)
-                values = BinarizedByteVectorValues(codes, corr, cen, 1)
+                ix, codes, corr, cen = capi.Index.build(np.asarray(vectors, np.float32), capi.SIMS[self._sim], self._lambda, self._iters,
+                                                        index_bits=self._config["indexBits"])
+                values = BinarizedByteVectorValues(codes, corr, cen, self._config["indexBits"])
                 values._device_index = ix
             else:
                 codes, corr, cen = capi.quantize_vectors(np.asarray(vectors, np.float32), capi.SIMS[self._sim],

@@ -16,7 +16,7 @@ SIMS = {"EUCLIDEAN": 0, "COSINE": 1, "MAXIMUM_INNER_PRODUCT": 2}
 
 # every symbol include/bbq.h declares (tests/test_capi_symbols.py checks the library exports all of them)
 SYMBOLS = [
-    "bbq_last_error", "bbq_abi_version", "bbq_device_count", "bbq_index_create", "bbq_index_create_shard", "bbq_index_create_multi", "bbq_index_shards", "bbq_index_build",
+    "bbq_last_error", "bbq_abi_version", "bbq_device_count", "bbq_index_create", "bbq_index_create_shard", "bbq_index_create_multi", "bbq_index_shards", "bbq_index_build", "bbq_index_build_bits",
     "bbq_index_destroy", "bbq_index_size", "bbq_index_dimension", "bbq_index_bytes_per_row", "bbq_index_bits", "bbq_search",
     "bbq_search_batch", "bbq_score_rows", "bbq_shard_scan", "bbq_shard_list_cap", "bbq_replay", "bbq_replay_batch",
     "bbq_quantize_vectors", "bbq_quantize_query", "bbq_quantize_query_vector", "bbq_centroid_dp", "bbq_get_stats",
@@ -61,6 +61,7 @@ def lib():
     L.bbq_index_shards.argtypes = [vp]
     L.bbq_index_shards.restype = i32
     L.bbq_index_build.argtypes = [vp, i64, i32, i32, dbl, i32, i32, C.POINTER(vp), vp, vp, vp, vp, vp]
+    L.bbq_index_build_bits.argtypes = [vp, i64, i32, i32, i32, dbl, i32, i32, C.POINTER(vp), vp, vp, vp, vp, vp]
     L.bbq_index_destroy.argtypes = [vp]
     L.bbq_index_destroy.restype = None
     L.bbq_index_size.argtypes = [vp]
@@ -206,20 +207,20 @@ class Index:
         return lib().bbq_index_shards(self._h)
 
     @classmethod
-    def build(cls, vectors, sim, lam=0.1, iters=5, device=0, want_host_copy=True):
-        """quantizeVectors on the device (bbq_index_build): returns (index, codes, corr, centroid); codes/corr are None
+    def build(cls, vectors, sim, lam=0.1, iters=5, device=0, want_host_copy=True, index_bits=1):
+        """quantizeVectors on the device (bbq_index_build_bits): returns (index, codes, corr, centroid); codes/corr are None
         unless want_host_copy"""
         v = np.ascontiguousarray(vectors, np.float32)
         if v.ndim != 2:
             raise BBQError(ERR_INVALID_ARG, "vectors must be [n, dim]")
         n, dim = v.shape
         cen = np.zeros(dim, np.float32)
-        codes = np.zeros((n, (dim + 7) // 8), np.uint8) if want_host_copy else None
+        codes = np.zeros((n, (dim + 7) // 8 if index_bits == 1 else dim), np.uint8) if want_host_copy else None
         corr = np.zeros((n, 4), np.float64) if want_host_copy else None
         h = C.c_void_p()
-        _chk(lib().bbq_index_build(_ptr(v), n, dim, sim, lam, iters, device, C.byref(h), _ptr(cen), _ptr(codes), _ptr(corr), None, None))
+        _chk(lib().bbq_index_build_bits(_ptr(v), n, dim, sim, index_bits, lam, iters, device, C.byref(h), _ptr(cen), _ptr(codes), _ptr(corr), None, None))
         self = cls.__new__(cls)
-        self._h, self.dim, self.n, self.index_bits = h, dim, n, 1
+        self._h, self.dim, self.n, self.index_bits = h, dim, n, index_bits
         return self, codes, corr, cen
 
     def save(self, path_prefix, centroid, sim):

@@ -86,8 +86,8 @@ int bbq_index_create(const uint8_t *codes, const double *corr, int64_t n_rows, i
 
 /* quantizeVectors ON THE DEVICE and the index built in place: BinaryQuantizationFormat.quantizeVectors
  * (src/binaryQuantizationFormat.ts:165-263: normalizeVector for COSINE, NaN/Infinity validation, computeCentroid,
- * scalarQuantize, packAsBinary) for indexBits == 1, bit-exact with the TypeScript path, followed by what
- * bbq_index_create does.  vectors [n*dim] row-major host floats.
+ * scalarQuantize, packAsBinary) for indexBits == 1 (bbq_index_build_bits: any indexBits), bit-exact with the TypeScript path,
+ * followed by what bbq_index_create does.  vectors [n*dim] row-major host floats.
  *   centroid [dim]            (host, required)  the f32 centroid; centroid_dp is derived from it
  *   codes [n*ceil(dim/8)], corr [n*4]  (host, each may be NULL) what quantizeVectors returns, for hosts that keep
  *                             the BinarizedByteVectorValues accessors (vectorValue / getCorrectiveTerms)
@@ -95,6 +95,12 @@ int bbq_index_create(const uint8_t *codes, const double *corr, int64_t n_rows, i
 int bbq_index_build(const float *vectors, int64_t n, int32_t dim, int32_t sim, double lambda, int32_t iters,
                     int32_t device, bbq_index **out, float *centroid, uint8_t *codes, double *corr,
                     int64_t *bad_row, int32_t *bad_col);
+
+/* The same for any indexBits (1..8): codes [n*ceil(dim/8)] for index_bits == 1, [n*dim] (one byte per dimension,
+ * src/binaryQuantizationFormat.ts:241-245) otherwise. */
+int bbq_index_build_bits(const float *vectors, int64_t n, int32_t dim, int32_t sim, int32_t index_bits, double lambda, int32_t iters,
+                         int32_t device, bbq_index **out, float *centroid, uint8_t *codes, double *corr,
+                         int64_t *bad_row, int32_t *bad_col);
 
 /* Row-sharded variant for one-process-per-GPU deployments (new; the reference has no distribution).
  *   row_base     global row id of this shard's row 0 (shards are contiguous, ascending)
