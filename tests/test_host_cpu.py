@@ -186,3 +186,32 @@ def test_quantize_queries_batch_equals_one_by_one(sim, qb):
     assert e.value.code == e1.value.code and str(e.value) == str(e1.value)
     with pytest.raises(B.BBQError):
         B.quantize_queries(qs[:, :10], cen, sim, qb)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_heap_order_is_the_descending_sort_when_the_top_scores_differ(seed):
+    """the fact the device-side answers rest on: if the k+1 largest f32 scores are pairwise different, the
+    reference's heap returns the k best rows sorted by score, whatever the arrival order and however many ties lie below;
+    checked here with the product's replay of the reference heap (bbq_replay) and with the oracle's"""
+    rng = np.random.default_rng(900 + seed)
+    n = int(rng.choice([5, 64, 1000, 20000]))
+    k = int(rng.choice([1, 3, 10, 100]))
+    k2 = min(k, n)
+    # few distinct values below the top, strictly separated values on top, shuffled arrival order
+    s = rng.integers(0, 7, n).astype(np.float32) * np.float32(0.125)
+    top = rng.choice(n, min(k2 + 1, n), replace=False)
+    s[top] = np.float32(10.0) + np.arange(len(top), dtype=np.float32) * np.float32(0.5)
+    want = np.argsort(-s, kind="stable")[:k2]
+    ent = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | s.view(np.uint32).astype(np.uint64)
+    idx, sc = B.replay([ent], n, k)
+    np.testing.assert_array_equal(idx, want)
+    np.testing.assert_array_equal(sc, s[want])
+    oi, osc = O.heap_topk(s, k)
+    np.testing.assert_array_equal(oi, want)
+    # and the converse matters too: with a tie inside the answer the heap's history decides, so the sort is NOT generally the answer
+    if n >= 64 and k2 >= 3:
+        t = s.copy()
+        t[top[:2]] = t[top[0]]
+        oi2, _ = O.heap_topk(t, k)
+        idx2, _ = B.replay([(np.arange(n, dtype=np.uint64) << np.uint64(32)) | t.view(np.uint32).astype(np.uint64)], n, k)
+        np.testing.assert_array_equal(idx2, oi2)     # the replay follows the reference either way

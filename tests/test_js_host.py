@@ -51,3 +51,14 @@ def test_js_quickstart_example():
                        timeout=300)
     print(r.stdout[-2000:])
     assert r.returncode == 0, r.stdout[-4000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_js_multi_gpu_and_multibit_example():
+    """examples/multi_gpu_and_multibit.js with two shards on the one GPU"""
+    r = subprocess.run(["node", os.path.join(ROOT, "examples", "multi_gpu_and_multibit.js")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=300, env=dict(os.environ, BBQ_DEVICES="0,0"))
+    print(r.stdout[-2000:])
+    assert r.returncode == 0, r.stdout[-4000:]
+    assert "shards: 2" in r.stdout and "batch agrees: true" in r.stdout and "bytes per row on the device: 68" in r.stdout
