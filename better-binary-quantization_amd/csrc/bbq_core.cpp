@@ -411,7 +411,18 @@ void fill_query(const bbq_index *ix, uint8_t *planes_dst, QueryParams *pp, const
                 int one_bit, int sim) {
   memset(planes_dst, 0, (size_t)query_data_bytes(ix, planes));
   if (ix->store_bits == 1) {
-    for (int d = 0; d < ix->dim; ++d) {
+    // eight dimensions (one byte of every plane) at a time: bit p of the eight query bytes, gathered MSB-first by one multiply -
+    // source bit 8i (dimension 8*byte + i) goes to bit 63 - i of the product, no two partial products share a position
+    const int full = ix->dim >> 3;
+    for (int byte = 0; byte < full; ++byte) {
+      uint64_t x;
+      memcpy(&x, q + (size_t)byte * 8, 8);
+      if (!x) continue;
+      const int j = byte >> 4, b = byte & 15;
+      for (int p = 0; p < planes; ++p)
+        planes_dst[((size_t)j * planes + p) * 16 + b] = (uint8_t)((((x >> p) & 0x0101010101010101ull) * 0x8040201008040201ull) >> 56);
+    }
+    for (int d = full * 8; d < ix->dim; ++d) {  // the last, partial byte
       const uint8_t v = q[d];
       if (!v) continue;
       const int byte = d >> 3, j = byte >> 4, b = byte & 15;
