@@ -29,6 +29,11 @@ export declare class BinaryQuantizedScorer {
   computeQuantizedScore(quantizedQuery: Uint8Array, queryCorrections: QuantizationResult, targetVectors: BinarizedByteVectorValues, targetOrd: number, queryBits: number, originalQueryVector?: Float32Array): QuantizedScoreResult;
   computeBatchQuantizedScores(quantizedQuery: Uint8Array, queryCorrections: QuantizationResult, targetVectors: BinarizedByteVectorValues,
     targetOrds: number[], queryBits: number, originalQueryVector?: Float32Array): QuantizedScoreResult[];
+  /** src/binaryQuantizedScorer.ts:429-617 */
+  computeOriginalScore(originalQuery: Float32Array, targetVector: Float32Array, similarityFunction: VectorSimilarityFunction): number;
+  compareScores(originalScore: number, quantizedScore: number): { difference: number; relativeError: number; correlation: number };
+  computeQuantizationAccuracy(originalScores: number[], quantizedScores: number[]): { meanError: number; maxError: number; minError: number; stdError: number; correlation: number };
+  getSimilarityFunction(): VectorSimilarityFunction;
 }
 export declare class BinaryQuantizationFormat {
   constructor(config: BinaryQuantizationConfig);
@@ -43,6 +48,8 @@ export declare class BinaryQuantizationFormat {
   /** extension: <prefix>.veb (device tile records) + <prefix>.vemb (MetadataFormat + centroid) */
   saveIndex(quantizedVectors: BinarizedByteVectorValues, pathPrefix: string): void;
   loadIndex(pathPrefix: string): BinarizedByteVectorValues;
+  /** src/binaryQuantizationFormat.ts:420-476: every query against vector 0, quantized vs fp32 score */
+  computeQuantizationAccuracy(originalVectors: Float32Array[], queryVectors: Float32Array[]): { meanError: number; maxError: number; minError: number; stdError: number; correlation: number };
   getConfig(): BinaryQuantizationConfig;
   getQuantizer(): OptimizedScalarQuantizer;
   getScorer(): BinaryQuantizedScorer;
@@ -112,5 +119,6 @@ export declare function copyVector(vector: Float32Array): Float32Array;
 export declare function computeVectorMagnitude(vector: Float32Array): number;
 export declare function createRandomVector(dimension: number, min?: number, max?: number): Float32Array;
 export declare function createZeroVector(dimension: number): Float32Array;
-/** out of scope (accuracy statistics): throws */
-export declare function computeAccuracy(originalVectors: Float32Array[], queryVectors: Float32Array[], similarityFunction?: VectorSimilarityFunction): never;
+export interface QuantizationAccuracy { meanError: number; maxError: number; minError: number; stdError: number; correlation: number; }
+/** src/index.ts:120-134: computeQuantizationAccuracy of a format with lambda 0.1 / 5 iterations */
+export declare function computeAccuracy(originalVectors: Float32Array[], queryVectors: Float32Array[], similarityFunction?: VectorSimilarityFunction): QuantizationAccuracy;

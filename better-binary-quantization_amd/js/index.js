@@ -251,6 +251,59 @@ class BinaryQuantizedScorer {
       return { score: score, bitDotProduct: r.qcDist[ord - lo], corrections: { query: queryCorrections, index: ic } };
     });
   }
+  /** computeOriginalScore(originalQuery, targetVector, similarityFunction): computeSimilarity on the fp32 vectors (:429-447) */
+  computeOriginalScore(originalQuery, targetVector, similarityFunction) {
+    if (similarityFunction !== VectorSimilarityFunction.EUCLIDEAN && similarityFunction !== VectorSimilarityFunction.COSINE &&
+        similarityFunction !== VectorSimilarityFunction.MAXIMUM_INNER_PRODUCT) throw new Error('不支持的相似性函数: ' + similarityFunction);
+    return computeSimilarity(originalQuery, targetVector, similarityFunction);
+  }
+
+  /** compareScores(originalScore, quantizedScore) -> {difference, relativeError, correlation}  (:455-477, correlation of two single values :485-513) */
+  compareScores(originalScore, quantizedScore) {
+    const difference = Math.abs(originalScore - quantizedScore);
+    const relativeError = originalScore === 0 ? (quantizedScore === 0 ? 0 : Infinity) : difference / Math.abs(originalScore);
+    // the reference "correlates" two single values: 1 when they are equal, 0 when exactly one is zero, otherwise a quotient of
+    // deviations from themselves - 0 for finite values (0 / 0 is caught), NaN when a value is not finite (x - x is NaN then)
+    let correlation = 0;
+    if (originalScore === quantizedScore) correlation = 1;
+    else if (originalScore !== 0 && quantizedScore !== 0) {
+      const da = originalScore - originalScore, db = quantizedScore - quantizedScore, den = Math.abs(da) * Math.abs(db);
+      correlation = den === 0 ? 0 : (da * db) / den;
+    }
+    return { difference: difference, relativeError: relativeError, correlation: correlation };
+  }
+
+  /** computeQuantizationAccuracy(originalScores, quantizedScores) -> {meanError, maxError, minError, stdError, correlation (Pearson)}  (:524-617) */
+  computeQuantizationAccuracy(originalScores, quantizedScores) {
+    if (originalScores.length !== quantizedScores.length) throw new Error('原始分数和量化分数数组长度不匹配');
+    const errors = [];
+    let sumError = 0, maxError = 0, minError = Infinity;
+    for (let i = 0; i < originalScores.length; i++) {
+      const orig = originalScores[i], quant = quantizedScores[i];
+      if (orig !== undefined && quant !== undefined) {
+        const error = Math.abs(orig - quant);
+        errors.push(error);
+        sumError += error;
+        maxError = Math.max(maxError, error);
+        minError = Math.min(minError, error);
+      }
+    }
+    const meanError = sumError / errors.length;
+    let sq = 0;
+    for (const e of errors) { const d = e - meanError; sq += d * d; }
+    const stdError = Math.sqrt(sq / errors.length);
+    const n = originalScores.length;
+    let sumX = 0, sumY = 0, sumXY = 0, sumX2 = 0, sumY2 = 0;
+    for (let i = 0; i < n; i++) {
+      const xv = originalScores[i], yv = quantizedScores[i];
+      if (xv !== undefined && yv !== undefined) { sumX += xv; sumY += yv; sumXY += xv * yv; sumX2 += xv * xv; sumY2 += yv * yv; }
+    }
+    const numerator = n * sumXY - sumX * sumY;
+    const denominator = Math.sqrt((n * sumX2 - sumX * sumX) * (n * sumY2 - sumY * sumY));
+    return { meanError: meanError, maxError: maxError, minError: minError, stdError: stdError, correlation: denominator === 0 ? 0 : numerator / denominator };
+  }
+
+  getSimilarityFunction() { return this.similarityFunction; }
 }
 
 /** rows are unpacked bytes and the reference's batch scorer throws on them (dimension 1 is the one width where it does not) */
@@ -421,6 +474,25 @@ class BinaryQuantizationFormat {
     values._rowBytes = Math.ceil(r.dim / 8);
     values._device = r.handle;
     return values;
+  }
+
+  /**
+   * computeQuantizationAccuracy(originalVectors, queryVectors) -> {meanError, maxError, minError, stdError, correlation}  (:420-476).
+   * As in the reference every query is scored against vector 0 only: quantized (the single-row scorer, no original query passed, so a
+   * 4-bit query's centroid term is 0) against computeSimilarity on the fp32 vectors.
+   */
+  computeQuantizationAccuracy(originalVectors, queryVectors) {
+    if (originalVectors.length === 0) throw new Error('原始向量集合不能为空');
+    if (queryVectors.length === 0) throw new Error('查询向量集合不能为空');
+    if (originalVectors.length !== queryVectors.length) throw new Error('原始向量集合和查询向量集合长度不匹配');
+    const quantizedVectors = this.quantizeVectors(originalVectors).quantizedVectors;
+    const originalScores = [], quantizedScores = [];
+    for (const queryVector of queryVectors) {
+      const q = this.quantizeQueryVector(queryVector, quantizedVectors.getCentroid());
+      quantizedScores.push(this.scorer.computeQuantizedScore(q.quantizedQuery, q.queryCorrections, quantizedVectors, 0, this.config.queryBits).score);
+      originalScores.push(this.scorer.computeOriginalScore(queryVector, originalVectors[0], this.config.quantizer.similarityFunction));
+    }
+    return this.scorer.computeQuantizationAccuracy(originalScores, quantizedScores);
   }
 
   getConfig() { return this.config; }
@@ -693,13 +765,12 @@ function quickSearch(queryVector, targetVectors, k, similarityFunction) {
   }
 }
 
-/**
- * computeAccuracy (src/index.ts:118-134) drives computeQuantizationAccuracy, the reference's accuracy-statistics report: outside the
- * scan path this package replaces (SURVEY section 2 / DESIGN.md "Out of scope").  Exported so that the import resolves; calling it
- * says so instead of failing with "not a function".
- */
-function computeAccuracy() {
-  throw new Error('computeAccuracy is not part of the MI355X search-path build (accuracy statistics are out of scope): use getOversampledTopKWithHeap / a brute force for recall');
+/** computeAccuracy(originalVectors, queryVectors, similarityFunction = COSINE): the accuracy report of a lambda-0.1 / 5-iteration format (src/index.ts:120-134) */
+function computeAccuracy(originalVectors, queryVectors, similarityFunction) {
+  const format = new BinaryQuantizationFormat({
+    quantizer: { similarityFunction: similarityFunction === undefined ? VectorSimilarityFunction.COSINE : similarityFunction, lambda: 0.1, iters: 5 },
+  });
+  return format.computeQuantizationAccuracy(originalVectors, queryVectors);
 }
 
 module.exports = Object.assign({}, require('./helpers'), {

@@ -338,6 +338,32 @@ function runApiBehaviour() {
     ['centerVector', function () { VO.centerVector(va, new Float32Array(2)); }]].forEach(function (p) {
     try { p[1](); out.helpers.errors[p[0]] = null; } catch (e) { out.helpers.errors[p[0]] = String(e.message); }
   });
+  // computeAccuracy (src/index.ts:120-134) = computeQuantizationAccuracy of a format with lambda 0.1 / iters 5
+  // (src/binaryQuantizationFormat.ts:420-476, src/binaryQuantizedScorer.ts:429-617): the statistics, the scorer's small helpers, the errors
+  out.accuracy = { n: 40, dim: 32, base_seed: 910, query_seed: 911, results: {}, scorer: {}, errors: {} };
+  const accBase = randMatrix(910, 40, 32), accQueries = randMatrix(911, 40, 32);
+  SIMS.forEach(function (sim) {
+    [[4, 1], [1, 1], [4, 2]].forEach(function (qi) {
+      const fmt = new BinaryQuantizationFormat({ queryBits: qi[0], indexBits: qi[1], quantizer: { similarityFunction: sim, lambda: 0.1, iters: 5 } });
+      out.accuracy.results[sim + '_qb' + qi[0] + '_ib' + qi[1]] = fmt.computeQuantizationAccuracy(accBase, accQueries);
+    });
+  });
+  const sc = F().getScorer();
+  out.accuracy.scorer.compareScores = [[0.5, 0.4], [0, 0], [0, 1], [2, 2], [-1, 3]].map(function (p) {
+    const r = sc.compareScores(p[0], p[1]);
+    return { a: p[0], b: p[1], difference: r.difference, relativeError: String(r.relativeError), correlation: r.correlation };
+  });
+  out.accuracy.scorer.computeOriginalScore = SIMS.map(function (sim) { return sc.computeOriginalScore(accQueries[0], accBase[0], sim); });
+  out.accuracy.scorer.computeQuantizationAccuracy = sc.computeQuantizationAccuracy([0.1, 0.5, 0.9, 0.3], [0.12, 0.45, 0.97, 0.3]);
+  out.accuracy.scorer.constantScores = sc.computeQuantizationAccuracy([0.5, 0.5], [0.4, 0.6]);
+  out.accuracy.scorer.getSimilarityFunction = sc.getSimilarityFunction();
+  [['empty originals', function () { F().computeQuantizationAccuracy([], accQueries); }],
+    ['empty queries', function () { F().computeQuantizationAccuracy(accBase, []); }],
+    ['length mismatch', function () { F().computeQuantizationAccuracy(accBase, accQueries.slice(0, 3)); }],
+    ['scores length mismatch', function () { sc.computeQuantizationAccuracy([1, 2], [1]); }],
+    ['bad similarity', function () { sc.computeOriginalScore(accQueries[0], accBase[0], 'NOPE'); }]].forEach(function (p) {
+    try { p[1](); out.accuracy.errors[p[0]] = null; } catch (e) { out.accuracy.errors[p[0]] = String(e.message); }
+  });
   fs.writeFileSync(path.join(OUT, 'api_behaviour.json'), JSON.stringify(out, null, 1));
   console.log('api_behaviour ok');
 }

@@ -185,9 +185,42 @@ T.check(packed[0] === 0xAA, 'packAsBinary');
     try { bbq[name](va, new Float32Array(2)); } catch (e) { msg = String(e.message); }
     T.check(msg === h.errors[name], 'helper ' + name + ' dimension error: ' + msg);
   });
-  let threw = false;
-  try { bbq.computeAccuracy([], []); } catch (e) { threw = /out of scope/.test(e.message); }
-  T.check(threw, 'computeAccuracy says it is out of scope');
+})();
+// --- computeAccuracy / computeQuantizationAccuracy and the scorer's score-comparison helpers (src/index.ts:120-134,
+//     src/binaryQuantizationFormat.ts:420-476, src/binaryQuantizedScorer.ts:429-617) against what the reference returned
+(function () {
+  const A = api.accuracy, base = T.randMatrix(A.base_seed, A.n, A.dim), queries = T.randMatrix(A.query_seed, A.n, A.dim);
+  const same = function (got, want, label) { T.check(JSON.stringify(got) === JSON.stringify(want), 'accuracy ' + label + ': ' + JSON.stringify(got) + ' vs ' + JSON.stringify(want)); };
+  Object.keys(A.results).forEach(function (key) {
+    const m = /^(.*)_qb(\d)_ib(\d)$/.exec(key);
+    const fmt = new bbq.BinaryQuantizationFormat({ queryBits: Number(m[2]), indexBits: Number(m[3]), quantizer: { similarityFunction: m[1], lambda: 0.1, iters: 5 } });
+    same(fmt.computeQuantizationAccuracy(base, queries), A.results[key], key);
+    if (m[2] === '4' && m[3] === '1') same(bbq.computeAccuracy(base, queries, m[1]), A.results[key], 'computeAccuracy ' + m[1]);
+  });
+  same(bbq.computeAccuracy(base, queries), A.results.COSINE_qb4_ib1, 'computeAccuracy default similarity');
+  const sc = new bbq.BinaryQuantizedScorer('COSINE');
+  same(A.scorer.compareScores.map(function (p) {
+    const r = sc.compareScores(p.a, p.b);
+    return { a: p.a, b: p.b, difference: r.difference, relativeError: String(r.relativeError), correlation: r.correlation };
+  }), A.scorer.compareScores, 'compareScores');
+  T.check(Number.isNaN(sc.compareScores(Infinity, 1).correlation) && sc.compareScores(NaN, 0).correlation === 0, 'compareScores non-finite corners');
+  same(['EUCLIDEAN', 'COSINE', 'MAXIMUM_INNER_PRODUCT'].map(function (sim) { return sc.computeOriginalScore(queries[0], base[0], sim); }), A.scorer.computeOriginalScore, 'computeOriginalScore');
+  same(sc.computeQuantizationAccuracy([0.1, 0.5, 0.9, 0.3], [0.12, 0.45, 0.97, 0.3]), A.scorer.computeQuantizationAccuracy, 'scorer.computeQuantizationAccuracy');
+  same(sc.computeQuantizationAccuracy([0.5, 0.5], [0.4, 0.6]), A.scorer.constantScores, 'constant scores');
+  same(sc.getSimilarityFunction(), A.scorer.getSimilarityFunction, 'getSimilarityFunction');
+  const F = function () { return new bbq.BinaryQuantizationFormat({ quantizer: { similarityFunction: 'COSINE', lambda: 0.1, iters: 5 } }); };
+  const errs = {
+    'empty originals': function () { F().computeQuantizationAccuracy([], queries); },
+    'empty queries': function () { F().computeQuantizationAccuracy(base, []); },
+    'length mismatch': function () { F().computeQuantizationAccuracy(base, queries.slice(0, 3)); },
+    'scores length mismatch': function () { sc.computeQuantizationAccuracy([1, 2], [1]); },
+    'bad similarity': function () { sc.computeOriginalScore(queries[0], base[0], 'NOPE'); },
+  };
+  Object.keys(A.errors).forEach(function (name) {
+    let msg = null;
+    try { errs[name](); } catch (e) { msg = String(e.message); }
+    T.check(msg === A.errors[name], 'accuracy error "' + name + '": ' + msg);
+  });
 })();
 
 T.finish('js cpu_checks');

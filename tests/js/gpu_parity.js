@@ -159,4 +159,15 @@ T.goldenNames().filter(function (n) { return /^rerank_/.test(n); }).forEach(func
 })();
 
 T.check(warnings > 0, 'multi-bit indexes warn like the reference fallback');
+// --- computeAccuracy with the device-built index (src/index.ts:120-134): the reference's statistics, bit for bit
+(function () {
+  const A = T.loadGolden('api_behaviour').accuracy, base = T.randMatrix(A.base_seed, A.n, A.dim), queries = T.randMatrix(A.query_seed, A.n, A.dim);
+  Object.keys(A.results).forEach(function (key) {
+    const m = /^(.*)_qb(\d)_ib(\d)$/.exec(key);
+    const fmt = new bbq.BinaryQuantizationFormat({ queryBits: Number(m[2]), indexBits: Number(m[3]), quantizer: { similarityFunction: m[1], lambda: 0.1, iters: 5 } });
+    T.check(JSON.stringify(fmt.computeQuantizationAccuracy(base, queries)) === JSON.stringify(A.results[key]), 'computeQuantizationAccuracy ' + key);
+  });
+  T.check(JSON.stringify(bbq.computeAccuracy(base, queries, 'EUCLIDEAN')) === JSON.stringify(A.results.EUCLIDEAN_qb4_ib1), 'computeAccuracy EUCLIDEAN');
+})();
+
 T.finish('js gpu_parity');
