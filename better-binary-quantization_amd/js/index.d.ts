@@ -21,7 +21,16 @@ export interface QuantizedScoreResult { score: number; bitDotProduct: number; co
 export declare class OptimizedScalarQuantizer {
   constructor(config: QuantizerConfig);
   scalarQuantize(vector: Float32Array, destination: Uint8Array, bits: number, centroid: Float32Array): QuantizationResult;
+  multiScalarQuantize(vector: Float32Array, destinations: Uint8Array[], bits: number[], centroid: Float32Array): QuantizationResult[];
   static packAsBinary(vector: Uint8Array, packed: Uint8Array): void;
+  static discretize(value: number, bucket: number): number;
+  /** one byte per bit: quantQueryByte.length === q.length * 4 */
+  static transposeHalfByte(q: Uint8Array, quantQueryByte: Uint8Array): void;
+  static transposeHalfByteOptimized(q: Uint8Array, quantQueryByte: Uint8Array, useCache?: boolean): void;
+  /** packed planes: quantQueryByte.length === ceil(q.length / 8) * 4 */
+  static transposeHalfByteFast(q: Uint8Array, quantQueryByte: Uint8Array): void;
+  static clearTransposeCache(): void;
+  static getTransposeCacheStats(): { size: number; hitRate: number };
 }
 export declare class BinaryQuantizedScorer {
   constructor(similarityFunction: VectorSimilarityFunction);

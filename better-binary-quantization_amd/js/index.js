@@ -146,6 +146,8 @@ function flatten(vectors, dim) {
 }
 
 /** the quantizer handle the reference returns as `queryQuantizer` (OptimizedScalarQuantizer) */
+const transposeCache = { map: new WeakMap(), hits: 0, misses: 0 };
+
 class OptimizedScalarQuantizer {
   constructor(config) {
     this.lambda = (config.lambda !== undefined && config.lambda !== null) ? config.lambda : DEFAULT_LAMBDA;
@@ -166,6 +168,62 @@ class OptimizedScalarQuantizer {
     const r = native.quantizeQuery(Float32Array.from(vector), centroid, sim, bits, this.lambda, this.iters, false);
     destination.set(r.quantizedQuery);
     return corrObject(r.corrections, 0);
+  }
+  /** multiScalarQuantize(vector, destinations, bits[], centroid): one scalarQuantize per (destination, bits) pair, src/optimizedScalarQuantizer.ts:67-93 */
+  multiScalarQuantize(vector, destinations, bits, centroid) {
+    if (destinations.length !== bits.length) throw new Error('目标数组和位数数组长度不匹配');
+    const results = [];
+    for (let i = 0; i < destinations.length; i++) {
+      if (destinations[i] && bits[i] !== undefined) results.push(this.scalarQuantize(vector, destinations[i], bits[i], centroid));
+    }
+    return results;
+  }
+  /** discretize(value, bucket): value rounded up to a multiple of bucket, :460-463 */
+  static discretize(value, bucket) { return Math.floor((value + (bucket - 1)) / bucket) * bucket; }
+  /**
+   * transposeHalfByte(q, quantQueryByte): the four bit-planes of a 4-bit query, ONE BYTE PER BIT (plane p of dimension i at
+   * i + p * q.length), :476-517.  (The device keeps the planes packed eight dimensions to a byte: bbq_core.cpp fill_query.)
+   */
+  static transposeHalfByte(q, quantQueryByte) {
+    if (!q || !quantQueryByte) throw new Error('输入数组不能为空');
+    const n = q.length;
+    if (quantQueryByte.length !== n * 4) throw new Error('转置数组长度不正确，期望' + n * 4 + '，实际' + quantQueryByte.length);
+    quantQueryByte.fill(0);
+    for (let i = 0; i < n; i++) {
+      const v = q[i];
+      if (v === undefined || v < 0 || v > 15) throw new Error('4位量化值必须在0-15之间');
+      for (let p = 0; p < 4; p++) quantQueryByte[i + p * n] = (v >> p) & 1;
+    }
+  }
+  /** transposeHalfByteOptimized(q, quantQueryByte, useCache = true): the same through a cache keyed by the query ARRAY (identity), :528-552 */
+  static transposeHalfByteOptimized(q, quantQueryByte, useCache) {
+    const cache = useCache === undefined ? true : useCache;
+    if (cache) {
+      const hit = transposeCache.map.get(q);
+      if (hit) { transposeCache.hits++; quantQueryByte.set(hit); return; }
+      transposeCache.misses++;
+    }
+    OptimizedScalarQuantizer.transposeHalfByte(q, quantQueryByte);
+    if (cache) transposeCache.map.set(q, new Uint8Array(quantQueryByte));
+  }
+  /** transposeHalfByteFast(q, quantQueryByte): PACKED planes, eight dimensions per byte, MSB first, plane size = quantQueryByte.length / 4; no validation, :561-592 */
+  static transposeHalfByteFast(q, quantQueryByte) {
+    quantQueryByte.fill(0);
+    const n = q.length, planeSize = quantQueryByte.length / 4;
+    for (let g = 0; g * 8 < n; g++) {
+      const planes = [0, 0, 0, 0];
+      for (let j = 0; j < 8 && g * 8 + j < n; j++) {
+        const v = q[g * 8 + j];
+        for (let p = 0; p < 4; p++) planes[p] |= ((v >> p) & 1) << (7 - j);
+      }
+      for (let p = 0; p < 4; p++) quantQueryByte[g + p * planeSize] = planes[p];
+    }
+  }
+  static clearTransposeCache() { transposeCache.map = new WeakMap(); transposeCache.hits = 0; transposeCache.misses = 0; }
+  /** {size: 0 (a WeakMap has none), hitRate}, :619-627 */
+  static getTransposeCacheStats() {
+    const total = transposeCache.hits + transposeCache.misses;
+    return { size: 0, hitRate: total > 0 ? transposeCache.hits / total : 0 };
   }
   /** packAsBinary, src/optimizedScalarQuantizer.ts:420-446 */
   static packAsBinary(vector, packed) {

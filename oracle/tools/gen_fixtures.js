@@ -364,6 +364,37 @@ function runApiBehaviour() {
     ['bad similarity', function () { sc.computeOriginalScore(accQueries[0], accBase[0], 'NOPE'); }]].forEach(function (p) {
     try { p[1](); out.accuracy.errors[p[0]] = null; } catch (e) { out.accuracy.errors[p[0]] = String(e.message); }
   });
+  // the quantizer's remaining public utilities (src/optimizedScalarQuantizer.ts:67-93, 460-627)
+  const OSQ = require(path.join(ERASED, 'optimizedScalarQuantizer')).OptimizedScalarQuantizer;
+  const qz = out.quantizer_utils = { values: {}, errors: {} };
+  qz.values.discretize = [[0, 8], [1, 8], [8, 8], [9, 8], [100, 64], [7.5, 4], [-3, 4]].map(function (p) { return OSQ.discretize(p[0], p[1]); });
+  const q4 = new Uint8Array(19); { const r = mulberry32(930); for (let i = 0; i < q4.length; i++) q4[i] = Math.floor(r() * 16); }
+  qz.q4 = arr(q4);
+  { const o = new Uint8Array(q4.length * 4); OSQ.transposeHalfByte(q4, o); qz.values.transposeHalfByte = arr(o); }
+  { const o = new Uint8Array(Math.ceil(q4.length / 8) * 4); OSQ.transposeHalfByteFast(q4, o); qz.values.transposeHalfByteFast = arr(o); }
+  { const o = new Uint8Array(16 * 4); OSQ.transposeHalfByteFast(q4.subarray(0, 16), o); qz.values.transposeHalfByteFast_wide_output = arr(o); }
+  OSQ.clearTransposeCache();
+  qz.values.cache = [];
+  { const o = new Uint8Array(q4.length * 4), o2 = new Uint8Array(q4.length * 4), copy = new Uint8Array(q4);
+    qz.values.cache.push(OSQ.getTransposeCacheStats());
+    OSQ.transposeHalfByteOptimized(q4, o); qz.values.cache.push(OSQ.getTransposeCacheStats());
+    OSQ.transposeHalfByteOptimized(q4, o2); qz.values.cache.push(OSQ.getTransposeCacheStats());
+    OSQ.transposeHalfByteOptimized(copy, o2); qz.values.cache.push(OSQ.getTransposeCacheStats());     // same values, another array: a miss
+    OSQ.transposeHalfByteOptimized(copy, o2, false); qz.values.cache.push(OSQ.getTransposeCacheStats());  // uncached: not counted
+    q4[0] ^= 1; OSQ.transposeHalfByteOptimized(q4, o2); q4[0] ^= 1;                                     // a hit returns the stale planes
+    qz.values.cache_stale_hit_equals_first = arr(o2).join() === arr(o).join();
+    OSQ.clearTransposeCache(); qz.values.cache.push(OSQ.getTransposeCacheStats()); }
+  { const qn = new OSQ({ similarityFunction: 'EUCLIDEAN', lambda: 0.1, iters: 5 });
+    const v = randMatrix(931, 1, 24)[0], cen = randMatrix(932, 1, 24)[0].map(function (x) { return x * 0.1; });
+    const d = [new Uint8Array(24), new Uint8Array(24), new Uint8Array(24)];
+    const rs = qn.multiScalarQuantize(v, d, [1, 4, 7], Float32Array.from(cen));
+    qz.values.multiScalarQuantize = { seeds: [931, 932], dim: 24, bits: [1, 4, 7], destinations: d.map(arr), results: rs };
+    [['multi length mismatch', function () { qn.multiScalarQuantize(v, d, [1, 4], Float32Array.from(cen)); }],
+      ['transpose null', function () { OSQ.transposeHalfByte(null, new Uint8Array(4)); }],
+      ['transpose length', function () { OSQ.transposeHalfByte(new Uint8Array(3), new Uint8Array(4)); }],
+      ['transpose value', function () { OSQ.transposeHalfByte(new Uint8Array([1, 16]), new Uint8Array(8)); }]].forEach(function (p) {
+      try { p[1](); qz.errors[p[0]] = null; } catch (e) { qz.errors[p[0]] = String(e.message); }
+    }); }
   fs.writeFileSync(path.join(OUT, 'api_behaviour.json'), JSON.stringify(out, null, 1));
   console.log('api_behaviour ok');
 }

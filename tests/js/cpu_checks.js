@@ -223,4 +223,42 @@ T.check(packed[0] === 0xAA, 'packAsBinary');
   });
 })();
 
+// --- the quantizer's remaining public utilities (src/optimizedScalarQuantizer.ts:67-93, 460-627) against what the reference returned
+(function () {
+  const Z = api.quantizer_utils, W = Z.values, OSQ = bbq.OptimizedScalarQuantizer, q4 = Uint8Array.from(Z.q4);
+  const same = function (got, want, label) { T.check(JSON.stringify(got) === JSON.stringify(want), 'quantizer ' + label + ': ' + JSON.stringify(got) + ' vs ' + JSON.stringify(want)); };
+  same([[0, 8], [1, 8], [8, 8], [9, 8], [100, 64], [7.5, 4], [-3, 4]].map(function (p) { return OSQ.discretize(p[0], p[1]); }), W.discretize, 'discretize');
+  let o = new Uint8Array(q4.length * 4); OSQ.transposeHalfByte(q4, o); same(Array.from(o), W.transposeHalfByte, 'transposeHalfByte');
+  o = new Uint8Array(Math.ceil(q4.length / 8) * 4); OSQ.transposeHalfByteFast(q4, o); same(Array.from(o), W.transposeHalfByteFast, 'transposeHalfByteFast');
+  o = new Uint8Array(64); OSQ.transposeHalfByteFast(q4.subarray(0, 16), o); same(Array.from(o), W.transposeHalfByteFast_wide_output, 'transposeHalfByteFast, output wider than needed');
+  OSQ.clearTransposeCache();
+  const stats = [], first = new Uint8Array(q4.length * 4), o2 = new Uint8Array(q4.length * 4), copy = new Uint8Array(q4);
+  stats.push(OSQ.getTransposeCacheStats());
+  OSQ.transposeHalfByteOptimized(q4, first); stats.push(OSQ.getTransposeCacheStats());
+  OSQ.transposeHalfByteOptimized(q4, o2); stats.push(OSQ.getTransposeCacheStats());
+  OSQ.transposeHalfByteOptimized(copy, o2); stats.push(OSQ.getTransposeCacheStats());
+  OSQ.transposeHalfByteOptimized(copy, o2, false); stats.push(OSQ.getTransposeCacheStats());
+  q4[0] ^= 1; OSQ.transposeHalfByteOptimized(q4, o2); q4[0] ^= 1;
+  same(Array.from(o2).join() === Array.from(first).join(), W.cache_stale_hit_equals_first, 'a cache hit returns the planes of the first call');
+  same(Array.from(first), W.transposeHalfByte, 'transposeHalfByteOptimized');
+  OSQ.clearTransposeCache(); stats.push(OSQ.getTransposeCacheStats());
+  same(stats, W.cache, 'transpose cache statistics');
+  const M = W.multiScalarQuantize, qn = new OSQ({ similarityFunction: 'EUCLIDEAN', lambda: 0.1, iters: 5 });
+  const v = T.randMatrix(M.seeds[0], 1, M.dim)[0], cen = Float32Array.from(T.randMatrix(M.seeds[1], 1, M.dim)[0].map(function (x) { return x * 0.1; }));
+  const d = M.bits.map(function () { return new Uint8Array(M.dim); });
+  same(qn.multiScalarQuantize(v, d, M.bits, cen), M.results, 'multiScalarQuantize corrections');
+  same(d.map(function (x) { return Array.from(x); }), M.destinations, 'multiScalarQuantize codes');
+  const errs = {
+    'multi length mismatch': function () { qn.multiScalarQuantize(v, d, [1, 4], cen); },
+    'transpose null': function () { OSQ.transposeHalfByte(null, new Uint8Array(4)); },
+    'transpose length': function () { OSQ.transposeHalfByte(new Uint8Array(3), new Uint8Array(4)); },
+    'transpose value': function () { OSQ.transposeHalfByte(new Uint8Array([1, 16]), new Uint8Array(8)); },
+  };
+  Object.keys(Z.errors).forEach(function (name) {
+    let msg = null;
+    try { errs[name](); } catch (e) { msg = String(e.message); }
+    T.check(msg === Z.errors[name], 'quantizer error "' + name + '": ' + msg);
+  });
+})();
+
 T.finish('js cpu_checks');
