@@ -278,7 +278,7 @@ def main():
     ap.add_argument("--config", default=None, choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json configs: c2 = 1Mx768 qb4/ib1 k100; c3 = the default (10Mx768); c4 = 10Mx1536 MAXIMUM_INNER_PRODUCT; "
                          "c5 = 1Mx1024 queryBits 8 / indexBits 2")
-    ap.add_argument("--sub-batch", type=int, default=32, help="queries per device launch sequence (pipelined inside a step)")
+    ap.add_argument("--sub-batch", type=int, default=0, help="queries per device launch sequence (pipelined inside a step); 0 = the library's choice by index size")
     ap.add_argument("--slots", type=int, default=3, help="pipeline slots (streams) inside the library")
     ap.add_argument("--replay-threads", type=int, default=16, help="host threads replaying the reference heap")
     ap.add_argument("--pilot", type=int, default=32768, help="replicated pilot rows per non-root shard (multi-GPU)")
@@ -371,6 +371,8 @@ def main():
             pilot = rows_of(0, P)
     ix = B.Index(codes, corr, dim, cdp, device=device, index_bits=IB, row_base=r0,
                  pilot_codes=None if pilot is None else pilot[0], pilot_corr=None if pilot is None else pilot[1])
+    # 0: the library's choice by the rows of the index / shard (bbq_core.cpp effective_batch): 32 from 6 M rows, 64 from 2.5 M, 128 below
+    sub_batch = min(args.sub_batch, Q) if args.sub_batch > 0 else min(Q, 32 if r1 - r0 >= 6_000_000 else 64 if r1 - r0 >= 2_500_000 else 128)
     ix.set_option("batch_queries", min(args.sub_batch, Q))
     ix.set_option("pipeline_slots", args.slots)
     ix.set_option("replay_threads", args.replay_threads)
@@ -494,7 +496,7 @@ def main():
             "dtype": "u64 popcount + f64 score epilogue" if IB == 1 else "u4/u8 packed integer dot (u32 accumulate) + f64 score epilogue",
             "data": "synthetic",
             "config": {"workload": "%dx%d-dim %d-bit index, queryBits=%d, k=%d, %s, row-sharded over %d GPU(s)" % (N, dim, IB, QB, k, args.sim, world),
-                       "queries_per_step": Q, "queries_per_launch": min(args.sub_batch, Q), "sweeps_per_query": 1,
+                       "queries_per_step": Q, "queries_per_launch": sub_batch, "sweeps_per_query": 1,
                        "pipeline_slots": args.slots, "replay_threads": args.replay_threads, "bytes_per_row": bytes_per_row,
                        "parallelism": "row-shard x%d" % world},
             # frac / frac_hipevent: this run, HIP events on the kernel's own stream; frac_rocprof_avg: the committed kernel-trace

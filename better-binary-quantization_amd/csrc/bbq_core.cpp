@@ -204,6 +204,15 @@ int storage_from_device_rows(bbq_index *ix, Storage &st, const uint8_t *d_codes,
 
 namespace {
 
+// queries per launch sequence (sub-batch).  The largest sweep of a sub-batch should run for about a millisecond: shorter ones pay the
+// device's dependent-launch gaps and their own ramp (1.25 M rows x 2048 queries: 52.5 K q/s with 32 per sub-batch, 56.5 K with 64,
+// 57 K with 96-128; at 10 M rows 32 is as good as 64 and needs half the workspace)
+int effective_batch(const bbq_index *ix) {
+  if (ix->opt_batch > 0) return ix->opt_batch;
+  const int64_t rows = ix->main.view.n_rows;
+  return rows >= 6000000 ? 32 : rows >= 2500000 ? 64 : 128;
+}
+
 // ------------------------------------------------------------------------------------------------ plan
 
 int cap_for(int64_t k, int64_t rows_before) {
@@ -286,7 +295,7 @@ void build_plan(bbq_index *ix, int64_t k, int64_t final_k = 0, bool latency = fa
   // per query; bounded so that the overflow areas of one pipeline slot stay within 512 MB however many queries a sub-batch has
   p.flood_cap = std::min<int64_t>(ix->opt_flood, (ix->main.view.n_rows + 1023) / 1024 * 1024);
   if (p.flood_cap > 0)
-    p.flood_cap = std::min<int64_t>(p.flood_cap, std::max<int64_t>(16384, ((64ll << 20) / std::max(32, ix->opt_batch)) / 1024 * 1024));
+    p.flood_cap = std::min<int64_t>(p.flood_cap, std::max<int64_t>(16384, ((64ll << 20) / std::max(32, effective_batch(ix))) / 1024 * 1024));
 }
 
 // ------------------------------------------------------------------------------------------------ slots
@@ -329,7 +338,7 @@ int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
                   (!own_lists || s.d_lists != nullptr);
   if (ok) return BBQ_OK;
   free_slot_buffers(s);
-  const int Q = (std::max(nq, ix->opt_batch) + 31) / 32 * 32;  // multiple of 32: the MFMA query layout is per group of 32
+  const int Q = (std::max(nq, effective_batch(ix)) + 31) / 32 * 32;  // multiple of 32: the MFMA query layout is per group of 32
   s.qbuf_bytes = qb;
   s.chunks_cap = std::max<int64_t>(p.max_chunks, 1);
   s.slots_cap = std::max<int64_t>(p.max_slots, 1);
@@ -1058,7 +1067,7 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
   const int64_t final_k = (keff <= kFinalSelectMax && ix->opt_device_select) ? keff : 0;
   cs.k = final_k > 0 ? keff + 1 : keff;
   build_plan(ix, cs.k, final_k, final_k > 0 && n_queries <= ix->opt_latency_queries);
-  const int Q = std::max(1, ix->opt_batch);
+  const int Q = effective_batch(ix);
   const int nslots = std::min(std::max(1, ix->opt_slots), kMaxSlots);
   const int64_t nsub = ((int64_t)n_queries + Q - 1) / Q;
   auto fail_out = [&](int code) {
@@ -1199,7 +1208,7 @@ int bbq_shard_scan(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, cons
     ix->shard_q_cap = n_queries;
     ix->shard_list_cap = list_cap;
   }
-  const int Q = std::max(1, ix->opt_batch);
+  const int Q = effective_batch(ix);
   const int nslots = std::min(std::max(1, ix->opt_slots), kMaxSlots);
   const int64_t nsub = ((int64_t)n_queries + Q - 1) / Q;
   auto retire = [&](Slot &s) -> int {
@@ -1249,7 +1258,7 @@ int bbq_set_option(bbq_index *ix, const char *name, int64_t v) {
   if (!ix || !name) return fail(BBQ_ERR_INVALID_ARG, "bbq_set_option: null");
   if (ix->multi) return multi_set_option(ix, name, v);
   const std::string n(name);
-  if (n == "batch_queries" && v >= 1 && v <= 1024) ix->opt_batch = (int)v;
+  if (n == "batch_queries" && v >= 0 && v <= 1024) ix->opt_batch = (int)v;  // 0: by index size
   else if (n == "pipeline_slots" && v >= 1 && v <= kMaxSlots) ix->opt_slots = (int)v;
   else if (n == "segment_growth" && v >= 2 && v <= 1024) { ix->opt_growth = (int)v; ix->plan.k = -1; }
   else if (n == "first_segment_rows" && v >= 1024 && v <= 8192 && v % kChunkRows == 0) { ix->opt_s0 = v; ix->plan.k = -1; }

@@ -153,7 +153,7 @@ struct bbq_index {
   int32_t *d_shard_counts = nullptr;
   int64_t shard_q_cap = 0, shard_list_cap = 0;
   // options
-  int opt_batch = 32, opt_slots = 2, opt_growth = 8, opt_force_dense = 0, opt_share = 1, opt_device_select = 1;
+  int opt_batch = 0 /* 0: by index size, effective_batch() */, opt_slots = 2, opt_growth = 8, opt_force_dense = 0, opt_share = 1, opt_device_select = 1;
   // a call with few queries is latency-bound: every segment costs a dependent scan + finalize launch pair (~15-20 us), so such calls
   // walk the index in fewer, faster-growing segments (more candidates per query - the device selects the answer itself anyway)
   int opt_latency_queries = 4, opt_latency_growth = 64;

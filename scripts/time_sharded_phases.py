@@ -26,7 +26,6 @@ Q = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 dim, k = 768, 100
 codes, corr = bench.synth_rows(1, 0, n, dim // 8)
 ix = B.Index(codes, corr, dim, 0.01)
-ix.set_option("batch_queries", 32)
 ix.set_option("pipeline_slots", 3)
 S = ShardedSearcher(ix, n, k, Q, replay_threads=16, device="cuda:0")
 T = {"scan": [], "merge": []}
