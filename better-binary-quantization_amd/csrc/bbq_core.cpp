@@ -337,21 +337,28 @@ int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
                   s.flood_cap >= p.flood_cap && s.final_stride >= p.final_k + 2 &&
                   (!own_lists || s.d_lists != nullptr);
   if (ok) return BBQ_OK;
+  // grow-only in every dimension: a process that alternates between call shapes (single queries use another segment plan than
+  // batches, k varies) would otherwise free and allocate the workspace at every switch - each time sized for the plan at hand and
+  // therefore too small for the other one (milliseconds per switch)
+  const int old_q = s.q_cap;
+  const int64_t old_final = s.final_stride;
+  const bool had_lists = s.d_lists != nullptr;
   free_slot_buffers(s);
-  const int Q = (std::max(nq, effective_batch(ix)) + 31) / 32 * 32;  // multiple of 32: the MFMA query layout is per group of 32
-  s.qbuf_bytes = qb;
-  s.chunks_cap = std::max<int64_t>(p.max_chunks, 1);
-  s.slots_cap = std::max<int64_t>(p.max_slots, 1);
-  s.dense_cap = p.s0;
-  s.list_cap = p.list_cap + (own_lists ? p.flood_cap : 0);  // own lists can take a flood; external ones are the caller's size
-  s.flood_cap = p.flood_cap;
-  s.k_cap = std::max<int64_t>(p.k, 1);
-  s.hprefix = hprefix;
+  own_lists = own_lists || had_lists;
+  const int Q = std::max((std::max(nq, effective_batch(ix)) + 31) / 32 * 32, old_q);  // multiple of 32: the MFMA query layout is per group of 32
+  s.qbuf_bytes = std::max(s.qbuf_bytes, qb);
+  s.chunks_cap = std::max<int64_t>(s.chunks_cap, std::max<int64_t>(p.max_chunks, 1));
+  s.slots_cap = std::max<int64_t>(s.slots_cap, std::max<int64_t>(p.max_slots, 1));
+  s.dense_cap = std::max<int64_t>(s.dense_cap, p.s0);
+  s.flood_cap = std::max<int64_t>(s.flood_cap, p.flood_cap);
+  s.list_cap = std::max<int64_t>(s.list_cap, p.list_cap + (own_lists ? s.flood_cap : 0));  // own lists can take a flood; external ones are the caller's size
+  s.k_cap = std::max<int64_t>(s.k_cap, std::max<int64_t>(p.k, 1));
+  s.hprefix = std::max<int64_t>(s.hprefix, hprefix);
   // theta | flags | topk_counts | list_counts | ovf_counts | append_counts live in one control block in front of the staged queries: the copy that
   // brings a sub-batch's queries also resets them (the host twin's control part stays zero)
   s.ctrl_bytes = ((int64_t)Q * 28 + 255) / 256 * 256;
-  HIPCHK(hipMalloc((void **)&s.d_block, (size_t)(s.ctrl_bytes + Q * qb)));
-  HIPCHK(hipHostMalloc((void **)&s.h_block, (size_t)(s.ctrl_bytes + Q * qb), hipHostMallocDefault));
+  HIPCHK(hipMalloc((void **)&s.d_block, (size_t)(s.ctrl_bytes + Q * s.qbuf_bytes)));
+  HIPCHK(hipHostMalloc((void **)&s.h_block, (size_t)(s.ctrl_bytes + Q * s.qbuf_bytes), hipHostMallocDefault));
   memset(s.h_block, 0, (size_t)s.ctrl_bytes);
   s.d_qbuf = s.d_block + s.ctrl_bytes;
   s.h_qbuf = s.h_block + s.ctrl_bytes;
@@ -371,7 +378,7 @@ int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
     HIPCHK(hipMalloc((void **)&s.d_lists, (size_t)(Q * s.list_cap) * 8));
     HIPCHK(hipHostMalloc((void **)&s.h_lists, (size_t)(Q * s.hprefix) * 8, hipHostMallocDefault));
   }
-  s.final_stride = std::max<int64_t>(p.final_k, 126) + 2;
+  s.final_stride = std::max<int64_t>(old_final, std::max<int64_t>(p.final_k, 126) + 2);
   HIPCHK(hipMalloc((void **)&s.d_final, (size_t)(Q * s.final_stride) * 8));
   HIPCHK(hipHostMalloc((void **)&s.h_final, (size_t)(Q * s.final_stride) * 8, hipHostMallocDefault));
   s.q_cap = Q;
