@@ -883,6 +883,49 @@ def test_load_rejects_damaged_files(tmp_path):
     ix.close()
 
 
+def test_config4_shape_10m_x_1536_mip_properties():
+    """BASELINE config 4's shape at full size (10 M x 1536-d, MAXIMUM_INNER_PRODUCT, k = 100): the oracle's answer for one query
+    (about 6 s of CPU), size-independent properties for more - single-query plan == batch plan == dense replay == host replay,
+    returned scores equal the rows' own scores"""
+    bench = __import__("importlib").import_module("bench")
+    n, dim, k, sim = 10_000_000, 1536, 100, 2
+    codes, corr = bench.synth_rows(1, 0, n, dim // 8)
+    qq, qc = bench.synth_queries(2, 6, dim)
+    cdp = 0.0009110655808639536
+    ix = _make_index(codes, corr, dim, cdp, True)
+    try:
+        assert ix.bytes_per_row == 192 + 4
+        idx, sc, cnt = ix.search_batch(qq, qc, 4, sim, k)           # 6 queries: the batch plan
+        assert (cnt == k).all() and ix.stats()["dense_fallbacks"] == 0 and ix.stats()["host_replays"] == 0
+        d, s64, s32 = O.score_all(codes, corr, dim, qq[0], qc[0], 4, sim, cdp)
+        oi, osc = O.heap_topk(s32, k)
+        np.testing.assert_array_equal(idx[0], oi)
+        np.testing.assert_array_equal(sc[0].view(np.uint32), osc.view(np.uint32))
+        for q in range(6):                                          # one query per call: the latency plan (three segments, append mode)
+            i1, s1 = ix.search(qq[q], qc[q], 4, sim, k)
+            np.testing.assert_array_equal(i1, idx[q])
+            np.testing.assert_array_equal(s1.view(np.uint32), sc[q].view(np.uint32))
+        ix.set_option("device_select", 0)                           # the host replays the heap over the candidate lists
+        hi, hs, _ = ix.search_batch(qq, qc, 4, sim, k)
+        assert ix.stats()["host_replays"] == 6
+        ix.set_option("device_select", 1)
+        np.testing.assert_array_equal(hi, idx)
+        np.testing.assert_array_equal(hs.view(np.uint32), sc.view(np.uint32))
+        ix.set_option("force_dense", 1)
+        di, ds, _ = ix.search_batch(qq[4:6], qc[4:6], 4, sim, k)
+        ix.set_option("force_dense", 0)
+        np.testing.assert_array_equal(di, idx[4:6])
+        np.testing.assert_array_equal(ds.view(np.uint32), sc[4:6].view(np.uint32))
+        for q in range(1, 6):
+            assert (np.diff(sc[q]) <= 0).all()
+            for j in (0, 50, 99):
+                r = int(idx[q, j])
+                _, _, one = ix.score_rows(qq[q], qc[q], 4, sim, r, 1)
+                assert one[0].view(np.uint32) == sc[q, j].view(np.uint32)
+    finally:
+        ix.close()
+
+
 # ---------------------------------------------------------------- randomized sweep of shapes and options
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BBQ_FUZZ_SEEDS", "24"))))   # BBQ_FUZZ_SEEDS=400 for a soak
