@@ -19,11 +19,19 @@ int bbq_index_build(const float *vectors, int64_t n, int32_t dim, int32_t sim, d
 // quantizeVectors on the device + index in place (bbq_build_kernels.hip)
 int bbq_index_build_bits(const float *vectors, int64_t n, int32_t dim, int32_t sim, int32_t index_bits, double lambda, int32_t iters,
                          int32_t device, bbq_index **out, float *centroid, uint8_t *codes, double *corr, int64_t *bad_row, int32_t *bad_col) {
+  return bbq_index_build_opts(vectors, n, dim, sim, index_bits, lambda, iters, device, nullptr, out, centroid, codes, corr, bad_row, bad_col);
+}
+
+int bbq_index_build_opts(const float *vectors, int64_t n, int32_t dim, int32_t sim, int32_t index_bits, double lambda, int32_t iters,
+                         int32_t device, const bbq_index_options *opts, bbq_index **out, float *centroid, uint8_t *codes, double *corr,
+                         int64_t *bad_row, int32_t *bad_col) {
   clear_error();
   if (!out) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_build: out is null");
   *out = nullptr;
   if (index_bits < 1 || index_bits > 8) return fail(BBQ_ERR_INVALID_ARG, "indexBits必须在1-8之间");
-  if ((int64_t)dim * 255 * 255 > 0x7fffffffll) return fail(BBQ_ERR_UNSUPPORTED, "dimension %d: the integer dot product would not fit 31 bits", dim);
+  if (check_options(opts) != BBQ_OK) return BBQ_ERR_INVALID_ARG;
+  if (!dim_supported(dim, dim == 1 ? 1 : store_bits_of(index_bits)))
+    return fail(BBQ_ERR_UNSUPPORTED, "dimension %d at indexBits %d: the integer dot product would not fit 31 bits", dim, index_bits);
   if (n == 0) return fail(BBQ_ERR_EMPTY, "向量集合不能为空");
   if (n < 0 || dim <= 0 || !vectors || !centroid) return fail(BBQ_ERR_INVALID_ARG, "输入向量不能为空");
   if (sim < 0 || sim > 2) return fail(BBQ_ERR_INVALID_ARG, "不支持的相似性函数: %d", sim);
@@ -106,10 +114,7 @@ int bbq_index_build_bits(const float *vectors, int64_t n, int32_t dim, int32_t s
   ix->w16 = (ix->pb + 15) / 16;
   ix->n_rows = n;
   ix->row_base = 0;
-  {
-    const char *e = getenv("BBQ_COMPACT_CORRECTIONS");
-    ix->want_compact = (e && e[0] == '0') ? 0 : 1;
-  }
+  ix->want_compact = want_compact_of(opts);
   if (index_bits > 1) {
     // more than one bit: the kernel leaves what the reference keeps for such an index - one byte per dimension - and the corrections
     // in device memory; the tile records are built from there exactly as bbq_index_create builds them from host rows

@@ -182,11 +182,11 @@ int storage_from_device_rows(bbq_index *ix, Storage &st, const uint8_t *d_codes,
       uint32_t bad = 0;
       if (!m_mis.p) HIPCHK(m_mis.alloc(4));
       HIPCHK(hipMemsetAsync(m_mis.p, 0, 4, s));
-      HIPCHK(launch_retile_multibit(d_codes, d_corr, n_rows, ix->dim, ix->store_bits, st.d_tiles, ix->w16, ix->tile_stride, ix->has_x1, ix->layout,
+      HIPCHK(launch_retile_multibit(d_codes, d_corr, n_rows, ix->dim, ix->store_bits, ix->index_bits, st.d_tiles, ix->w16, ix->tile_stride, ix->has_x1, ix->layout,
                                     st.d_exact, m_mis.as<uint32_t>(), s));
       HIPCHK(hipMemcpyAsync(&bad, m_mis.p, 4, hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
-      if (bad) return fail(BBQ_ERR_INVALID_ARG, "indexBits=%d: a quantized value does not fit %d bits", ix->index_bits, ix->store_bits);
+      if (bad) return fail(BBQ_ERR_INVALID_ARG, "indexBits=%d: a quantized value is not below %d", ix->index_bits, 1 << ix->index_bits);
     } else {
       HIPCHK(launch_retile(d_codes, d_corr, n_rows, (int32_t)pb, st.d_tiles, ix->w16, ix->tile_stride, ix->has_x1, ix->layout, st.d_exact, s));
     }
@@ -527,9 +527,21 @@ struct BatchCtx {
   int maxq = 255;  // largest quantized query value of the call (the MFMA sweep needs <= 127)
 };
 
-int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64_t *d_lists_ext, int64_t list_cap_ext,
-                     int32_t *d_counts_ext) {
+// outputs of a sharded scan: the per-query lists live in the index's own buffers and (optionally) the shard-local answers go straight
+// into the caller's device memory (bbq_shard_scan_begin)
+struct ExtOut {
+  uint64_t *lists = nullptr;     // [nq of the batch][list_cap], this sub-batch's first row
+  int64_t list_cap = 0;
+  int32_t *counts = nullptr;     // [nq][2]
+  uint64_t *answers = nullptr;   // this sub-batch's first row of the caller's [n_queries][answers_stride], or null
+  int64_t answers_stride = 0;
+};
+
+int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const ExtOut *ext) {
   bbq_index *ix = c.ix;
+  uint64_t *d_lists_ext = ext ? ext->lists : nullptr;
+  const int64_t list_cap_ext = ext ? ext->list_cap : 0;
+  int32_t *d_counts_ext = ext ? ext->counts : nullptr;
   const Plan &p = ix->plan;
   const int64_t qb = query_data_bytes(ix, c.planes);
   uint8_t *hp = s.h_qbuf;
@@ -651,6 +663,11 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, uint64
       f.final_out = s.d_final;
       f.final_stride = (int32_t)s.final_stride;
       f.final_k = (int32_t)p.final_k;
+    } else if (ext && ext->answers && p.final_k > 0 && &g == &p.segs.back()) {
+      f.final_out = ext->answers;
+      f.final_stride = (int32_t)ext->answers_stride;
+      f.final_k = (int32_t)p.final_k;
+      f.final_shard = 1;
     }
     HIPCHK(launch_finalize(f, nq, st));
   }
@@ -759,25 +776,48 @@ int begin_replay(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score,
     }
   auto final_cnt = [&s](int i) { return (int32_t)(uint32_t)s.h_final[(size_t)i * s.final_stride + 1]; };
   auto final_replay = [&s](int i) { return (uint32_t)(s.h_final[(size_t)i * s.final_stride + 1] >> 32) != 0; };
-  const int64_t covered = fin ? 0 : s.hprefix;  // list entries the enqueue-time copy brought over
+  // list entries of query i that sit in the pinned h_lists row: the prefix the enqueue-time copy brought over, or - when the device was
+  // to answer and could not (equal scores) - the whole list, fetched below with ONE batch of asynchronous copies on the slot's stream
+  // (a synchronous pageable copy per query on the null stream stalled every other slot: duplicated vectors make such queries common)
+  s.host_cnt.assign((size_t)nq, 0);
   int n_replay = 0;
   struct CountReplays {  // on every exit path
     bbq_index *ix; int &n;
     ~CountReplays() { ix->stats.host_replays += n; }
   } count_replays{ix, n_replay};
+  bool fetched = false;
   for (int i = 0; i < nq; ++i) {
     const int32_t cnt = s.h_list_counts[2 * i], flags = s.h_list_counts[2 * i + 1];
     if (flags != 0) { s.dense_q.push_back(i); continue; }
     if (fin && !final_replay(i)) continue;  // answered on the device
     ++n_replay;
-    if (cnt > covered) {  // rare: fetch what the enqueue-time copy did not cover (everything, when the device was to answer)
-      s.tails[(size_t)i].resize((size_t)(cnt - covered));
-      HIPCHK(hipMemcpy(s.tails[(size_t)i].data(), s.d_lists + (size_t)i * s.list_cap + covered, (size_t)(cnt - covered) * 8,
-                       hipMemcpyDeviceToHost));
-      // append mode leaves the entries of a segment in arrival order: the reference loop wants them by row (row << 32 | score bits)
-      if (s.appended) std::sort(s.tails[(size_t)i].begin(), s.tails[(size_t)i].end());
+    int64_t have = fin ? 0 : std::min<int64_t>(cnt, s.hprefix);
+    if (fin && cnt > 0) {
+      have = std::min<int64_t>(cnt, s.hprefix);
+      HIPCHK(hipMemcpyAsync(s.h_lists + (size_t)i * s.hprefix, s.d_lists + (size_t)i * s.list_cap, (size_t)have * 8, hipMemcpyDeviceToHost, s.stream));
+      fetched = true;
+    }
+    s.host_cnt[(size_t)i] = have;
+    if (cnt > have) {  // rare (a flood): the rest of a list longer than the pinned row
+      s.tails[(size_t)i].resize((size_t)(cnt - have));
+      HIPCHK(hipMemcpyAsync(s.tails[(size_t)i].data(), s.d_lists + (size_t)i * s.list_cap + have, (size_t)(cnt - have) * 8, hipMemcpyDeviceToHost, s.stream));
+      fetched = true;
     }
   }
+  if (fetched) HIPCHK(hipStreamSynchronize(s.stream));
+  if (s.appended)  // append mode leaves the entries of a segment in arrival order: the reference loop wants them by row (row << 32 | score bits)
+    for (int i = 0; i < nq; ++i) {
+      if (s.host_cnt[(size_t)i] == 0 && s.tails[(size_t)i].empty()) continue;
+      uint64_t *l = s.h_lists + (size_t)i * s.hprefix;
+      std::vector<uint64_t> &t = s.tails[(size_t)i];
+      if (t.empty()) {
+        std::sort(l, l + s.host_cnt[(size_t)i]);
+      } else {  // list longer than the pinned row: sort the whole of it in the tail vector
+        t.insert(t.begin(), l, l + s.host_cnt[(size_t)i]);
+        s.host_cnt[(size_t)i] = 0;
+        std::sort(t.begin(), t.end());
+      }
+    }
   const int64_t k = c.k, n_total = ix->main.row_id_base + ix->main.view.n_rows;
   Slot *sp = &s;
   if (fin) {  // queries the last finalize launch answered: the sorted rows are the result
@@ -794,7 +834,7 @@ int begin_replay(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score,
       out_n[qi] = m;
     }
   }
-  auto replay_range = [sp, k, n_total, out_idx, out_score, out_n, fin, covered](int lo, int hi) {
+  auto replay_range = [sp, k, n_total, out_idx, out_score, out_n, fin](int lo, int hi) {
     Slot &s = *sp;
     for (int i = lo; i < hi; ++i) {
       const int32_t cnt = s.h_list_counts[2 * i], flags = s.h_list_counts[2 * i + 1];
@@ -802,7 +842,8 @@ int begin_replay(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score,
       if (fin && (uint32_t)(s.h_final[(size_t)i * s.final_stride + 1] >> 32) == 0) continue;
       HeapReplay hr(k, n_total);
       const uint64_t *l = s.h_lists + (size_t)i * s.hprefix;
-      const int64_t head = std::min<int64_t>(cnt, covered);
+      const int64_t head = s.host_cnt[(size_t)i];
+      (void)cnt;
       for (int64_t j = 0; j < head; ++j) {
         const uint32_t bits = (uint32_t)l[j];
         float sc;
@@ -864,7 +905,7 @@ int finish_replay(const BatchCtx &c, Slot &s, int32_t *out_idx, float *out_score
       cs.k = ix->plan.k;  // the rank the device runs this call with
       const int share = ix->opt_share;
       ix->opt_share = 1;
-      int rc = enqueue_subbatch(cs, s, qi, 1, nullptr, 0, nullptr);
+      int rc = enqueue_subbatch(cs, s, qi, 1, nullptr);
       ix->opt_share = share;
       if (rc == BBQ_OK) rc = begin_replay(c, s, out_idx, out_score, out_n);
       if (rc != BBQ_OK) return rc;
@@ -901,6 +942,18 @@ int drain(bbq_index *ix) {
 
 namespace bbq {
 
+int settle_shard_slots(DeviceCtx *ctx, bbq_index *owner) {
+  for (int i = 0; i < kMaxSlots; ++i) {
+    Slot &s = ctx->slots[i];
+    if (!s.busy || !s.shard_owner || (owner && s.shard_owner != owner)) continue;
+    HIPCHK(hipEventSynchronize(s.ev_done));
+    s.busy = false;
+    account_timing(s.shard_owner, s);
+    s.shard_owner = nullptr;
+  }
+  return BBQ_OK;
+}
+
 // every f32 score of one query on this index (shard), to host memory: the dense path of a multi-device index
 int dense_scores_host(bbq_index *ix, const uint8_t *qquant, const double *qcorr, int32_t query_bits, int32_t sim, float *out) {
   std::lock_guard<std::mutex> lk(ix->ctx->mu);
@@ -920,8 +973,13 @@ void destroy_unlocked(bbq_index *ix) {
   if (ix->pilot.d_exact) (void)hipFree(ix->pilot.d_exact);
   if (ix->main.d_exact) (void)hipFree(ix->main.d_exact);
   if (ix->d_dense_all) (void)hipFree(ix->d_dense_all);
-  if (ix->d_shard_lists) (void)hipFree(ix->d_shard_lists);
-  if (ix->d_shard_counts) (void)hipFree(ix->d_shard_counts);
+  if (ix->ctx) (void)settle_shard_slots(ix->ctx, ix);  // sub-batches of an asynchronous scan that was never waited for
+  for (bbq_index::ShardSet &set : ix->shard_set) {
+    if (set.done) { (void)hipEventSynchronize(set.done); (void)hipEventDestroy(set.done); }
+    if (set.h_total) (void)hipHostFree(set.h_total);
+    if (set.d_lists) (void)hipFree(set.d_lists);
+    if (set.d_counts) (void)hipFree(set.d_counts);
+  }
   delete ix;
 }
 
@@ -940,13 +998,21 @@ int bbq_device_count(void) {
 int bbq_index_create_shard(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim, int32_t index_bits,
                            double centroid_dp, int64_t row_base, const uint8_t *pilot_codes, const double *pilot_corr,
                            int64_t n_pilot, int32_t device, bbq_index **out) {
+  return bbq_index_create_shard_opts(codes, corr, n_rows, dim, index_bits, centroid_dp, row_base, pilot_codes, pilot_corr, n_pilot, device, nullptr, out);
+}
+
+int bbq_index_create_shard_opts(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim, int32_t index_bits,
+                                double centroid_dp, int64_t row_base, const uint8_t *pilot_codes, const double *pilot_corr,
+                                int64_t n_pilot, int32_t device, const bbq_index_options *opts, bbq_index **out) {
   clear_error();
   if (!out) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_create: out is null");
   *out = nullptr;
   if (n_rows < 0 || dim <= 0 || row_base < 0 || n_pilot < 0) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_create: bad size");
   if (n_rows > 0 && (!codes || !corr)) return fail(BBQ_ERR_INVALID_ARG, "目标向量集合不能为空");
   if (index_bits < 1 || index_bits > 8) return fail(BBQ_ERR_INVALID_ARG, "indexBits必须在1-8之间");
-  if ((int64_t)dim * 255 * 255 > 0x7fffffffll) return fail(BBQ_ERR_UNSUPPORTED, "dimension %d: the integer dot product would not fit 31 bits", dim);
+  if (check_options(opts) != BBQ_OK) return BBQ_ERR_INVALID_ARG;
+  if (!dim_supported(dim, dim == 1 ? 1 : store_bits_of(index_bits)))
+    return fail(BBQ_ERR_UNSUPPORTED, "dimension %d at indexBits %d: the integer dot product would not fit 31 bits", dim, index_bits);
   if (n_pilot > 0 && (!pilot_codes || !pilot_corr)) return fail(BBQ_ERR_INVALID_ARG, "pilot arrays are null");
   if (n_pilot > 0 && row_base == 0) return fail(BBQ_ERR_INVALID_ARG, "the shard that owns row 0 takes no pilot replica");
   if (n_pilot > 0 && n_pilot > row_base) return fail(BBQ_ERR_INVALID_ARG, "pilot rows must precede the shard (n_pilot <= row_base)");
@@ -972,10 +1038,7 @@ int bbq_index_create_shard(const uint8_t *codes, const double *corr, int64_t n_r
   ix->row_base = row_base;
   ix->centroid_dp = centroid_dp;
   ix->has_pilot = n_pilot > 0;
-  {
-    const char *e = getenv("BBQ_COMPACT_CORRECTIONS");  // 0: stream the exact f64 corrections (120 B/row at 768-d) instead
-    ix->want_compact = (e && e[0] == '0') ? 0 : 1;
-  }
+  ix->want_compact = want_compact_of(opts);
   DeviceCtx *ctx = nullptr;
   int rc0 = get_ctx(device, &ctx);
   if (rc0 != BBQ_OK) return rc0;
@@ -1050,6 +1113,8 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
     return fail(BBQ_ERR_INVALID_ARG, "bbq_search on a non-root shard: use bbq_shard_scan + bbq_replay");
   std::lock_guard<std::mutex> lk(ix->ctx->mu);
   HIPCHK(hipSetDevice(ix->device));
+  rc = settle_shard_slots(ix->ctx, nullptr);  // an asynchronous sharded scan on this device may have left slots busy
+  if (rc != BBQ_OK) return rc;
   ix->stats.candidates = 0;
   ix->stats.dense_fallbacks = 0;
   ix->stats.host_replays = 0;
@@ -1091,7 +1156,7 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
     const int nq = (int)std::min<int64_t>(Q, n_queries - i * Q);
     rc = ensure_slot(ix, s, nq, true);
     if (rc != BBQ_OK) return fail_out(rc);
-    rc = enqueue_subbatch(cs, s, i * Q, nq, nullptr, 0, nullptr);
+    rc = enqueue_subbatch(cs, s, i * Q, nq, nullptr);
     if (rc != BBQ_OK) return fail_out(rc);
     // hand finished sub-batches to the replay workers as early as possible (their slot is needed again soon)
     for (int j = 0; j < nslots; ++j) {
@@ -1181,76 +1246,156 @@ int bbq_score_rows(bbq_index *ix, const uint8_t *qquant, const double *qcorr, in
 int64_t bbq_shard_list_cap(const bbq_index *cix, int64_t k) {
   if (!cix || k <= 0 || cix->multi) return 0;
   bbq_index *ix = const_cast<bbq_index *>(cix);
+  // the scan runs with rank k + 1 whenever it can leave shard-local answers (k <= kFinalSelectMax): size for that plan
   const int64_t keff = std::min<int64_t>(k, kMaxFastK);
-  build_plan(ix, keff);
+  std::lock_guard<std::mutex> lk(ix->ctx->mu);
+  if (keff <= kFinalSelectMax) build_plan(ix, keff + 1, keff);
+  else build_plan(ix, keff);
   return ix->plan.list_cap;
+}
+
+int bbq_shard_scan_begin(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, const double *qcorr, int32_t query_bits, int32_t sim,
+                         int64_t k, void *dev_packed, int64_t packed_cap, void *dev_offsets, void *dev_flags, void *dev_answers,
+                         int64_t answers_stride) {
+  clear_error();
+  int rc = validate_query_args(ix, n_queries, qquant, qcorr, query_bits, sim, k);
+  if (rc != BBQ_OK) return rc;
+  if (n_queries <= 0) return fail(BBQ_ERR_INVALID_ARG, "bbq_shard_scan: n_queries must be positive");
+  if (!dev_packed || !dev_offsets || !dev_flags || packed_cap <= 0) return fail(BBQ_ERR_INVALID_ARG, "bbq_shard_scan: null output buffers");
+  if (k == 0 || k > kMaxFastK) return fail(BBQ_ERR_UNSUPPORTED, "bbq_shard_scan: k must be in 1..%lld", (long long)kMaxFastK);
+  if (dev_answers && answers_stride < k + 3) return fail(BBQ_ERR_INVALID_ARG, "bbq_shard_scan: answers_stride must be at least k + 3");
+  if (dev_answers && k > kFinalSelectMax)
+    return fail(BBQ_ERR_UNSUPPORTED, "bbq_shard_scan: shard-local answers exist for k <= %d (pass dev_answers = NULL and merge the lists)", kFinalSelectMax);
+  if (ix->multi) return fail(BBQ_ERR_INVALID_ARG, "bbq_shard_scan: the handle is a multi-device index (it shards by itself)");
+  std::lock_guard<std::mutex> lk(ix->ctx->mu);
+  HIPCHK(hipSetDevice(ix->device));
+  if (ix->shard_begun - ix->shard_waited >= 2) return fail(BBQ_ERR_INVALID_ARG, "bbq_shard_scan_begin: two batches are already in flight on this index (wait for one first)");
+  BatchCtx c{ix, qquant, qcorr, planes_of_call(ix, qquant, (int64_t)n_queries * ix->dim, query_bits == 1), query_bits == 1 ? 1 : 0, sim, k};
+  // with answers the shard runs with rank k + 1, like the single index does: its last finalize launch then knows the (k + 1)-th largest
+  // key of everything it has seen (the cut) and the rows above it.  Lists for rank k + 1 are supersets of the lists for rank k.
+  const bool answers = dev_answers != nullptr;
+  if (answers) { c.k = k + 1; build_plan(ix, k + 1, k); }
+  else build_plan(ix, k);
+  bbq_index::ShardSet &set = ix->shard_set[ix->shard_begun & 1];
+  if (!set.done) {
+    HIPCHK(hipEventCreateWithFlags(&set.done, hipEventDisableTiming));
+    HIPCHK(hipHostMalloc((void **)&set.h_total, 8, hipHostMallocDefault));
+  }
+  // per-query lists with room for a flood (rows stored cluster by cluster); what travels is packed, so the headroom costs
+  // device memory only
+  const int64_t list_cap = ix->plan.list_cap + std::min<int64_t>(ix->plan.flood_cap, 65536);
+  if (set.q_cap < n_queries || set.list_cap < list_cap) {  // per-query lists the finalize kernels build (the set is idle: its last batch was waited for)
+    if (set.d_lists) HIPCHK(hipFree(set.d_lists));
+    if (set.d_counts) HIPCHK(hipFree(set.d_counts));
+    set.d_lists = nullptr;
+    set.d_counts = nullptr;
+    HIPCHK(hipMalloc((void **)&set.d_lists, (size_t)n_queries * (size_t)list_cap * 8));
+    HIPCHK(hipMalloc((void **)&set.d_counts, (size_t)n_queries * 8 + 16));
+    set.q_cap = n_queries;
+    set.list_cap = list_cap;
+  }
+  const int Q = effective_batch(ix);
+  const int nslots = std::min(std::max(1, ix->opt_slots), kMaxSlots);
+  const int64_t nsub = ((int64_t)n_queries + Q - 1) / Q;
+  auto bail = [&](int code) {
+    (void)settle_shard_slots(ix->ctx, nullptr);
+    drain(ix);
+    return code;
+  };
+  // slots other indexes (or the previous batch of this one) have left busy are retired one by one as they are needed: the device
+  // keeps working on them while this batch is being enqueued behind
+  for (int64_t i = 0; i < nsub; ++i) {
+    Slot &s = ix->slots[i % nslots];
+    if (s.busy) {
+      HIPCHK(hipEventSynchronize(s.ev_done));
+      s.busy = false;
+      account_timing(s.shard_owner ? s.shard_owner : ix, s);
+      s.shard_owner = nullptr;
+    }
+    const int nq = (int)std::min<int64_t>(Q, n_queries - i * Q);
+    rc = ensure_slot(ix, s, nq, false);
+    if (rc != BBQ_OK) return bail(rc);
+    ExtOut ext;
+    ext.lists = set.d_lists + (size_t)(i * Q) * list_cap;
+    ext.list_cap = list_cap;
+    ext.counts = set.d_counts + (size_t)(i * Q) * 2;
+    if (answers) {
+      ext.answers = reinterpret_cast<uint64_t *>(dev_answers) + (size_t)(i * Q) * (size_t)answers_stride;
+      ext.answers_stride = answers_stride;
+    }
+    rc = enqueue_subbatch(c, s, i * Q, nq, &ext);
+    if (rc != BBQ_OK) return bail(rc);
+    s.shard_owner = ix;
+  }
+  // the packing runs on the auxiliary stream behind the last sub-batch of every slot this batch has used
+  hipStream_t aux = ix->aux_stream;
+  for (int j = 0; j < nslots; ++j)
+    if (ix->slots[j].busy && ix->slots[j].shard_owner == ix) HIPCHK(hipStreamWaitEvent(aux, ix->slots[j].ev_done, 0));
+  // pack: [nq][list_cap] -> contiguous entries + offsets, what the host framework sends over RCCL
+  int64_t *d_total = reinterpret_cast<int64_t *>(set.d_counts + (size_t)n_queries * 2);
+  d_total = reinterpret_cast<int64_t *>(((uintptr_t)d_total + 7) & ~(uintptr_t)7);
+  HIPCHK(launch_pack(set.d_counts, set.d_lists, list_cap, ix->plan.list_cap, n_queries, reinterpret_cast<int64_t *>(dev_offsets),
+                     reinterpret_cast<int32_t *>(dev_flags), d_total, reinterpret_cast<uint64_t *>(dev_packed), packed_cap, aux));
+  HIPCHK(hipMemcpyAsync(set.h_total, d_total, 8, hipMemcpyDeviceToHost, aux));
+  HIPCHK(hipEventRecord(set.done, aux));
+  set.packed_cap = packed_cap;
+  set.in_flight = true;
+  ix->shard_begun += 1;
+  return BBQ_OK;
+}
+
+int bbq_shard_scan_wait(bbq_index *ix, int64_t *out_total) {
+  clear_error();
+  if (!ix || ix->multi || !ix->ctx) return fail(BBQ_ERR_INVALID_ARG, "bbq_shard_scan_wait: not a shard handle");
+  if (out_total) *out_total = 0;
+  hipEvent_t ev = nullptr;
+  bbq_index::ShardSet *set = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(ix->ctx->mu);
+    if (ix->shard_begun == ix->shard_waited) return fail(BBQ_ERR_INVALID_ARG, "bbq_shard_scan_wait: no batch in flight");
+    set = &ix->shard_set[ix->shard_waited & 1];
+    ev = set->done;
+  }
+  // outside the device mutex: the next batch is being enqueued by another thread meanwhile
+  hipError_t e = hipEventSynchronize(ev);
+  std::lock_guard<std::mutex> lk(ix->ctx->mu);
+  set->in_flight = false;
+  ix->shard_waited += 1;
+  if (e != hipSuccess) return fail(BBQ_ERR_HIP, "bbq_shard_scan_wait: %s", hipGetErrorString(e));
+  const int64_t total = *set->h_total;
+  if (out_total) *out_total = total;
+  if (total > set->packed_cap) return fail(BBQ_ERR_OOM, "bbq_shard_scan: %lld candidates do not fit packed_cap %lld", (long long)total, (long long)set->packed_cap);
+  return BBQ_OK;
 }
 
 int bbq_shard_scan(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, const double *qcorr, int32_t query_bits,
                    int32_t sim, int64_t k, void *dev_packed, int64_t packed_cap, void *dev_offsets, void *dev_flags,
                    int64_t *out_total) {
-  clear_error();
-  int rc = validate_query_args(ix, n_queries, qquant, qcorr, query_bits, sim, k);
-  if (rc != BBQ_OK) return rc;
   if (out_total) *out_total = 0;
-  if (n_queries == 0) return BBQ_OK;
-  if (!dev_packed || !dev_offsets || !dev_flags || !out_total || packed_cap <= 0)
-    return fail(BBQ_ERR_INVALID_ARG, "bbq_shard_scan: null output buffers");
-  if (k == 0 || k > kMaxFastK) return fail(BBQ_ERR_UNSUPPORTED, "bbq_shard_scan: k must be in 1..%lld", (long long)kMaxFastK);
-  if (ix->multi) return fail(BBQ_ERR_INVALID_ARG, "bbq_shard_scan: the handle is a multi-device index (it shards by itself)");
-  std::lock_guard<std::mutex> lk(ix->ctx->mu);
-  HIPCHK(hipSetDevice(ix->device));
-  BatchCtx c{ix, qquant, qcorr, planes_of_call(ix, qquant, (int64_t)n_queries * ix->dim, query_bits == 1), query_bits == 1 ? 1 : 0, sim, k};
-  build_plan(ix, k);
-  // per-query lists with room for a flood (rows stored cluster by cluster); what travels is packed, so the headroom costs
-  // device memory only
-  const int64_t list_cap = ix->plan.list_cap + std::min<int64_t>(ix->plan.flood_cap, 65536);
-  if (ix->shard_q_cap < n_queries || ix->shard_list_cap < list_cap) {  // per-query lists the finalize kernels build
-    if (ix->d_shard_lists) HIPCHK(hipFree(ix->d_shard_lists));
-    if (ix->d_shard_counts) HIPCHK(hipFree(ix->d_shard_counts));
-    ix->d_shard_lists = nullptr;
-    ix->d_shard_counts = nullptr;
-    HIPCHK(hipMalloc((void **)&ix->d_shard_lists, (size_t)n_queries * (size_t)list_cap * 8));
-    HIPCHK(hipMalloc((void **)&ix->d_shard_counts, (size_t)n_queries * 8 + 16));
-    ix->shard_q_cap = n_queries;
-    ix->shard_list_cap = list_cap;
+  if (n_queries == 0) {
+    clear_error();
+    return validate_query_args(ix, n_queries, qquant, qcorr, query_bits, sim, k);
   }
-  const int Q = effective_batch(ix);
-  const int nslots = std::min(std::max(1, ix->opt_slots), kMaxSlots);
-  const int64_t nsub = ((int64_t)n_queries + Q - 1) / Q;
-  auto retire = [&](Slot &s) -> int {
-    HIPCHK(hipEventSynchronize(s.ev_done));
-    s.busy = false;
-    account_timing(ix, s);
-    return BBQ_OK;
-  };
-  for (int64_t i = 0; i < nsub; ++i) {
-    Slot &s = ix->slots[i % nslots];
-    if (s.busy && (rc = retire(s)) != BBQ_OK) { drain(ix); return rc; }
-    const int nq = (int)std::min<int64_t>(Q, n_queries - i * Q);
-    rc = ensure_slot(ix, s, nq, false);
-    if (rc != BBQ_OK) { drain(ix); return rc; }
-    rc = enqueue_subbatch(c, s, i * Q, nq, ix->d_shard_lists + (size_t)(i * Q) * list_cap, list_cap, ix->d_shard_counts + (size_t)(i * Q) * 2);
-    if (rc != BBQ_OK) { drain(ix); return rc; }
-  }
-  for (int i = 0; i < nslots; ++i)
-    if (ix->slots[i].busy && (rc = retire(ix->slots[i])) != BBQ_OK) { drain(ix); return rc; }
-  // pack: [nq][list_cap] -> contiguous entries + offsets, what the host framework sends over RCCL
-  int64_t *d_total = reinterpret_cast<int64_t *>(ix->d_shard_counts + (size_t)n_queries * 2);
-  d_total = reinterpret_cast<int64_t *>(((uintptr_t)d_total + 7) & ~(uintptr_t)7);
-  HIPCHK(launch_pack(ix->d_shard_counts, ix->d_shard_lists, list_cap, ix->plan.list_cap, n_queries, reinterpret_cast<int64_t *>(dev_offsets),
-                     reinterpret_cast<int32_t *>(dev_flags), d_total, reinterpret_cast<uint64_t *>(dev_packed), packed_cap, ix->aux_stream));
-  int64_t total = 0;
-  HIPCHK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, ix->aux_stream));
-  HIPCHK(hipStreamSynchronize(ix->aux_stream));
-  *out_total = total;
-  if (total > packed_cap) return fail(BBQ_ERR_OOM, "bbq_shard_scan: %lld candidates do not fit packed_cap %lld", (long long)total, (long long)packed_cap);
-  return BBQ_OK;
+  if (!out_total) return fail(BBQ_ERR_INVALID_ARG, "bbq_shard_scan: null output buffers");
+  int rc = bbq_shard_scan_begin(ix, n_queries, qquant, qcorr, query_bits, sim, k, dev_packed, packed_cap, dev_offsets, dev_flags, nullptr, 0);
+  if (rc != BBQ_OK) return rc;
+  rc = bbq_shard_scan_wait(ix, out_total);
+  if (rc != BBQ_OK) return rc;
+  std::lock_guard<std::mutex> lk(ix->ctx->mu);  // the synchronous form leaves nothing in flight: timings are booked when it returns
+  return settle_shard_slots(ix->ctx, ix);
 }
 
 int bbq_get_stats(bbq_index *ix, bbq_stats *out) {
   if (!ix || !out) return fail(BBQ_ERR_INVALID_ARG, "bbq_get_stats: null");
   if (ix->multi) return multi_get_stats(ix, out);
+  if (ix->ctx) {
+    std::lock_guard<std::mutex> lk(ix->ctx->mu);
+    HIPCHK(hipSetDevice(ix->device));
+    int rc = settle_shard_slots(ix->ctx, ix);  // timings of an asynchronous scan are booked when its slots are retired
+    if (rc != BBQ_OK) return rc;
+    *out = ix->stats;
+    return BBQ_OK;
+  }
   *out = ix->stats;
   return BBQ_OK;
 }

@@ -146,8 +146,13 @@ struct FinalizeArgs {
   // the list on the host}, then the answer (global row << 32 | f32 score bits) descending by score: ONE device-to-host copy
   // brings everything the host needs
   uint64_t *final_out;
-  int32_t final_stride;        // >= final_k + 2
+  int32_t final_stride;        // >= final_k + 2 (+ 3 in shard mode)
   int32_t final_k;             // k2 = min(k, rows of the index)
+  // Shard mode (bbq_shard_scan_begin's dev_answers, include/bbq.h): this storage is one row shard of a larger index and the running top
+  // keys may include rows of a pilot replica, so the launch cannot prove an answer by itself.  It leaves what the merge needs instead:
+  // slot 1 = {m, unproven}, slot 2 = the cut = the (k2 + 1)-th largest key over every row this shard has seen (0: it has seen at most
+  // k2), then the m <= k2 listed rows above the cut, descending by score.  No tie check here: the merge checks the global answer.
+  int32_t final_shard;
 };
 constexpr int kFinalSelectMax = 1024;  // largest k2 the finalize kernel selects and sorts itself
 

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <atomic>
 #include <algorithm>
 #include <mutex>
@@ -93,11 +94,15 @@ struct Slot {
   bool replaying = false;
   std::atomic<int> pending{0};
   std::vector<std::vector<uint64_t>> tails;
+  std::vector<int64_t> host_cnt;  // entries of query i in its h_lists row (the rest, if any, in tails[i])
   std::vector<int> dense_q;
   int nq = 0;
   int64_t q_first = 0;
   bool timed = false;
   int64_t timed_rows = 0, timed_bytes = 0;
+  // non-null: the in-flight sub-batch belongs to an asynchronous sharded scan of that index (bbq_shard_scan_begin); nothing is to be
+  // collected from it but the timing.  Such slots stay busy ACROSS API calls: every entry point that uses the slots settles them first.
+  bbq_index *shard_owner = nullptr;
 };
 
 // Per-device context shared by every index on that device: streams, events and the per-slot workspace are expensive
@@ -148,10 +153,17 @@ struct bbq_index {
   uint32_t *d_aux_flags = nullptr;
   float *d_dense_all = nullptr;
   int64_t dense_all_cap = 0;
-  // bbq_shard_scan: per-query lists before packing
-  uint64_t *d_shard_lists = nullptr;
-  int32_t *d_shard_counts = nullptr;
-  int64_t shard_q_cap = 0, shard_list_cap = 0;
+  // bbq_shard_scan_begin / _wait: per-query lists before packing, two sets (two batches may be in flight) and their tickets
+  struct ShardSet {
+    uint64_t *d_lists = nullptr;
+    int32_t *d_counts = nullptr;  // [q_cap][2] + the packed total (int64) behind them
+    int64_t q_cap = 0, list_cap = 0;
+    hipEvent_t done = nullptr;    // recorded behind the packing of the batch
+    int64_t *h_total = nullptr;   // pinned
+    int64_t packed_cap = 0;
+    bool in_flight = false;
+  } shard_set[2];
+  int64_t shard_begun = 0, shard_waited = 0;  // batches begun / waited for: ticket t uses set t & 1
   // options
   int opt_batch = 0 /* 0: by index size, effective_batch() */, opt_slots = 2, opt_growth = 8, opt_force_dense = 0, opt_share = 1, opt_device_select = 1;
   // a call with few queries is latency-bound: every segment costs a dependent scan + finalize launch pair (~15-20 us), so such calls
@@ -170,12 +182,30 @@ struct bbq_index {
 };
 
 namespace bbq {
+// corrections layout asked for at creation: an explicit option wins, the environment variable only speaks for callers that passed none
+inline int want_compact_of(const bbq_index_options *opts) {
+  if (opts && opts->size >= (int32_t)sizeof(bbq_index_options) && opts->corrections != BBQ_CORRECTIONS_DEFAULT)
+    return opts->corrections == BBQ_CORRECTIONS_INLINE ? 0 : 1;
+  const char *e = getenv("BBQ_COMPACT_CORRECTIONS");
+  return (e && e[0] == '0') ? 0 : 1;
+}
+inline int check_options(const bbq_index_options *opts) {
+  if (!opts) return BBQ_OK;
+  if (opts->size < (int32_t)sizeof(bbq_index_options)) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_options.size is %d, this library expects at least %d", opts->size, (int)sizeof(bbq_index_options));
+  if (opts->corrections < BBQ_CORRECTIONS_DEFAULT || opts->corrections > BBQ_CORRECTIONS_COMPACT) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_options.corrections out of range: %d", opts->corrections);
+  return BBQ_OK;
+}
+// the integer dot product of one row must fit 31 bits: dim * 255 for packed 1-bit rows (query values <= 255), dim * 255 * 255 for multi-bit fields
+inline bool dim_supported(int64_t dim, int store_bits) { return dim * 255 * (store_bits > 1 ? 255 : 1) <= 0x7fffffffll; }
 // frees what the index owns; the device context (streams, workspace) stays.  Call with the context mutex held.
 void destroy_unlocked(bbq_index *ix);
 // rows already in device memory (codes in the caller's shape: packed bits, or one byte per dimension for a multi-bit index;
 // corrections [n][4]) -> tile records of `st`, deciding the index's layout on the way.  Context mutex held by the caller.
 int storage_from_device_rows(bbq_index *ix, Storage &st, const uint8_t *d_codes, const double *d_corr, int64_t n_rows, int64_t row_id_base,
                              bool check_x1);
+// waits for the slots an asynchronous sharded scan has left busy on this device (all, or only `owner`'s) and books their timing.
+// Context mutex held by the caller.
+int settle_shard_slots(DeviceCtx *ctx, bbq_index *owner);
 // every f32 score of one query on this (single-device) index, to host memory [n_rows]
 int dense_scores_host(bbq_index *ix, const uint8_t *qquant, const double *qcorr, int32_t query_bits, int32_t sim, float *out);
 // multi-device index (bbq_multi.cpp): what the entry points of a handle with ix->multi != nullptr dispatch to

@@ -747,16 +747,20 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
 
   if (a.final_out) {  // last segment: select and sort the answer on the device when that is provably what the heap returns
     const int k2 = a.final_k;
+    const bool shard = a.final_shard != 0;
+    const int hdr_slots = shard ? 3 : 2;
     const int64_t total = base + m_new;  // entries of the complete list
     const uint32_t tcount = (uint32_t)a.topk_counts[q];
-    bool ok = f_all == 0 && a.emit && total <= a.list_cap && k2 >= 1 && k2 <= kFinalSelectMax && k2 + 2 <= a.final_stride &&
-              m_new <= (uint32_t)kFinalizeKeyCap - tcount;
+    bool ok = f_all == 0 && a.emit && total <= a.list_cap && k2 >= 1 && k2 <= kFinalSelectMax && k2 + hdr_slots <= a.final_stride &&
+              m_new <= (uint32_t)kFinalizeKeyCap - tcount && a.k == k2 + 1;
     uint64_t *__restrict__ s_sel = reinterpret_cast<uint64_t *>(s_jobs);  // the copy jobs are done with
     auto bits_of = [](uint32_t key) -> uint32_t { return (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key; };
     uint32_t n_sel = 0, th1 = 0;  // rows with key > th1 are the answer
-    const bool take_all = total <= (int64_t)k2;
+    // single index: a list of at most k2 rows holds every row of the index.  Shard: fewer than k2 + 1 rows SEEN (pilot replica included)
+    // means no cut exists yet and every listed row stays in the running
+    const bool take_all = shard ? (m_new + tcount < (uint32_t)(k2 + 1)) : (total <= (int64_t)k2);
     if (ok && !take_all) {
-      // the (k2 + 1)-th largest key of the whole index = the (k2 + 1)-th largest of {running top keys (the k2 + 1 largest of the
+      // the (k2 + 1)-th largest key of everything seen = the (k2 + 1)-th largest of {running top keys (the k2 + 1 largest of the
       // earlier segments, a.k == k2 + 1) U this segment's keys}; s_keys[0, m_new) still holds the latter
       const uint32_t *__restrict__ tk = a.topk_keys + (size_t)q * a.k;
       for (uint32_t i = tid; i < tcount; i += kFinalizeThreads) s_keys[m_new + i] = tk[i];
@@ -764,7 +768,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
       const uint32_t M4 = (M + 3u) & ~3u;
       if (tid < (int)(M4 - M)) s_keys[M + tid] = 0u;  // key 0 is below every key of a finite score
       __syncthreads();
-      if (a.k != k2 + 1 || M < (uint32_t)(k2 + 1)) {
+      if (M < (uint32_t)(k2 + 1)) {
         ok = false;  // uniform
       } else if (M <= 2048u) {
         // few keys: the wanted key X is the one with  #(keys > X) <= k2 < #(keys >= X)  - counted per key, two barriers in all
@@ -800,13 +804,15 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
       }
       __syncthreads();
       n_sel = s_misc[2];
-      // exactly k2 rows above the boundary (fewer: the boundary value repeats; a list shorter than k2 + 1 rows holds them all)
-      ok = take_all ? (n_sel == (uint32_t)total) : (n_sel == (uint32_t)k2);
+      // single index: exactly k2 rows above the boundary (fewer: the boundary value repeats; a list shorter than k2 + 1 rows holds them
+      // all).  Shard: at most k2 rows lie above an order statistic of rank k2 + 1, however many of them are this shard's own
+      ok = shard ? (n_sel <= (uint32_t)k2) : take_all ? (n_sel == (uint32_t)total) : (n_sel == (uint32_t)k2);
     }
     if (ok) {
       // sort by counting (no barriers): the place of a row = the number of rows above it.  Equal scores (as floats: +0 == -0)
-      // anywhere in the answer or at its boundary mean that the heap's history decides: flagged, the host replays
-      uint64_t *__restrict__ fo = a.final_out + (size_t)q * a.final_stride + 2;
+      // anywhere in the answer or at its boundary mean that the heap's history decides: flagged, the host replays (a shard leaves
+      // that check to the merge, which sees the global answer)
+      uint64_t *__restrict__ fo = a.final_out + (size_t)q * a.final_stride + hdr_slots;
       const float fth = __uint_as_float(bits_of(th1));
       for (uint32_t i = tid; i < n_sel; i += kFinalizeThreads) {
         const uint64_t x = s_sel[i];
@@ -817,7 +823,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
           rank += y > x ? 1u : 0u;
           same += __uint_as_float(bits_of((uint32_t)(y >> 32))) == fx ? 1u : 0u;
         }
-        if (same > 1u || (!take_all && fx == fth)) s_misc[3] = 1;
+        if (!shard && (same > 1u || (!take_all && fx == fth))) s_misc[3] = 1;
         fo[rank] = ((uint64_t)(uint32_t)x << 32) | bits_of((uint32_t)(x >> 32));
       }
       __syncthreads();
@@ -828,6 +834,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
       const uint32_t listed = a.emit ? (uint32_t)min((int64_t)(base + m_new), a.list_cap) : 0u;
       hdr[0] = (uint64_t)listed | ((uint64_t)f_all << 32);
       hdr[1] = (uint64_t)(ok ? n_sel : 0u) | ((uint64_t)(ok ? 0u : 1u) << 32);
+      if (shard) hdr[2] = (ok && !take_all) ? (uint64_t)th1 : 0ull;
     }
   }
 }
@@ -880,9 +887,9 @@ __global__ __launch_bounds__(256) void bbq_retile_kernel(const uint8_t *__restri
 }
 
 // multi-bit index: unpacked rows (one byte per dimension, [n][dim]) -> store_bits-wide fields in tile records; the corrections
-// block is written exactly as above.  A code that does not fit its field raises *bad (the index is refused).
+// block is written exactly as above.  A code that is not below 2^index_bits raises *bad (the index is refused).
 __global__ __launch_bounds__(256) void bbq_retile_multibit_kernel(const uint8_t *__restrict__ codes, const double *__restrict__ corr,
-                                                                 int64_t n_rows, int32_t dim, int32_t store_bits, uint8_t *__restrict__ tiles,
+                                                                 int64_t n_rows, int32_t dim, int32_t store_bits, int32_t index_bits, uint8_t *__restrict__ tiles,
                                                                  int32_t w16, int32_t tile_stride, int32_t has_x1, int64_t n_rows_padded,
                                                                  int32_t layout, double *__restrict__ exact, uint32_t *__restrict__ bad) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -897,14 +904,14 @@ __global__ __launch_bounds__(256) void bbq_retile_multibit_kernel(const uint8_t 
     if (row < n_rows) {
       const int per_dword = 32 / store_bits;
       const uint8_t *src = codes + row * (int64_t)dim;
-      const uint32_t limit = 1u << store_bits;
+      const uint32_t limit = 1u << index_bits, field = (1u << store_bits) - 1u;  // values of an indexBits-bit quantizer are < 2^indexBits (include/bbq.h)
       for (int t = 0; t < 4; ++t)
         for (int f = 0; f < per_dword; ++f) {
           const int d = (j * 4 + t) * per_dword + f;
           if (d < dim) {
             const uint32_t v = src[d];
             if (v >= limit) atomicOr(bad, 1u);
-            w[t] |= (v & (limit - 1u)) << (f * store_bits);
+            w[t] |= (v & field) << (f * store_bits);
           }
         }
     }
@@ -1162,13 +1169,13 @@ hipError_t launch_retile(const uint8_t *codes, const double *corr, int64_t n_row
   return hipGetLastError();
 }
 
-hipError_t launch_retile_multibit(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim, int32_t store_bits, uint8_t *tiles,
+hipError_t launch_retile_multibit(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim, int32_t store_bits, int32_t index_bits, uint8_t *tiles,
                                   int32_t w16, int32_t tile_stride, int32_t has_x1, int32_t layout, double *exact, uint32_t *bad, hipStream_t s) {
   const int64_t n_pad = (n_rows + kTileRows - 1) / kTileRows * kTileRows;
   const int64_t threads = n_pad * (w16 + 1);
   if (threads == 0) return hipSuccess;
   const int64_t blocks = (threads + 255) / 256;
-  hipLaunchKernelGGL(bbq_retile_multibit_kernel, dim3((unsigned)blocks), dim3(256), 0, s, codes, corr, n_rows, dim, store_bits, tiles, w16,
+  hipLaunchKernelGGL(bbq_retile_multibit_kernel, dim3((unsigned)blocks), dim3(256), 0, s, codes, corr, n_rows, dim, store_bits, index_bits, tiles, w16,
                      tile_stride, has_x1, n_pad, layout, exact, bad);
   return hipGetLastError();
 }

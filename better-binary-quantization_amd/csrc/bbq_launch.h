@@ -20,8 +20,8 @@ hipError_t launch_pack(const int32_t *counts, const uint64_t *lists, int64_t lis
                        int32_t *flags_out, int64_t *total_out, uint64_t *packed, int64_t packed_cap, hipStream_t s);
 hipError_t launch_retile(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t pb, uint8_t *tiles, int32_t w16,
                          int32_t tile_stride, int32_t has_x1, int32_t layout, double *exact, hipStream_t s);
-// multi-bit index (store_bits 2 / 4 / 8): codes are unpacked rows [n][dim]; *bad is raised by a code that does not fit its field
-hipError_t launch_retile_multibit(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim, int32_t store_bits, uint8_t *tiles,
+// multi-bit index (store_bits 2 / 4 / 8): codes are unpacked rows [n][dim]; *bad is raised by a code that is not below 2^index_bits
+hipError_t launch_retile_multibit(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim, int32_t store_bits, int32_t index_bits, uint8_t *tiles,
                                   int32_t w16, int32_t tile_stride, int32_t has_x1, int32_t layout, double *exact, uint32_t *bad, hipStream_t s);
 hipError_t launch_check_x1_multibit(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim, uint32_t *mismatch, hipStream_t s);
 // compact layout: each tile's {min, max} of additionalCorrection (read from exact[]) -> add_range[tile][2]

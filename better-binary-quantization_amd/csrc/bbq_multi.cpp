@@ -7,13 +7,18 @@
 //   shard s = rows [r_s, r_{s+1}) on device d_s (contiguous, ascending: global row order is what the exact heap replay needs),
 //             every shard but the first with a PILOT REPLICA of the global prefix so that it derives valid thresholds without
 //             waiting for the shards before it (bbq_index_create_shard)
-//   search  = per round of queries: one worker thread per shard sweeps its shard (bbq_shard_scan: candidates packed in that
-//             device's memory) and copies offsets / flags / packed entries to pinned host memory over ITS OWN PCIe link; the
-//             calling thread replays the reference heap over the shards' lists in shard order (bbq_replay_batch) while the
-//             workers already sweep the next round (two buffer sets).
-// There is no device-to-device step: the merge is a host heap replay, so a gather to one GPU (RCCL / xGMI) would only add a
-// hop before the same D2H copy; the one-process-per-GPU deployment (torch.distributed over RCCL) is python/bbq_amd/distributed.py.
-// A query some shard cannot bound (NaN scores, a flood beyond every buffer, k > 4096) is scored densely on every shard and
+//   search  = per round of queries: one worker thread per shard enqueues the sweep of its shard (bbq_shard_scan_begin: the shard's
+//             own top rows above its cut - the SHARD-LOCAL ANSWER, k + 3 words per query - and the packed candidate lists stay in
+//             that device's memory) and lands the answers in pinned host memory over ITS OWN PCIe link; the calling thread merges
+//             the shards' answers (bbq_merge_answers: an S-way merge of k entries each plus the proof that the reference heap
+//             returns exactly that) while the workers' next round is already running on the devices (two buffer sets, the sweep of
+//             round r + 1 is enqueued before round r is waited for).  Only a query whose answer has equal scores in or at the edge
+//             of it needs its lists: they are fetched for that round and the heap is replayed (bbq_replay), as every query was
+//             before ABI 3.
+// There is no device-to-device step: the merge is host work of microseconds per query, so a gather to one GPU (RCCL / xGMI) would
+// only add a hop before the same D2H copy; the one-process-per-GPU deployment (torch.distributed over RCCL) is
+// python/bbq_amd/distributed.py.
+// A query some shard cannot bound (NaN scores, a flood beyond every buffer) or k > 4096 is scored densely on every shard and
 // replayed row by row: exact, slow, rare.
 #include <hip/hip_runtime.h>
 #include <string.h>
@@ -73,13 +78,17 @@ class ShardWorker {
   std::thread th_;
 };
 
-struct ShardBuf {  // one round's output of one shard: packed on the device, landed in pinned host memory
+struct ShardBuf {  // one round's output of one shard: answers + packed lists on the device, answers landed in pinned host memory
   uint64_t *d_packed = nullptr, *h_packed = nullptr;
   int64_t *d_offsets = nullptr, *h_offsets = nullptr;
   int32_t *d_flags = nullptr, *h_flags = nullptr;
-  int64_t packed_cap = 0;
+  uint64_t *d_answers = nullptr, *h_answers = nullptr;
+  int64_t answers_stride = 0;
+  hipEvent_t landed = nullptr;  // behind the copy of the answers
+  int64_t packed_cap = 0, h_packed_cap = 0;
   int32_t q_cap = 0;
   int64_t total = 0;
+  bool lists_on_host = false;
   int rc = BBQ_OK;
   std::string err;
 };
@@ -100,6 +109,7 @@ struct MultiState {
   std::mutex done_mu;
   std::condition_variable done_cv;
   std::vector<int> done_count;  // per round: shards finished
+  int fetch_count = 0;          // shards that have landed their lists for the round being merged
 };
 
 }  // namespace bbq
@@ -110,41 +120,75 @@ void free_buf(ShardBuf &b) {
   if (b.d_packed) (void)hipFree(b.d_packed);
   if (b.d_offsets) (void)hipFree(b.d_offsets);
   if (b.d_flags) (void)hipFree(b.d_flags);
+  if (b.d_answers) (void)hipFree(b.d_answers);
   if (b.h_packed) (void)hipHostFree(b.h_packed);
   if (b.h_offsets) (void)hipHostFree(b.h_offsets);
+  if (b.h_answers) (void)hipHostFree(b.h_answers);
   if (b.h_flags) (void)hipHostFree(b.h_flags);
+  if (b.landed) (void)hipEventDestroy(b.landed);
   b = ShardBuf();
 }
 
 int ensure_buf(MultiShard &sh, ShardBuf &b, int32_t nq, int64_t k) {
   const int64_t want = std::max<int64_t>(bbq_shard_list_cap(sh.ix, k), 1024) * nq;
-  if (b.q_cap >= nq && b.packed_cap >= want) return BBQ_OK;
+  const int64_t stride = k + 3;
+  if (b.q_cap >= nq && b.packed_cap >= want && b.answers_stride >= stride) return BBQ_OK;
   HIPCHK(hipSetDevice(sh.device));
   free_buf(b);
   HIPCHK(hipMalloc((void **)&b.d_packed, (size_t)want * 8));
   HIPCHK(hipMalloc((void **)&b.d_offsets, (size_t)(nq + 1) * 8));
   HIPCHK(hipMalloc((void **)&b.d_flags, (size_t)nq * 4));
-  HIPCHK(hipHostMalloc((void **)&b.h_packed, (size_t)want * 8, hipHostMallocDefault));
+  HIPCHK(hipMalloc((void **)&b.d_answers, (size_t)nq * (size_t)stride * 8));
   HIPCHK(hipHostMalloc((void **)&b.h_offsets, (size_t)(nq + 1) * 8, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void **)&b.h_answers, (size_t)nq * (size_t)stride * 8, hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void **)&b.h_flags, (size_t)nq * 4, hipHostMallocDefault));
+  HIPCHK(hipEventCreateWithFlags(&b.landed, hipEventDisableTiming));
   b.packed_cap = want;
   b.q_cap = nq;
+  b.answers_stride = stride;
   return BBQ_OK;
 }
 
-// one shard's part of one round: sweep, then land the packed lists in host memory
-int shard_round(MultiShard &sh, ShardBuf &b, int32_t nq, const uint8_t *qq, const double *qc, int32_t query_bits, int32_t sim, int64_t k) {
+// one shard's part of one round, first half: enqueue the sweep and, behind it, the copy of the answers to the host.  Returns at once.
+int shard_begin(MultiShard &sh, ShardBuf &b, int32_t nq, const uint8_t *qq, const double *qc, int32_t query_bits, int32_t sim, int64_t k,
+                bool answers) {
   int rc = ensure_buf(sh, b, nq, k);
   if (rc != BBQ_OK) return rc;
   b.total = 0;
-  rc = bbq_shard_scan(sh.ix, nq, qq, qc, query_bits, sim, k, b.d_packed, b.packed_cap, b.d_offsets, b.d_flags, &b.total);
+  b.lists_on_host = false;
+  rc = bbq_shard_scan_begin(sh.ix, nq, qq, qc, query_bits, sim, k, b.d_packed, b.packed_cap, b.d_offsets, b.d_flags, answers ? b.d_answers : nullptr,
+                            b.answers_stride);
   if (rc != BBQ_OK) return rc;
   HIPCHK(hipSetDevice(sh.device));
-  hipStream_t st = sh.ix->aux_stream;
-  HIPCHK(hipMemcpyAsync(b.h_offsets, b.d_offsets, (size_t)(nq + 1) * 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(b.h_flags, b.d_flags, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-  if (b.total > 0) HIPCHK(hipMemcpyAsync(b.h_packed, b.d_packed, (size_t)b.total * 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  hipStream_t st = sh.ix->aux_stream;  // the stream the packing of this batch was enqueued on
+  if (answers) HIPCHK(hipMemcpyAsync(b.h_answers, b.d_answers, (size_t)nq * (size_t)b.answers_stride * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(b.landed, st));
+  return BBQ_OK;
+}
+
+// second half: wait for the sweep and the copy
+int shard_finish(MultiShard &sh, ShardBuf &b) {
+  int rc = bbq_shard_scan_wait(sh.ix, &b.total);
+  if (rc != BBQ_OK) return rc;
+  HIPCHK(hipSetDevice(sh.device));
+  HIPCHK(hipEventSynchronize(b.landed));
+  return BBQ_OK;
+}
+
+// the round's packed lists to host memory (only when some query of the round needs its heap replayed)
+int shard_fetch_lists(MultiShard &sh, ShardBuf &b, int32_t nq) {
+  HIPCHK(hipSetDevice(sh.device));
+  if (b.h_packed_cap < std::max<int64_t>(b.total, 1)) {
+    if (b.h_packed) HIPCHK(hipHostFree(b.h_packed));
+    b.h_packed = nullptr;
+    b.h_packed_cap = std::max<int64_t>(b.total, 1024) * 5 / 4;
+    HIPCHK(hipHostMalloc((void **)&b.h_packed, (size_t)b.h_packed_cap * 8, hipHostMallocDefault));
+  }
+  // a stream of its own would be one more object per shard: the null stream serves this rare path (the shard's other streams are non-blocking)
+  HIPCHK(hipMemcpy(b.h_offsets, b.d_offsets, (size_t)(nq + 1) * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(b.h_flags, b.d_flags, (size_t)nq * 4, hipMemcpyDeviceToHost));
+  if (b.total > 0) HIPCHK(hipMemcpy(b.h_packed, b.d_packed, (size_t)b.total * 8, hipMemcpyDeviceToHost));
+  b.lists_on_host = true;
   return BBQ_OK;
 }
 
@@ -199,18 +243,34 @@ int multi_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, 
   const int S = (int)ms->shards.size();
   const int R = std::max(1, ms->round_queries);
   const int64_t rounds = ((int64_t)n_queries + R - 1) / R;
+  const bool answers = keff <= kFinalSelectMax && ix->opt_device_select;
   {
     std::lock_guard<std::mutex> dl(ms->done_mu);
     ms->done_count.assign((size_t)rounds, 0);
   }
-  auto post_round = [&](int64_t r) {
+  // every shard's worker is a FIFO: begin(r) enqueues round r's sweep and returns, finish(r) waits for it.  Posted as
+  // begin(0) begin(1) finish(0) finish(1) | begin(2) finish(2) | ... so that a device always has the next round queued behind the one
+  // being waited for
+  auto post_begin = [&](int64_t r) {
     const int32_t q0 = (int32_t)(r * R), nq = (int32_t)std::min<int64_t>(R, n_queries - r * R);
     for (int s = 0; s < S; ++s) {
       MultiShard *sh = &ms->shards[(size_t)s];
       ShardBuf *b = &sh->buf[r & 1];
-      sh->worker->post([ms, sh, b, r, nq, q0, qquant, qcorr, query_bits, sim, keff, dim] {
-        b->rc = shard_round(*sh, *b, nq, qquant + (size_t)q0 * dim, qcorr + (size_t)q0 * 4, query_bits, sim, keff);
+      sh->worker->post([sh, b, nq, q0, qquant, qcorr, query_bits, sim, keff, dim, answers] {
+        b->rc = shard_begin(*sh, *b, nq, qquant + (size_t)q0 * dim, qcorr + (size_t)q0 * 4, query_bits, sim, keff, answers);
         if (b->rc != BBQ_OK) b->err = bbq_last_error();
+      });
+    }
+  };
+  auto post_finish = [&](int64_t r) {
+    for (int s = 0; s < S; ++s) {
+      MultiShard *sh = &ms->shards[(size_t)s];
+      ShardBuf *b = &sh->buf[r & 1];
+      sh->worker->post([ms, sh, b, r] {
+        if (b->rc == BBQ_OK) {
+          b->rc = shard_finish(*sh, *b);
+          if (b->rc != BBQ_OK) b->err = bbq_last_error();
+        }
         {
           std::lock_guard<std::mutex> dl(ms->done_mu);
           ms->done_count[(size_t)r] += 1;
@@ -223,12 +283,46 @@ int multi_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, 
     std::unique_lock<std::mutex> dl(ms->done_mu);
     ms->done_cv.wait(dl, [&] { return ms->done_count[(size_t)r] == S; });
   };
-  int64_t posted = 0;
-  for (; posted < std::min<int64_t>(rounds, 2); ++posted) post_round(posted);
+  // the lists of round r on the host (rare): every worker copies its shard's, the caller waits for all of them
+  auto fetch_lists = [&](int64_t r, int32_t nq) -> int {
+    {
+      std::lock_guard<std::mutex> dl(ms->done_mu);
+      ms->fetch_count = 0;
+    }
+    for (int s = 0; s < S; ++s) {
+      MultiShard *sh = &ms->shards[(size_t)s];
+      ShardBuf *b = &sh->buf[r & 1];
+      sh->worker->post([ms, sh, b, nq] {
+        if (!b->lists_on_host) {
+          b->rc = shard_fetch_lists(*sh, *b, nq);
+          if (b->rc != BBQ_OK) b->err = bbq_last_error();
+        }
+        {
+          std::lock_guard<std::mutex> dl(ms->done_mu);
+          ms->fetch_count += 1;
+        }
+        ms->done_cv.notify_all();
+      });
+    }
+    std::unique_lock<std::mutex> dl(ms->done_mu);
+    ms->done_cv.wait(dl, [&] { return ms->fetch_count == S; });
+    for (int s = 0; s < S; ++s) {
+      ShardBuf &b = ms->shards[(size_t)s].buf[r & 1];
+      if (b.rc != BBQ_OK) return fail(b.rc, "%s", b.err.c_str());
+    }
+    return BBQ_OK;
+  };
+  const int64_t ahead = std::min<int64_t>(rounds, 2);
+  for (int64_t r = 0; r < ahead; ++r) post_begin(r);
+  for (int64_t r = 0; r < ahead; ++r) post_finish(r);
+  int64_t posted = ahead;
   int rc_all = BBQ_OK;
   std::string err_all;
-  std::vector<const bbq_cand *> packed((size_t)S);
-  std::vector<const int64_t *> offsets((size_t)S);
+  std::vector<const uint64_t *> blocks((size_t)S);
+  std::vector<int64_t> strides((size_t)S);
+  std::vector<const bbq_cand *> lists((size_t)S);
+  std::vector<int64_t> counts((size_t)S);
+  std::vector<uint8_t> status;
   for (int64_t r = 0; r < rounds; ++r) {
     wait_round(r);
     const int32_t q0 = (int32_t)(r * R), nq = (int32_t)std::min<int64_t>(R, n_queries - r * R);
@@ -236,25 +330,43 @@ int multi_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, 
       for (int s = 0; s < S; ++s) {
         ShardBuf &b = ms->shards[(size_t)s].buf[r & 1];
         if (b.rc != BBQ_OK && rc_all == BBQ_OK) { rc_all = b.rc; err_all = b.err; }
-        packed[(size_t)s] = b.h_packed;
-        offsets[(size_t)s] = b.h_offsets;
+        blocks[(size_t)s] = b.h_answers;
+        strides[(size_t)s] = b.answers_stride;
       }
     }
     if (rc_all == BBQ_OK) {
-      ix->stats.host_replays += nq;
-      rc_all = bbq_replay_batch(S, packed.data(), offsets.data(), nq, ix->n_rows, k, ix->opt_replay_threads, out_idx + (int64_t)q0 * k,
-                                out_score + (int64_t)q0 * k, out_n + q0);
-      if (rc_all != BBQ_OK) err_all = bbq_last_error();
+      status.assign((size_t)nq, 1);
+      if (answers) {
+        rc_all = bbq_merge_answers(S, blocks.data(), strides.data(), nq, ix->n_rows, k, ix->opt_replay_threads, out_idx + (int64_t)q0 * k,
+                                   out_score + (int64_t)q0 * k, out_n + q0, status.data());
+        if (rc_all != BBQ_OK) err_all = bbq_last_error();
+      }
+      bool need_lists = false;
+      for (int32_t q = 0; q < nq; ++q) need_lists = need_lists || status[(size_t)q] != 0;
+      if (rc_all == BBQ_OK && need_lists) {
+        rc_all = fetch_lists(r, nq);
+        if (rc_all != BBQ_OK) err_all = bbq_last_error();
+      }
       for (int32_t q = 0; q < nq && rc_all == BBQ_OK; ++q) {
-        bool flagged = false;
+        if (status[(size_t)q] == 0) { ix->stats.candidates += keff; continue; }
+        const int64_t qi = q0 + q;
+        bool flagged = status[(size_t)q] == 2;
         int64_t cand = 0;
         for (int s = 0; s < S; ++s) {
           const ShardBuf &b = ms->shards[(size_t)s].buf[r & 1];
-          flagged = flagged || b.h_flags[q] != 0;
-          cand += b.h_offsets[q + 1] - b.h_offsets[q];
+          lists[(size_t)s] = b.h_packed + b.h_offsets[q];
+          counts[(size_t)s] = b.h_offsets[q + 1] - b.h_offsets[q];
+          cand += counts[(size_t)s];
         }
-        if (!flagged) { ix->stats.candidates += cand; continue; }
-        const int64_t qi = q0 + q;
+        if (!answers)  // no answer blocks in this call (k > 1024, device_select 0): the shards' flags came with the lists
+          for (int s = 0; s < S; ++s) flagged = flagged || ms->shards[(size_t)s].buf[r & 1].h_flags[q] != 0;
+        if (!flagged) {
+          ix->stats.host_replays += 1;
+          ix->stats.candidates += cand;
+          rc_all = bbq_replay(S, lists.data(), counts.data(), ix->n_rows, k, out_idx + qi * k, out_score + qi * k, out_n + qi);
+          if (rc_all != BBQ_OK) err_all = bbq_last_error();
+          continue;
+        }
         rc_all = dense_query(ix, qquant + (size_t)qi * dim, qcorr + (size_t)qi * 4, query_bits, sim, k, out_idx + qi * k, out_score + qi * k, out_n + qi);
         if (rc_all != BBQ_OK) err_all = bbq_last_error();
         ix->stats.dense_fallbacks += 1;
@@ -262,7 +374,11 @@ int multi_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, 
       }
     }
     // the buffers of round r are free again: round r + 2 may start (every posted round is waited for, also after an error)
-    if (posted < rounds) post_round(posted++);
+    if (posted < rounds) {
+      post_begin(posted);
+      post_finish(posted);
+      ++posted;
+    }
   }
   if (rc_all != BBQ_OK) return fail(rc_all, "%s", err_all.c_str());
   return BBQ_OK;
@@ -309,19 +425,24 @@ int multi_set_option(bbq_index *ix, const char *name, int64_t v) {
   const std::string n(name);
   if (n == "replay_threads") ix->opt_replay_threads = (int)v;
   if (n == "force_dense") ix->opt_force_dense = (int)v;
+  if (n == "device_select") ix->opt_device_select = (int)v;  // 0: no shard-local answers, every query replays its lists (the ABI-2 path)
   return BBQ_OK;
 }
 
 int multi_get_stats(bbq_index *ix, bbq_stats *out) {
   MultiState *ms = ix->multi;
-  bbq_stats agg = ix->stats;  // candidates / dense_fallbacks of the merged lists
+  std::lock_guard<std::mutex> lk(ms->mu);
+  bbq_stats agg = ix->stats;  // candidates / dense_fallbacks / host_replays of the merged answers
+  // the shards sweep side by side: the time of a sweep is the slowest shard's, the bytes are everybody's
   for (MultiShard &sh : ms->shards) {
     bbq_stats s{};
     if (bbq_get_stats(sh.ix, &s) != BBQ_OK) continue;
-    if (s.last_scan_ms > agg.last_scan_ms) { agg.last_scan_ms = s.last_scan_ms; agg.last_scan_rows = s.last_scan_rows; agg.last_scan_bytes = s.last_scan_bytes; }
-    agg.total_scan_ms += s.total_scan_ms;
+    agg.last_scan_ms = std::max(agg.last_scan_ms, s.last_scan_ms);
+    agg.last_scan_rows += s.last_scan_rows;
+    agg.last_scan_bytes += s.last_scan_bytes;
+    agg.total_scan_ms = std::max(agg.total_scan_ms, s.total_scan_ms);
     agg.total_scan_bytes += s.total_scan_bytes;
-    agg.total_scan_launches += s.total_scan_launches;
+    agg.total_scan_launches = std::max(agg.total_scan_launches, s.total_scan_launches);
   }
   *out = agg;
   return BBQ_OK;
@@ -329,6 +450,7 @@ int multi_get_stats(bbq_index *ix, bbq_stats *out) {
 
 int multi_reset_stats(bbq_index *ix) {
   MultiState *ms = ix->multi;
+  std::lock_guard<std::mutex> lk(ms->mu);
   ix->stats = bbq_stats{};
   for (MultiShard &sh : ms->shards) (void)bbq_reset_stats(sh.ix);
   return BBQ_OK;
@@ -340,6 +462,11 @@ extern "C" {
 
 int bbq_index_create_multi(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim, int32_t index_bits, double centroid_dp,
                            int32_t n_shards, const int32_t *devices, int64_t pilot_rows, bbq_index **out) {
+  return bbq_index_create_multi_opts(codes, corr, n_rows, dim, index_bits, centroid_dp, n_shards, devices, pilot_rows, nullptr, out);
+}
+
+int bbq_index_create_multi_opts(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim, int32_t index_bits, double centroid_dp,
+                                int32_t n_shards, const int32_t *devices, int64_t pilot_rows, const bbq_index_options *opts, bbq_index **out) {
   clear_error();
   if (!out) return fail(BBQ_ERR_INVALID_ARG, "bbq_index_create_multi: out is null");
   *out = nullptr;
@@ -355,6 +482,10 @@ int bbq_index_create_multi(const uint8_t *codes, const double *corr, int64_t n_r
     if (d < 0 || d >= ndev) return fail(BBQ_ERR_INVALID_ARG, "device %d out of range (0..%d)", d, ndev - 1);
   }
   if (n_rows > 0xFFFFFFFFll) return fail(BBQ_ERR_UNSUPPORTED, "more than 2^32 rows");
+  if (check_options(opts) != BBQ_OK) return BBQ_ERR_INVALID_ARG;
+  // one layout decision for all shards: every shard is created with the explicit value (a shard whose sums are not the popcounts
+  // still falls back to inline on its own; bytes_per_row then reports the largest)
+  bbq_index_options shard_opts{(int32_t)sizeof(bbq_index_options), want_compact_of(opts) ? BBQ_CORRECTIONS_COMPACT : BBQ_CORRECTIONS_INLINE};
 
   std::unique_ptr<bbq_index> ix(new bbq_index());
   ix->dim = dim;
@@ -383,17 +514,21 @@ int bbq_index_create_multi(const uint8_t *codes, const double *corr, int64_t n_r
     sh.r1 = r1;
     int64_t P = 0;
     if (r0 > 0) P = pilot_rows >= r0 ? r0 : pilot_rows / kChunkRows * kChunkRows;
-    int rc = bbq_index_create_shard(codes ? codes + r0 * row_bytes : nullptr, corr ? corr + r0 * 4 : nullptr, r1 - r0, dim, index_bits, centroid_dp,
-                                    r0, P > 0 ? codes : nullptr, P > 0 ? corr : nullptr, P, sh.device, &sh.ix);
+    int rc = bbq_index_create_shard_opts(codes ? codes + r0 * row_bytes : nullptr, corr ? corr + r0 * 4 : nullptr, r1 - r0, dim, index_bits, centroid_dp,
+                                         r0, P > 0 ? codes : nullptr, P > 0 ? corr : nullptr, P, sh.device, &shard_opts, &sh.ix);
     if (rc != BBQ_OK) return bail(rc);
     sh.worker.reset(new ShardWorker());
     ms->shards.push_back(std::move(sh));
   }
-  bbq_index *first = ms->shards[0].ix;
-  ix->bytes_per_row = first->bytes_per_row;
-  ix->layout = first->layout;
-  ix->tile_stride = first->tile_stride;
-  ix->has_x1 = first->has_x1;
+  // every shard decides has_x1 (and with it a fallback to the inline layout) on its own rows: the handle reports the widest
+  for (const MultiShard &sh : ms->shards) {
+    if (sh.ix->bytes_per_row >= ix->bytes_per_row) {
+      ix->bytes_per_row = sh.ix->bytes_per_row;
+      ix->layout = sh.ix->layout;
+      ix->tile_stride = sh.ix->tile_stride;
+    }
+    ix->has_x1 = ix->has_x1 || sh.ix->has_x1;
+  }
   ix->multi = ms.release();
   *out = ix.release();
   return BBQ_OK;

@@ -61,7 +61,7 @@ int read_meta(const char *prefix, MetaHeader *h, std::vector<float> *centroid, u
   if (fread(h, sizeof *h, 1, fc.f) != 1) return fail(BBQ_ERR_INVALID_ARG, "%s: truncated header", path.c_str());
   if (memcmp(h->magic, "BVEC", 4) != 0) return fail(BBQ_ERR_INVALID_ARG, "%s: not a BVEC metadata file", path.c_str());
   if (h->version != kFileVersion) return fail(BBQ_ERR_UNSUPPORTED, "%s: format version %u (this build reads %u)", path.c_str(), h->version, kFileVersion);
-  if (h->dimensions <= 0 || h->dimensions > (1 << 24) || h->vectorCount < 0 || h->rowBase < 0 || h->indexBits < 1 || h->indexBits > 8 || h->tileRows != kTileRows ||
+  if (h->dimensions <= 0 || h->indexBits < 1 || h->indexBits > 8 || !dim_supported(h->dimensions, h->dimensions == 1 ? 1 : store_bits_of(h->indexBits)) || h->vectorCount < 0 || h->rowBase < 0 || h->indexBits < 1 || h->indexBits > 8 || h->tileRows != kTileRows ||
       (h->layout != kLayoutCompact && h->layout != kLayoutInline) || (h->hasX1 != 0 && h->hasX1 != 1) ||
       h->vectorSimilarityOrdinal < 0 || h->vectorSimilarityOrdinal > 2)
     return fail(BBQ_ERR_INVALID_ARG, "%s: header fields out of range", path.c_str());

@@ -11,6 +11,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <thread>
 #include <vector>
 #include "bbq_internal.h"
@@ -175,6 +176,97 @@ int bbq_replay_batch(int32_t n_sources, const bbq_cand *const *packed, const int
   }
   for (int32_t q = 0; q < n_queries; ++q)
     if (bad[(size_t)q]) return bbq::fail(BBQ_ERR_INVALID_ARG, "bbq_replay_batch: candidates of query %d not in ascending row order", q);
+  return BBQ_OK;
+}
+
+
+static inline uint32_t key_of_score_bits(uint32_t b) { return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+static inline float score_of_key(uint32_t key) {
+  const uint32_t b = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
+  float f;
+  memcpy(&f, &b, 4);
+  return f;
+}
+
+uint32_t bbq_key_of_score(float score) {
+  uint32_t b;
+  memcpy(&b, &score, 4);
+  return key_of_score_bits(b);
+}
+
+// The global answer from the shards' answer blocks (include/bbq.h, bbq_shard_scan_begin).  Every source s lists its own rows above
+// its cut c_s, and c_s never exceeds the key G of the global (k2 + 1)-th largest score; with C = max c_s the union E of the listed rows
+// above C is therefore EVERY row above C.  |E| >= k2 + 1: the k2 + 1 largest of E are the k2 + 1 largest of the index; |E| == k2: then
+// G == C and E is exactly the rows above the boundary; fewer: the boundary value repeats inside the answer.  Whenever the k2 best
+// scores and the boundary are pairwise different as floats the reference heap returns exactly those rows, descending (DESIGN.md
+// "Exact top-k"); otherwise its history decides and the caller replays it over the lists (status 1).
+int bbq_merge_answers(int32_t n_sources, const uint64_t *const *answers, const int64_t *strides, int32_t n_queries, int64_t n_total,
+                      int64_t k, int32_t n_threads, int32_t *out_idx, float *out_score, int64_t *out_n, uint8_t *status) {
+  bbq::clear_error();
+  if (n_sources <= 0 || n_sources > 4096 || !answers || !strides || n_queries < 0 || (n_queries > 0 && (!out_n || !status)))
+    return bbq::fail(BBQ_ERR_INVALID_ARG, "bbq_merge_answers: null argument");
+  if (k < 0) return bbq::fail(BBQ_ERR_NEGATIVE_K, "k值不能为负数");
+  if (k > 0 && n_queries > 0 && (!out_idx || !out_score)) return bbq::fail(BBQ_ERR_INVALID_ARG, "bbq_merge_answers: null output");
+  for (int32_t s = 0; s < n_sources; ++s)
+    if (!answers[s] || strides[s] < 3) return bbq::fail(BBQ_ERR_INVALID_ARG, "bbq_merge_answers: source %d has no block", s);
+  const int64_t k2 = std::min<int64_t>(k, n_total);
+  std::vector<int> bad((size_t)std::max(n_queries, 1), 0);
+  auto work = [&](int32_t lo, int32_t hi) {
+    std::vector<const uint64_t *> head((size_t)n_sources), end((size_t)n_sources);
+    std::vector<uint64_t> sel;
+    sel.reserve((size_t)k2 + 1);
+    for (int32_t q = lo; q < hi; ++q) {
+      uint32_t cut = 0, flags = 0, unproven = 0;
+      for (int32_t s = 0; s < n_sources; ++s) {
+        const uint64_t *b = answers[s] + (size_t)q * (size_t)strides[s];
+        flags |= (uint32_t)(b[0] >> 32);
+        unproven |= (uint32_t)(b[1] >> 32);
+        const uint64_t m = (uint32_t)b[1];
+        if ((int64_t)m + 3 > strides[s]) { bad[(size_t)q] = 1; unproven = 1; }
+        cut = std::max(cut, (uint32_t)b[2]);
+        head[(size_t)s] = b + 3;
+        end[(size_t)s] = b + 3 + ((int64_t)m + 3 > strides[s] ? 0 : m);
+      }
+      if (flags) { status[q] = 2; continue; }
+      if (unproven || k2 == 0) { status[q] = k2 == 0 ? 0 : 1; if (k2 == 0) out_n[q] = 0; continue; }
+      // the k2 + 1 largest entries above the cut, descending: S-way merge of descending lists
+      sel.clear();
+      while ((int64_t)sel.size() < k2 + 1) {
+        int best = -1;
+        uint32_t best_key = 0;
+        for (int32_t s = 0; s < n_sources; ++s) {
+          if (head[(size_t)s] == end[(size_t)s]) continue;
+          const uint32_t key = key_of_score_bits((uint32_t)*head[(size_t)s]);
+          if (best < 0 || key > best_key) { best = s; best_key = key; }
+        }
+        if (best < 0 || best_key <= cut) break;
+        sel.push_back(*head[(size_t)best]++);
+      }
+      const int64_t have = (int64_t)sel.size();
+      bool ok = have >= k2;
+      auto fscore = [](uint64_t e) { const uint32_t b = (uint32_t)e; float f; memcpy(&f, &b, 4); return f; };
+      for (int64_t j = 0; ok && j + 1 < have; ++j) ok = fscore(sel[(size_t)j]) != fscore(sel[(size_t)j + 1]);  // sorted: equal scores are neighbours (+0 / -0 too)
+      if (ok && have == k2 && cut != 0u) ok = fscore(sel[(size_t)k2 - 1]) != score_of_key(cut);       // the boundary is the cut itself
+      if (!ok) { status[q] = 1; continue; }
+      for (int64_t j = 0; j < k2; ++j) {
+        out_idx[(int64_t)q * k + j] = (int32_t)(uint32_t)(sel[(size_t)j] >> 32);
+        out_score[(int64_t)q * k + j] = fscore(sel[(size_t)j]);
+      }
+      out_n[q] = k2;
+      status[q] = 0;
+    }
+  };
+  int T = n_threads > 0 ? n_threads : 1;
+  if (T > n_queries / 64) T = std::max(1, n_queries / 64);  // a query merges in a few microseconds: threads only pay for large batches
+  if (T <= 1) {
+    work(0, n_queries);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(work, (int32_t)((int64_t)n_queries * t / T), (int32_t)((int64_t)n_queries * (t + 1) / T));
+    for (auto &x : th) x.join();
+  }
+  for (int32_t q = 0; q < n_queries; ++q)
+    if (bad[(size_t)q]) return bbq::fail(BBQ_ERR_INVALID_ARG, "bbq_merge_answers: query %d: an answer block claims more entries than its stride holds", q);
   return BBQ_OK;
 }
 

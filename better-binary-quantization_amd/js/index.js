@@ -116,24 +116,20 @@ class BinarizedByteVectorValuesImpl {
 }
 
 /**
- * Devices an index of `rows` rows is sharded over.  BBQ_DEVICES = a list of HIP ordinals ("0,1,2,3"; repeats allowed: several
- * shards on one GPU) or a count ("8" = devices 0..7); unset: every visible GPU once the index is large enough for the sharding to
- * pay (BBQ_SHARD_MIN_ROWS, default 4 M rows), else BBQ_DEVICE (default 0) alone.
+ * Devices an index of `rows` rows is sharded over.  Sharding is OPT-IN: BBQ_DEVICES = a list of HIP ordinals ("0,1,2,3"; repeats
+ * allowed: several shards on one GPU) or a count ("8" = devices 0..7), applied to indexes of at least BBQ_SHARD_MIN_ROWS rows
+ * (default 0: every index).  Unset: BBQ_DEVICE (default 0) alone - one GPU answers a single 10 M-row query in 0.2 ms, and the
+ * multi-GPU path has not been measured on more than one physical device yet (bench.py reports it when it has).
  */
 function shardDevices(rows) {
   const one = [Number(process.env.BBQ_DEVICE || 0)];
   const spec = process.env.BBQ_DEVICES;
-  if (spec !== undefined && spec !== '') {
+  if (spec !== undefined && spec !== '' && rows >= Number(process.env.BBQ_SHARD_MIN_ROWS || 0)) {
     if (spec.indexOf(',') >= 0) return spec.split(',').map(Number);
     const n = Number(spec);
     if (!(n >= 1)) return one;
     if (n === 1) return one;
     const out = []; for (let i = 0; i < n; i++) out.push(i);
-    return out;
-  }
-  const visible = native.deviceCount();
-  if (visible > 1 && rows >= Number(process.env.BBQ_SHARD_MIN_ROWS || 4000000)) {
-    const out = []; for (let i = 0; i < visible; i++) out.push(i);
     return out;
   }
   return one;

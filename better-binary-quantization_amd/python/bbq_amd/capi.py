@@ -23,6 +23,8 @@ SYMBOLS = [
     "bbq_reset_stats", "bbq_set_option", "bbq_vectors_create", "bbq_vectors_destroy", "bbq_vectors_size",
     "bbq_vectors_dimension", "bbq_rerank_scores", "bbq_search_rerank_batch", "bbq_index_save", "bbq_index_file_info",
     "bbq_index_load", "bbq_index_export", "bbq_quantize_queries",
+    "bbq_index_create_shard_opts", "bbq_index_create_multi_opts", "bbq_index_build_opts",
+    "bbq_shard_scan_begin", "bbq_shard_scan_wait", "bbq_merge_answers", "bbq_key_of_score",
 ]
 
 
@@ -30,6 +32,22 @@ class BBQError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(message)
         self.code = code
+
+
+class IndexOptions(C.Structure):
+    """bbq_index_options (include/bbq.h)"""
+    _fields_ = [("size", C.c_int32), ("corrections", C.c_int32)]
+
+
+CORRECTIONS_DEFAULT, CORRECTIONS_INLINE, CORRECTIONS_COMPACT = -1, 0, 1
+
+
+def _opts(corrections):
+    """corrections: None (library default) | "inline" | "compact" | a BBQ_CORRECTIONS_* ordinal"""
+    if corrections is None:
+        return None
+    v = {"inline": CORRECTIONS_INLINE, "compact": CORRECTIONS_COMPACT, "default": CORRECTIONS_DEFAULT}.get(corrections, corrections)
+    return C.byref(IndexOptions(C.sizeof(IndexOptions), int(v)))
 
 
 class Stats(C.Structure):
@@ -58,6 +76,9 @@ def lib():
     L.bbq_index_create.argtypes = [vp, vp, i64, i32, i32, dbl, i32, C.POINTER(vp)]
     L.bbq_index_create_shard.argtypes = [vp, vp, i64, i32, i32, dbl, i64, vp, vp, i64, i32, C.POINTER(vp)]
     L.bbq_index_create_multi.argtypes = [vp, vp, i64, i32, i32, dbl, i32, vp, i64, C.POINTER(vp)]
+    L.bbq_index_create_shard_opts.argtypes = [vp, vp, i64, i32, i32, dbl, i64, vp, vp, i64, i32, vp, C.POINTER(vp)]
+    L.bbq_index_create_multi_opts.argtypes = [vp, vp, i64, i32, i32, dbl, i32, vp, i64, vp, C.POINTER(vp)]
+    L.bbq_index_build_opts.argtypes = [vp, i64, i32, i32, i32, dbl, i32, i32, vp, C.POINTER(vp), vp, vp, vp, vp, vp]
     L.bbq_index_shards.argtypes = [vp]
     L.bbq_index_shards.restype = i32
     L.bbq_index_build.argtypes = [vp, i64, i32, i32, dbl, i32, i32, C.POINTER(vp), vp, vp, vp, vp, vp]
@@ -76,6 +97,11 @@ def lib():
     L.bbq_search_batch.argtypes = [vp, i32, vp, vp, i32, i32, i64, vp, vp, vp]
     L.bbq_score_rows.argtypes = [vp, vp, vp, i32, i32, i64, i64, vp, vp, vp]
     L.bbq_shard_scan.argtypes = [vp, i32, vp, vp, i32, i32, i64, vp, i64, vp, vp, C.POINTER(i64)]
+    L.bbq_shard_scan_begin.argtypes = [vp, i32, vp, vp, i32, i32, i64, vp, i64, vp, vp, vp, i64]
+    L.bbq_shard_scan_wait.argtypes = [vp, C.POINTER(i64)]
+    L.bbq_merge_answers.argtypes = [i32, vp, vp, i32, i64, i64, i32, vp, vp, vp, vp]
+    L.bbq_key_of_score.argtypes = [C.c_float]
+    L.bbq_key_of_score.restype = C.c_uint32
     L.bbq_shard_list_cap.argtypes = [vp, i64]
     L.bbq_shard_list_cap.restype = i64
     L.bbq_replay.argtypes = [i32, vp, vp, i64, i64, vp, vp, vp]
@@ -172,7 +198,7 @@ def centroid_dp(centroid):
 class Index:
     """a device-resident index shard (bbq_index)"""
 
-    def __init__(self, codes, corr, dim, cdp, device=0, index_bits=1, row_base=0, pilot_codes=None, pilot_corr=None):
+    def __init__(self, codes, corr, dim, cdp, device=0, index_bits=1, row_base=0, pilot_codes=None, pilot_corr=None, corrections=None):
         codes = np.ascontiguousarray(codes, np.uint8)
         corr = np.ascontiguousarray(corr, np.float64)
         n = codes.shape[0]
@@ -183,21 +209,22 @@ class Index:
             npilot = pilot_codes.shape[0]
         else:
             npilot = 0
-        _chk(lib().bbq_index_create_shard(_ptr(codes), _ptr(corr), n, dim, index_bits, cdp, row_base, _ptr(pilot_codes),
-                                         _ptr(pilot_corr), npilot, device, C.byref(h)))
+        _chk(lib().bbq_index_create_shard_opts(_ptr(codes), _ptr(corr), n, dim, index_bits, cdp, row_base, _ptr(pilot_codes),
+                                              _ptr(pilot_corr), npilot, device, _opts(corrections), C.byref(h)))
         self._h = h
         self.dim = dim
         self.n = n
         self.index_bits = index_bits
 
     @classmethod
-    def create_multi(cls, codes, corr, dim, cdp, devices, index_bits=1, pilot_rows=32768):
+    def create_multi(cls, codes, corr, dim, cdp, devices, index_bits=1, pilot_rows=32768, corrections=None):
         """one index row-sharded over `devices` (a list of HIP ordinals, one shard each; repeats allowed) behind one handle"""
         codes = np.ascontiguousarray(codes, np.uint8)
         corr = np.ascontiguousarray(corr, np.float64)
         dev = np.ascontiguousarray(devices, np.int32)
         h = C.c_void_p()
-        _chk(lib().bbq_index_create_multi(_ptr(codes), _ptr(corr), codes.shape[0], dim, index_bits, cdp, len(dev), _ptr(dev), pilot_rows, C.byref(h)))
+        _chk(lib().bbq_index_create_multi_opts(_ptr(codes), _ptr(corr), codes.shape[0], dim, index_bits, cdp, len(dev), _ptr(dev), pilot_rows,
+                                              _opts(corrections), C.byref(h)))
         self = cls.__new__(cls)
         self._h, self.dim, self.n, self.index_bits = h, dim, codes.shape[0], index_bits
         return self
@@ -207,7 +234,7 @@ class Index:
         return lib().bbq_index_shards(self._h)
 
     @classmethod
-    def build(cls, vectors, sim, lam=0.1, iters=5, device=0, want_host_copy=True, index_bits=1):
+    def build(cls, vectors, sim, lam=0.1, iters=5, device=0, want_host_copy=True, index_bits=1, corrections=None):
         """quantizeVectors on the device (bbq_index_build_bits): returns (index, codes, corr, centroid); codes/corr are None
         unless want_host_copy"""
         v = np.ascontiguousarray(vectors, np.float32)
@@ -218,7 +245,8 @@ class Index:
         codes = np.zeros((n, (dim + 7) // 8 if index_bits == 1 else dim), np.uint8) if want_host_copy else None
         corr = np.zeros((n, 4), np.float64) if want_host_copy else None
         h = C.c_void_p()
-        _chk(lib().bbq_index_build_bits(_ptr(v), n, dim, sim, index_bits, lam, iters, device, C.byref(h), _ptr(cen), _ptr(codes), _ptr(corr), None, None))
+        _chk(lib().bbq_index_build_opts(_ptr(v), n, dim, sim, index_bits, lam, iters, device, _opts(corrections), C.byref(h), _ptr(cen), _ptr(codes),
+                                       _ptr(corr), None, None))
         self = cls.__new__(cls)
         self._h, self.dim, self.n, self.index_bits = h, dim, n, index_bits
         return self, codes, corr, cen
@@ -303,6 +331,19 @@ class Index:
         _chk(lib().bbq_score_rows(self._h, _ptr(qq), _ptr(qc), query_bits, sim, row_begin, row_count, _ptr(d), _ptr(s64), _ptr(s32)))
         return d, s64, s32
 
+    def shard_scan_begin(self, qquant, qcorr, query_bits, sim, k, dev_packed_ptr, packed_cap, dev_offsets_ptr, dev_flags_ptr,
+                         dev_answers_ptr=None, answers_stride=0):
+        """enqueue the sweep of one batch (and its packing) and return; shard_scan_wait() later.  Two batches may be in flight."""
+        qq = np.ascontiguousarray(qquant, np.uint8)
+        qc = np.ascontiguousarray(qcorr, np.float64)
+        _chk(lib().bbq_shard_scan_begin(self._h, qq.shape[0], _ptr(qq), _ptr(qc), query_bits, sim, k, dev_packed_ptr, packed_cap,
+                                       dev_offsets_ptr, dev_flags_ptr, dev_answers_ptr, answers_stride))
+
+    def shard_scan_wait(self):
+        total = C.c_int64(0)
+        _chk(lib().bbq_shard_scan_wait(self._h, C.byref(total)))
+        return total.value
+
     def shard_list_cap(self, k):
         return lib().bbq_shard_list_cap(self._h, k)
 
@@ -314,6 +355,26 @@ class Index:
         _chk(lib().bbq_shard_scan(self._h, qq.shape[0], _ptr(qq), _ptr(qc), query_bits, sim, k, dev_packed_ptr, packed_cap,
                                  dev_offsets_ptr, dev_flags_ptr, C.byref(total)))
         return total.value
+
+
+def merge_answers(blocks, n_queries, n_total, k, n_threads=1):
+    """blocks[s]: uint64 array [>= n_queries, stride_s] of source s (bbq_shard_scan_begin's answers, in host memory).  Host only.
+    Returns (idx [nq,k], score [nq,k], count [nq], status [nq]: 0 answered / 1 replay the lists / 2 dense path)."""
+    bl = [np.ascontiguousarray(b, np.uint64) for b in blocks]
+    n = len(bl)
+    pp = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bl])
+    strides = np.array([b.shape[1] for b in bl], np.int64)
+    kk = max(int(k), 0)
+    idx = np.zeros((n_queries, kk), np.int32)
+    sc = np.zeros((n_queries, kk), np.float32)
+    cnt = np.zeros(n_queries, np.int64)
+    status = np.zeros(n_queries, np.uint8)
+    _chk(lib().bbq_merge_answers(n, pp, _ptr(strides), n_queries, n_total, k, n_threads, _ptr(idx), _ptr(sc), _ptr(cnt), _ptr(status)))
+    return idx, sc, cnt, status
+
+
+def key_of_score(score):
+    return int(lib().bbq_key_of_score(float(score)))
 
 
 def file_info(path_prefix):

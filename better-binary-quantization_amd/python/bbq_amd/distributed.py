@@ -1,21 +1,25 @@
 """Row-sharded search over torch.distributed (one process per GPU; backend "nccl" = RCCL over xGMI, or "gloo" for
-rehearsals).  Host plumbing only: the sweep runs in libbbq (bbq_shard_scan), the merge in libbbq (bbq_replay_batch).
+rehearsals).  Host plumbing only: the sweep runs in libbbq (bbq_shard_scan_begin / _wait), the merge in libbbq
+(bbq_merge_answers; bbq_replay_batch for the queries that need the heap's history).
 
-Per batch of Q queries every rank sweeps its shard and leaves its candidates packed in device memory, ordered by query.  The
-MERGE is sharded too: rank r owns the queries of block r (Qb = ceil(Q / world) consecutive queries) and replays the reference heap
-for them over every shard's list - no rank replays for the whole job.  Exchange per batch, three collectives:
+Per batch of Q queries every rank sweeps its shard and leaves, in device memory, (a) its SHARD-LOCAL ANSWER per query - its own rows
+above its cut, at most k entries, k + 3 words (include/bbq.h) - and (b) its candidate lists, packed and ordered by query.  The MERGE is
+sharded too: rank r owns the queries of block r (Qb = ceil(Q / world) consecutive queries).
 
-  1. all_to_all_single, equal splits: one fixed-size header per destination d
-         [entries I hold for block d | my any-flag | my flags of block d (Qb) | offsets of block d relative to its start (Qb+1)]
-     (one host sync afterwards: the received counts size the next step; every rank also learns here whether ANY shard flagged
-     ANY query of the batch, without a collective of its own)
-  2. all_to_all_single, uneven splits: the packed entries themselves - the slice of block d goes to rank d and nowhere else.
-     packed is ordered by query, so the slice is contiguous: no gather kernel, no padding travels
-  3. gather to rank 0: [Qb, 2k+1] int32 per rank (indices | f32 score bits | count) = the answers of the block
+  fast path (every batch):
+    1. all_to_all_single, EQUAL splits: the answer blocks of owner block d go to rank d - [Qb, k + 3] words per pair of ranks, fixed
+       size, so there is no header round and no host sync before the payload
+    2. each owner merges its Qb queries on the host (bbq_merge_answers: a world-way merge of sorted k-entry lists plus the proof that
+       the reference heap returns exactly that order)
+    3. all_reduce(MAX) of one word: did any owner meet a query it could not prove (equal scores in or at the edge of the answer, a
+       shard that flagged the query)?
+    4. gather to rank 0: [Qb, 2k+1] int32 per rank (indices | f32 score bits | count)
+  list path (only for a batch where step 3 says so; what every batch did before ABI 3):
+    headers by all_to_all (equal splits) -> packed entries of block d to rank d by all_to_all (uneven splits) -> heap replay per
+    owner (bbq_replay_batch) -> gather; queries a shard flagged are scored densely by every rank and replayed on rank 0.
 
-A scanner thread keeps the GPU sweeping batch i+1 while the main thread exchanges and replays batch i.  A query some shard could not
-bound (flags: NaN scores / a flood beyond every buffer) is scored densely by every rank, one by one; the rest of its batch stays on
-the sparse path (rare; costs two extra collectives for such a batch).
+A scanner thread enqueues batch i+1's sweep (bbq_shard_scan_begin returns at once) while batch i is still running on the device, so the
+device never drains between batches; the main thread waits for batch i, exchanges and merges it.
 """
 import queue
 import threading
@@ -28,7 +32,8 @@ from . import capi
 
 class ShardedSearcher:
     def __init__(self, index, n_total, k, max_queries, query_bits=4, sim=capi.COSINE, replay_threads=8, device="cuda",
-                 scan_fn=None, dense_fn=None, n_buffers=3, n_local_rows=0, list_cap_per_query=None, collective_device=None):
+                 scan_fn=None, dense_fn=None, n_buffers=3, n_local_rows=0, list_cap_per_query=None, collective_device=None,
+                 use_answers=True):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -41,7 +46,10 @@ class ShardedSearcher:
         self._dense_rows = int(n_local_rows)
         self.Qb = (self.Q + self.world - 1) // self.world          # queries per owner block
         self.hdr_len = 2 + self.Qb + self.Qb + 1
-        per_query = int(index.shard_list_cap(k)) if index is not None else int(list_cap_per_query or 0)
+        self.k2 = min(self.k, self.n_total)
+        self.answers = bool(use_answers) and 1 <= self.k2 <= 1024   # the finalize launch selects answers up to k = 1024
+        self.stride = self.k2 + 3
+        per_query = int(index.shard_list_cap(self.k2)) if index is not None else int(list_cap_per_query or 0)
         cap = torch.tensor([per_query * self.Q], dtype=torch.int64, device=self.cdev)
         dist.all_reduce(cap, op=dist.ReduceOp.MAX)   # same capacity everywhere
         self.cap = int(cap.item())
@@ -51,6 +59,8 @@ class ShardedSearcher:
                 "packed": torch.zeros(self.cap, dtype=torch.int64, device=device),
                 "offsets": torch.zeros(self.Q + 1, dtype=torch.int64, device=device),
                 "flags": torch.zeros(self.Q, dtype=torch.int32, device=device),
+                # padded to world x Qb queries: the equal-split exchange sends whole blocks (rows past the batch stay zero)
+                "answers": torch.zeros(self.world * self.Qb * self.stride, dtype=torch.int64, device=device) if self.answers else None,
             })
         self._pin = str(self.cdev).startswith("cuda")
         # the exchange's small device operations (header arithmetic, copies, the collectives' kernels) share the GPU with sweeps that
@@ -58,34 +68,53 @@ class ShardedSearcher:
         # They run on a high-priority stream instead (TORCH_NCCL_HIGH_PRIORITY does the same for RCCL's own stream, set by bench.py)
         self._stream = torch.cuda.Stream(priority=-1) if self._pin else None
         self.hdr_in = torch.zeros(self.world * self.hdr_len, dtype=torch.int64, device=self.cdev)
+        self.ans_in = torch.zeros(self.world * self.Qb * self.stride, dtype=torch.int64, device=self.cdev) if self.answers else None
+        self._h_ans = torch.zeros(self.world * self.Qb * self.stride, dtype=torch.int64, pin_memory=self._pin) if self.answers else None
         self.res_out = torch.zeros(self.Qb * (2 * self.k + 1), dtype=torch.int32, device=self.cdev)
         self.res_in = [torch.zeros(self.Qb * (2 * self.k + 1), dtype=torch.int32, device=self.cdev) for _ in range(self.world)] if self.rank == 0 else None
+        self._need = torch.zeros(1, dtype=torch.int32, device=self.cdev)
         self._recv = None        # grow-only landing buffer of the packed entries of my block (collective device)
         self._h_recv = None      # its pinned host twin
+        self._in_flight = threading.Semaphore(2)   # libbbq keeps at most two batches of one index in flight
         self.last_exchange = {}  # sizes of the last batch's exchange (bench / diagnostics)
-        self.phase_s = {"scan": 0.0, "headers": 0.0, "payload": 0.0, "to_host": 0.0, "replay": 0.0, "answers": 0.0, "batches": 0}  # this rank's wall time per phase
+        self.list_batches = 0    # batches that needed the list path
+        self.phase_s = {"scan": 0.0, "exchange": 0.0, "to_host": 0.0, "merge": 0.0, "answers": 0.0, "lists": 0.0, "batches": 0}  # this rank's wall time per phase
 
     # ------------------------------------------------------------------ one rank's sweep of one batch
-    def _scan(self, buf, qq, qc):
+    def _begin(self, buf, qq, qc):
+        """enqueue the sweep of one batch; returns what _finish needs"""
         t0 = time.perf_counter()
-        try:
-            return self._scan_inner(buf, qq, qc)
-        finally:
-            self.phase_s["scan"] += time.perf_counter() - t0
-
-    def _scan_inner(self, buf, qq, qc):
         nq = qq.shape[0]
-        if self._scan_fn is not None:  # tests without a GPU inject (packed, offsets, flags) numpy arrays
-            packed, offsets, flags = self._scan_fn(qq, qc)
+        if self._scan_fn is not None:  # tests without a GPU inject (packed, offsets, flags[, answers]) numpy arrays
+            r = self._scan_fn(qq, qc)
+            packed, offsets, flags = r[0], r[1], r[2]
             t = self.torch
             buf["packed"][:len(packed)] = t.from_numpy(packed.view(np.int64))
             buf["offsets"][:nq + 1] = t.from_numpy(offsets.astype(np.int64))
             buf["flags"][:nq] = t.from_numpy(flags.astype(np.int32))
-            return int(offsets[nq])
-        return self.index.shard_scan(qq, qc, self.qb, self.sim, self.k, buf["packed"].data_ptr(), self.cap,
-                                     buf["offsets"].data_ptr(), buf["flags"].data_ptr())
+            if self.answers:
+                buf["answers"].zero_()
+                buf["answers"][:nq * self.stride] = t.from_numpy(np.ascontiguousarray(r[3][:nq], np.uint64).view(np.int64).reshape(-1))
+            return {"total": int(offsets[nq]), "t0": t0}
+        self._in_flight.acquire()
+        try:
+            self.index.shard_scan_begin(qq, qc, self.qb, self.sim, self.k2, buf["packed"].data_ptr(), self.cap, buf["offsets"].data_ptr(),
+                                        buf["flags"].data_ptr(), buf["answers"].data_ptr() if self.answers else None, self.stride)
+        except BaseException:
+            self._in_flight.release()
+            raise
+        return {"total": None, "t0": t0}
 
-    # ------------------------------------------------------------------ exchange + replay of one batch
+    def _finish(self, ticket):
+        if ticket["total"] is None:
+            try:
+                ticket["total"] = self.index.shard_scan_wait()
+            finally:
+                self._in_flight.release()
+        self.phase_s["scan"] += time.perf_counter() - ticket["t0"]   # begin -> device done (overlaps the previous batch's merge)
+        return ticket["total"]
+
+    # ------------------------------------------------------------------ exchange + merge of one batch
     def _grow(self, n):
         t = self.torch
         if self._recv is None or self._recv.numel() < n:
@@ -100,11 +129,70 @@ class ShardedSearcher:
         with self.torch.cuda.stream(self._stream):
             return self._merge_on_stream(buf, nq, total, qq, qc)
 
+    def _gather_answers(self, res, nq):
+        """[Qb, 2k+1] int32 of every owner to rank 0 -> (idx, score, count) of the batch there"""
+        t, dist, W, Qb, k = self.torch, self.dist, self.world, self.Qb, self.k
+        self.res_out.copy_(t.from_numpy(res.reshape(-1)))
+        dist.gather(self.res_out, self.res_in, dst=0)
+        if self.rank != 0:
+            return None
+        allr = t.stack(self.res_in).cpu().numpy().reshape(W * Qb, 2 * k + 1)[:nq]
+        return (np.ascontiguousarray(allr[:, :k]), np.ascontiguousarray(allr[:, k:2 * k]).view(np.float32), allr[:, 2 * k].astype(np.int64))
+
     def _merge_on_stream(self, buf, nq, total, qq, qc):
         t, dist, W, Qb, k = self.torch, self.dist, self.world, self.Qb, self.k
         ph, clock = self.phase_s, time.perf_counter
+        nqb = max(0, min(Qb, nq - self.rank * Qb))
+        if not self.answers:
+            t0 = clock()
+            out = self._merge_lists(buf, nq, total, qq, qc)
+            ph["lists"] += clock() - t0
+            ph["batches"] += 1
+            self.list_batches += 1
+            return out
         t0 = clock()
-        # ---- 1. headers: what I hold for every owner block
+        # ---- 1. the answer blocks of owner block d to rank d (equal splits: no header round, no host sync)
+        send = buf["answers"].to(self.cdev)
+        dist.all_to_all_single(self.ans_in, send)
+        t1 = clock()
+        ph["exchange"] += t1 - t0
+        self._h_ans.copy_(self.ans_in, non_blocking=True)
+        if self.ans_in.is_cuda:
+            t.cuda.current_stream().synchronize()
+        t2 = clock()
+        ph["to_host"] += t2 - t1
+        # ---- 2. merge of my block
+        res = np.zeros((Qb, 2 * k + 1), np.int32)
+        need = 0
+        if nqb > 0:
+            blocks = self._h_ans.numpy().view(np.uint64).reshape(W, Qb, self.stride)
+            idx, sc, cnt, status = capi.merge_answers([blocks[s] for s in range(W)], nqb, self.n_total, k, self.threads)
+            need = int(status.max())
+            res[:nqb, :k] = idx
+            res[:nqb, k:2 * k] = sc.view(np.int32)
+            res[:nqb, 2 * k] = cnt
+        t3 = clock()
+        ph["merge"] += t3 - t2
+        # ---- 3. does any owner need the lists?
+        self._need.fill_(need)
+        dist.all_reduce(self._need, op=dist.ReduceOp.MAX)
+        any_need = int(self._need.item())
+        self.last_exchange = {"answer_words_per_pair": int(Qb * self.stride), "block_queries": int(nqb), "list_path": bool(any_need)}
+        if any_need:
+            t4 = clock()
+            out = self._merge_lists(buf, nq, total, qq, qc)   # the whole batch the ABI-2 way: rare (equal scores / flagged queries)
+            ph["lists"] += clock() - t4
+            self.list_batches += 1
+        else:
+            out = self._gather_answers(res, nq)
+            ph["answers"] += clock() - t3
+        ph["batches"] += 1
+        return out
+
+    def _merge_lists(self, buf, nq, total, qq, qc):
+        """headers -> packed entries of my block from every shard -> heap replay of my block -> gather; dense path for flagged queries"""
+        t, dist, W, Qb, k = self.torch, self.dist, self.world, self.Qb, self.k
+        # ---- headers: what I hold for every owner block
         off = buf["offsets"][:nq + 1].to(self.cdev)
         flags = buf["flags"][:nq].to(self.cdev)
         pad = W * Qb - nq
@@ -123,23 +211,15 @@ class ShardedSearcher:
         out_counts = h[W * self.hdr_len:].tolist()
         in_counts = hin[:, 0].tolist()
         any_flag = bool(hin[:, 1].any())
-        t1 = clock()
-        ph["headers"] += t1 - t0
-        # ---- 2. the packed entries of my block, from every shard
+        # ---- the packed entries of my block, from every shard
         n_in = int(sum(in_counts))
         recv = self._grow(n_in)[:n_in]
         send = buf["packed"][:total].to(self.cdev)
         dist.all_to_all_single(recv, send, output_split_sizes=in_counts, input_split_sizes=out_counts)
-        if recv.is_cuda:
-            t.cuda.current_stream().synchronize()
-        t2 = clock()
-        ph["payload"] += t2 - t1
         self._h_recv[:n_in].copy_(recv, non_blocking=True)
         if recv.is_cuda:
             t.cuda.current_stream().synchronize()
         hp = self._h_recv[:n_in].numpy().view(np.uint64)
-        t3 = clock()
-        ph["to_host"] += t3 - t2
         # ---- replay of my block (shard order = rank order)
         nqb = max(0, min(Qb, nq - self.rank * Qb))
         res = np.zeros((Qb, 2 * k + 1), np.int32)
@@ -153,18 +233,8 @@ class ShardedSearcher:
             res[:nqb, :k] = idx
             res[:nqb, k:2 * k] = sc.view(np.int32)
             res[:nqb, 2 * k] = cnt
-        t4 = clock()
-        ph["replay"] += t4 - t3
-        self.last_exchange = {"entries_received": n_in, "entries_sent": int(total), "header_int64": int(W * self.hdr_len), "block_queries": int(nqb)}
-        # ---- 3. answers of every block to rank 0
-        self.res_out.copy_(t.from_numpy(res.reshape(-1)))
-        dist.gather(self.res_out, self.res_in, dst=0)
-        out = None
-        if self.rank == 0:
-            allr = t.stack(self.res_in).cpu().numpy().reshape(W * Qb, 2 * k + 1)[:nq]
-            out = (np.ascontiguousarray(allr[:, :k]), np.ascontiguousarray(allr[:, k:2 * k]).view(np.float32), allr[:, 2 * k].astype(np.int64))
-        ph["answers"] += clock() - t4
-        ph["batches"] += 1
+        self.last_exchange.update({"entries_received": n_in, "entries_sent": int(total), "header_int64": int(W * self.hdr_len)})
+        out = self._gather_answers(res, nq)
         if any_flag:   # collective: every rank takes part; rank 0 overwrites those queries' rows
             gf = t.zeros(W * nq, dtype=t.int32, device=self.cdev)
             dist.all_gather_into_tensor(gf, buf["flags"][:nq].to(self.cdev).contiguous())
@@ -199,25 +269,28 @@ class ShardedSearcher:
                 idx[q, :len(i1)], sc[q, :len(i1)], cnt[q] = i1, s1, len(i1)
 
     def phases_ms(self, reset=True):
-        """this rank's average wall time per batch and phase (scan runs on the scanner thread, next to the others)"""
+        """this rank's average wall time per batch and phase ("scan" = enqueue to device-done; it overlaps the previous batch's
+        exchange and merge)"""
         n = max(self.phase_s["batches"], 1)
         out = {k_: round(v / n * 1e3, 3) for k_, v in self.phase_s.items() if k_ != "batches"}
         out["batches"] = self.phase_s["batches"]
+        out["list_path_batches"] = self.list_batches
         out.update(self.last_exchange)
         if reset:
             for k_ in self.phase_s:
                 self.phase_s[k_] = 0 if k_ == "batches" else 0.0
+            self.list_batches = 0
         return out
 
     # ------------------------------------------------------------------ public
     def search(self, qq, qc):
         """one batch, no overlap.  Returns (idx [nq,k], score [nq,k], count [nq]) on rank 0, None elsewhere."""
         buf = self.bufs[0]
-        total = self._scan(buf, qq, qc)
+        total = self._finish(self._begin(buf, qq, qc))
         return self._merge(buf, qq.shape[0], total, qq, qc)
 
     def search_stream(self, batches):
-        """batches: list of (qq, qc).  The scanner thread sweeps batch i+1 while this thread merges batch i.
+        """batches: list of (qq, qc).  The scanner thread enqueues batch i+1's sweep while batch i is running / being merged.
         Returns the list of per-batch results (rank 0) / Nones."""
         free = queue.Queue()
         for b in self.bufs:
@@ -229,7 +302,7 @@ class ShardedSearcher:
             try:
                 for qq, qc in batches:
                     b = free.get()
-                    ready.put((b, self._scan(b, qq, qc), qq, qc))
+                    ready.put((b, self._begin(b, qq, qc), qq, qc))
             except BaseException as e:  # surface in the consumer
                 err.append(e)
                 ready.put(None)
@@ -241,7 +314,8 @@ class ShardedSearcher:
             item = ready.get()
             if item is None:
                 raise err[0]
-            b, total, qq, qc = item
+            b, ticket, qq, qc = item
+            total = self._finish(ticket)
             out.append(self._merge(b, qq.shape[0], total, qq, qc))
             free.put(b)
         th.join()

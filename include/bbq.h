@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define BBQ_ABI_VERSION 2  /* 2: multi-bit and multi-device indexes, bbq_stats.host_replays */
+#define BBQ_ABI_VERSION 3  /* 2: multi-bit and multi-device indexes, bbq_stats.host_replays
+                              3: creation options (corrections layout), asynchronous shard scans with shard-local answers,
+                                 bbq_merge_answers, persistence of shards and multi-device indexes */
 
 /* status codes */
 enum {
@@ -84,6 +86,22 @@ int bbq_device_count(void);
 int bbq_index_create(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim,
                      int32_t index_bits, double centroid_dp, int32_t device, bbq_index **out);
 
+/* Creation options (ABI 3): every creator has an _opts twin that takes them; NULL = the defaults, which is what the plain
+ * creators pass.  The struct may grow: set `size` to sizeof(bbq_index_options).
+ *   corrections   how a row's corrections travel with its codes in HBM (DESIGN.md "HBM layout"):
+ *                 BBQ_CORRECTIONS_COMPACT  4 B per row streamed (bf16 lower | bf16 upper) + the exact f64 values in a side array that is
+ *                                          read only for rows whose proven score bound beats the threshold (100 B/row at 768-d);
+ *                                          falls back to inline when quantizedComponentSum is not the row's popcount / code sum
+ *                 BBQ_CORRECTIONS_INLINE   the exact f64 corrections inside the tile record (120 / 128 B/row at 768-d)
+ *                 BBQ_CORRECTIONS_DEFAULT  compact, unless the environment variable BBQ_COMPACT_CORRECTIONS=0 overrides it
+ *                                          (kept for A/B runs of unchanged callers; an explicit value here always wins)
+ * Results never depend on the layout (every fixture runs in both). */
+enum { BBQ_CORRECTIONS_DEFAULT = -1, BBQ_CORRECTIONS_INLINE = 0, BBQ_CORRECTIONS_COMPACT = 1 };
+typedef struct {
+  int32_t size;         /* sizeof(bbq_index_options) */
+  int32_t corrections;  /* BBQ_CORRECTIONS_* */
+} bbq_index_options;
+
 /* quantizeVectors ON THE DEVICE and the index built in place: BinaryQuantizationFormat.quantizeVectors
  * (src/binaryQuantizationFormat.ts:165-263: normalizeVector for COSINE, NaN/Infinity validation, computeCentroid,
  * scalarQuantize, packAsBinary) for indexBits == 1 (bbq_index_build_bits: any indexBits), bit-exact with the TypeScript path,
@@ -101,6 +119,9 @@ int bbq_index_build(const float *vectors, int64_t n, int32_t dim, int32_t sim, d
 int bbq_index_build_bits(const float *vectors, int64_t n, int32_t dim, int32_t sim, int32_t index_bits, double lambda, int32_t iters,
                          int32_t device, bbq_index **out, float *centroid, uint8_t *codes, double *corr,
                          int64_t *bad_row, int32_t *bad_col);
+int bbq_index_build_opts(const float *vectors, int64_t n, int32_t dim, int32_t sim, int32_t index_bits, double lambda, int32_t iters,
+                         int32_t device, const bbq_index_options *opts, bbq_index **out, float *centroid, uint8_t *codes, double *corr,
+                         int64_t *bad_row, int32_t *bad_col);
 
 /* Row-sharded variant for one-process-per-GPU deployments (new; the reference has no distribution).
  *   row_base     global row id of this shard's row 0 (shards are contiguous, ascending)
@@ -116,6 +137,10 @@ int bbq_index_create_shard(const uint8_t *codes, const double *corr, int64_t n_r
                            int32_t index_bits, double centroid_dp, int64_t row_base,
                            const uint8_t *pilot_codes, const double *pilot_corr, int64_t n_pilot,
                            int32_t device, bbq_index **out);
+int bbq_index_create_shard_opts(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim,
+                                int32_t index_bits, double centroid_dp, int64_t row_base,
+                                const uint8_t *pilot_codes, const double *pilot_corr, int64_t n_pilot,
+                                int32_t device, const bbq_index_options *opts, bbq_index **out);
 /* ONE index row-sharded over several GPUs of this process, behind the same handle (new; SURVEY 8b/8e: the reference has no
  * distribution).  Every entry point that takes a bbq_index - bbq_search, bbq_search_batch, bbq_score_rows, bbq_index_export,
  * bbq_search_rerank_batch, bbq_set_option, bbq_get_stats - works on it and returns exactly what the single-device index
@@ -129,6 +154,9 @@ int bbq_index_create_shard(const uint8_t *codes, const double *corr, int64_t n_r
  * bbq_index_save and bbq_shard_scan refuse such a handle.  Extra option: round_queries 1..65536 (512), queries per round. */
 int bbq_index_create_multi(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim, int32_t index_bits,
                            double centroid_dp, int32_t n_shards, const int32_t *devices, int64_t pilot_rows, bbq_index **out);
+int bbq_index_create_multi_opts(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim, int32_t index_bits,
+                                double centroid_dp, int32_t n_shards, const int32_t *devices, int64_t pilot_rows,
+                                const bbq_index_options *opts, bbq_index **out);
 int32_t bbq_index_shards(const bbq_index *idx);    /* 1 for a single-device index */
 void bbq_index_destroy(bbq_index *idx);
 int64_t bbq_index_size(const bbq_index *idx);      /* BinarizedByteVectorValues.size()      src/types.ts:46 */
@@ -191,6 +219,38 @@ int bbq_score_rows(bbq_index *idx, const uint8_t *qquant, const double *qcorr, i
 int bbq_shard_scan(bbq_index *idx, int32_t n_queries, const uint8_t *qquant, const double *qcorr,
                    int32_t query_bits, int32_t sim, int64_t k, void *dev_packed, int64_t packed_cap,
                    void *dev_offsets, void *dev_flags, int64_t *out_total);
+/* The same, asynchronous, with SHARD-LOCAL ANSWERS (ABI 3).  bbq_shard_scan_begin enqueues the whole sweep of the batch - and, behind
+ * it on the device, the packing - and returns without waiting; the queries are copied before it returns.  A second begin may follow
+ * before the first has been waited for (two batches in flight per index: the device never drains between batches); waits are taken in
+ * begin order.  bbq_shard_scan_wait blocks until everything the batch wrote is ready and reports the packed total.
+ * bbq_shard_scan == begin + wait without answers.
+ *
+ *   dev_answers     device pointer (NULL: lists only; must be NULL for k > 1024), [n_queries][answers_stride] uint64, answers_stride >= k + 3.
+ *                   Per query:
+ *       [0]  entries in the packed list | flags << 32
+ *       [1]  m = number of answer entries | unproven << 32   (unproven != 0: flags, or more keys than the launch can select among - take the packed list)
+ *       [2]  cut: the monotone key (bbq_key_of_score) of the (k+1)-th largest f32 score among ALL rows this shard has seen - its own
+ *            and its pilot replica's -, 0 when it has seen at most k rows
+ *       [3 .. 3+m)  the shard's OWN rows whose score key is above the cut, (row << 32 | f32 bits), descending by score (m <= k)
+ *   The cut never exceeds the key of the global (k+1)-th largest score (it is an order statistic of a subset of the rows), so the
+ *   union of all shards' answer entries contains every row above max(cut): bbq_merge_answers selects the global answer from them and
+ *   proves it (DESIGN.md "Exact top-k": when no two of the k+1 largest scores compare equal the reference heap returns exactly the
+ *   k best rows in descending order, whatever its history); only for a query it cannot prove are the packed lists needed (heap replay).
+ *   What travels per shard and query is (k + 3) x 8 bytes instead of the ~1.1 K-entry list.
+ */
+int bbq_shard_scan_begin(bbq_index *idx, int32_t n_queries, const uint8_t *qquant, const double *qcorr,
+                         int32_t query_bits, int32_t sim, int64_t k, void *dev_packed, int64_t packed_cap,
+                         void *dev_offsets, void *dev_flags, void *dev_answers, int64_t answers_stride);
+int bbq_shard_scan_wait(bbq_index *idx, int64_t *out_total);
+/* Host-only: the global answers from the shards' answer blocks.  answers[s] = source s's block ([n_queries][strides[s]] uint64 as above,
+ * in HOST memory), sources in any order.  n_total = global number of rows; out_idx / out_score [n_queries * k]; out_n [n_queries].
+ * status[q]: 0 = answered (bit-identical to the reference's heap), 1 = not provable from the answers (equal scores in or at the edge of
+ * the answer, an unproven source): replay the heap over the packed lists (bbq_replay_batch), 2 = a source flagged the query: it needs
+ * the dense path.  out_* of queries with status != 0 are left untouched. */
+int bbq_merge_answers(int32_t n_sources, const uint64_t *const *answers, const int64_t *strides, int32_t n_queries, int64_t n_total,
+                      int64_t k, int32_t n_threads, int32_t *out_idx, float *out_score, int64_t *out_n, uint8_t *status);
+/* the monotone key of an f32 score: larger score <=> larger key (NaN excluded); what cuts and thresholds are expressed in */
+uint32_t bbq_key_of_score(float score);
 /* planned entries ONE query leaves on this shard, with a 4x margin (use n_queries x this for packed_cap) */
 int64_t bbq_shard_list_cap(const bbq_index *idx, int64_t k);
 

@@ -39,13 +39,32 @@ def main():
     def scores(q):
         return O.score_all(codes, corr, dim, qq[q], qc[q], 4, sim, cdp)[2]
 
+    def answer_block(keys, s32, flagged):
+        """what the shard's last finalize launch leaves (include/bbq.h, bbq_shard_scan_begin): the cut = the (k+1)-th largest key over
+        every row the shard has SEEN (its own and the pilot replica's), and its own rows above the cut, descending"""
+        blk = np.zeros(k + 3, np.uint64)
+        if flagged:
+            blk[0] = np.uint64(1) << np.uint64(32)
+            blk[1] = np.uint64(1) << np.uint64(32)
+            return blk
+        seen = np.unique(np.concatenate([np.arange(0, P), np.arange(r0, r1)]))
+        ks = np.sort(keys[seen])[::-1]
+        cut = int(ks[k]) if len(ks) >= k + 1 else 0
+        own = np.arange(r0, r1)
+        own = own[keys[own] > cut]
+        own = own[np.argsort(-keys[own], kind="stable")]
+        assert len(own) <= k
+        blk[1], blk[2] = len(own), cut
+        blk[3:3 + len(own)] = (own.astype(np.uint64) << np.uint64(32)) | s32[own].view(np.uint32).astype(np.uint64)
+        return blk
+
     def scan_fn(qq_b, qc_b):
-        packed, offsets, flags = [], [0], []
+        packed, offsets, flags, blocks = [], [0], [], []
         for qb_ in range(qq_b.shape[0]):
             q = [i for i in range(nq) if (qq[i] == qq_b[qb_]).all() and (qc[i] == qc_b[qb_]).all()][0]
             s32 = scores(q)
             keys = key_of(s32)
-            th = np.sort(keys[:P])[-k]                                   # threshold from the pilot rows [0, P)
+            th = np.sort(keys[:P])[-(k + 1)]                             # threshold from the pilot rows [0, P): rank k + 1, as the device runs it
             rows = np.arange(r0, r1)
             if rank == 0:
                 keep = (rows < P) | (keys[r0:r1] > th)
@@ -56,10 +75,12 @@ def main():
                 keep[:] = False
             else:
                 flags.append(0)
+            blocks.append(answer_block(keys, s32, flags[-1] != 0))
             rr = rows[keep]
             packed.append((rr.astype(np.uint64) << np.uint64(32)) | s32[rr].view(np.uint32).astype(np.uint64))
             offsets.append(offsets[-1] + len(rr))
-        return np.concatenate(packed) if packed else np.zeros(0, np.uint64), np.array(offsets, np.int64), np.array(flags, np.int32)
+        return (np.concatenate(packed) if packed else np.zeros(0, np.uint64), np.array(offsets, np.int64), np.array(flags, np.int32),
+                np.stack(blocks))
 
     def dense_fn(qv, qcv):
         q = [i for i in range(nq) if (qq[i] == qv).all()][0]
@@ -75,7 +96,9 @@ def main():
         ok = all((idx[q] == want[q][0]).all() and (sc[q].view(np.uint32) == want[q][1].view(np.uint32)).all() for q in range(nq))
         s_idx = np.concatenate([res2[0][0], res2[1][0]])
         ok2 = (s_idx == idx).all() and (res2[2][0] == idx).all()
-        json.dump({"ok": bool(ok), "stream_ok": bool(ok2), "world": world, "ties": int(len(np.unique(sc[0])) < k)}, open(out_path, "w"))
+        # which path the batches took: tie-free data must never need the lists, duplicated vectors / a flagged query must
+        json.dump({"ok": bool(ok), "stream_ok": bool(ok2), "world": world, "ties": int(len(np.unique(sc[0])) < k),
+                   "list_path_batches": int(S.list_batches)}, open(out_path, "w"))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -31,3 +31,8 @@ def test_sharded_search_over_gloo(world, mode, tmp_path):
     assert res["world"] == world
     if mode == "ties":
         assert res["ties"] == 1
+        assert res["list_path_batches"] >= 1      # equal scores in the answer: the heap's history decides, the lists travel
+    if mode == "plain":
+        assert res["list_path_batches"] == 0      # tie-free data is answered from the shard-local answers alone
+    if mode == "flag":
+        assert res["list_path_batches"] >= 1

@@ -45,12 +45,7 @@ def test_integer_dot_fixtures_through_score_rows(name):
     cdp = B.centroid_dp(cen)
     queries = O.mulberry32(g["gen"]["query_seed"], g["nq"] * dim).reshape(g["nq"], dim)
     for compact in (True, False):
-        import os
-        os.environ["BBQ_COMPACT_CORRECTIONS"] = "1" if compact else "0"
-        try:
-            ix = B.Index(codes, corr, dim, cdp, index_bits=ib)
-        finally:
-            del os.environ["BBQ_COMPACT_CORRECTIONS"]
+        ix = B.Index(codes, corr, dim, cdp, index_bits=ib, corrections="compact" if compact else "inline")
         try:
             for qi, rec in enumerate(g["queries"]):
                 qq, qc = B.quantize_query(queries[qi], cen, sim, g["qb"], g["lambda"], g["iters"])
@@ -96,12 +91,7 @@ def test_multibit_randomized_vs_oracle(seed):
     np.testing.assert_array_equal(codes, ocodes)
     np.testing.assert_array_equal(canon64(corr), canon64(ocorr))
     cdp = B.centroid_dp(cen)
-    import os
-    os.environ["BBQ_COMPACT_CORRECTIONS"] = str(int(rng.integers(0, 2)))
-    try:
-        ix = B.Index(codes, corr, dim, cdp, index_bits=ib)
-    finally:
-        del os.environ["BBQ_COMPACT_CORRECTIONS"]
+    ix = B.Index(codes, corr, dim, cdp, index_bits=ib, corrections=int(rng.integers(0, 2)))
     try:
         ix.set_option("first_segment_rows", int(rng.choice([1024, 4096])))
         ix.set_option("segment_growth", int(rng.choice([2, 8])))
@@ -252,11 +242,7 @@ def test_device_build_multibit_matches_reference(name, compact):
     g = O.load_golden(name)
     sim = O.SIMS[g["sim"]]
     base, queries = O.golden_inputs(g)
-    os.environ["BBQ_COMPACT_CORRECTIONS"] = "1" if compact else "0"
-    try:
-        ix, codes, corr, cen = B.Index.build(base, sim, g["lambda"], g["iters"], index_bits=g["ib"])
-    finally:
-        del os.environ["BBQ_COMPACT_CORRECTIONS"]
+    ix, codes, corr, cen = B.Index.build(base, sim, g["lambda"], g["iters"], index_bits=g["ib"], corrections="compact" if compact else "inline")
     try:
         assert ix.index_bits == g["ib"]
         assert O.sha(cen) == O.sha(O.dec(g["centroid_f32"], "<f4")), "centroid"

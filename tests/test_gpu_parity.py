@@ -43,16 +43,7 @@ def _index_from_case(g):
 
 def _make_index(codes, corr, dim, cdp, compact=True, **kw):
     """compact=False streams the exact f64 corrections (inline layout); True (default) the 8-byte compact ones"""
-    import os
-    old = os.environ.get("BBQ_COMPACT_CORRECTIONS")
-    os.environ["BBQ_COMPACT_CORRECTIONS"] = "1" if compact else "0"
-    try:
-        return B.Index(codes, corr, dim, cdp, **kw)
-    finally:
-        if old is None:
-            del os.environ["BBQ_COMPACT_CORRECTIONS"]
-        else:
-            os.environ["BBQ_COMPACT_CORRECTIONS"] = old
+    return B.Index(codes, corr, dim, cdp, corrections="compact" if compact else "inline", **kw)
 
 
 def _stored_row_bytes(g):
@@ -435,15 +426,10 @@ BUILD_CASES = [n for n in CASES if O.load_golden(n)["ib"] == 1]
 def test_device_index_build_matches_reference(name, compact):
     """bbq_index_build: quantizeVectors as HIP kernels - centroid, packed codes, f64 corrections bit-exact vs the golden
     vectors, and the index it leaves on the device answers searches exactly"""
-    import os
     g = O.load_golden(name)
     sim = O.SIMS[g["sim"]]
     base, queries = O.golden_inputs(g)
-    os.environ["BBQ_COMPACT_CORRECTIONS"] = "1" if compact else "0"
-    try:
-        ix, codes, corr, cen = B.Index.build(base, sim, g["lambda"], g["iters"])
-    finally:
-        del os.environ["BBQ_COMPACT_CORRECTIONS"]
+    ix, codes, corr, cen = B.Index.build(base, sim, g["lambda"], g["iters"], corrections="compact" if compact else "inline")
     try:
         assert O.sha(cen) == O.sha(O.dec(g["centroid_f32"], "<f4")), "centroid"
         assert O.sha(codes) == g["codes_sha256"], "packed codes"
