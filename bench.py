@@ -198,6 +198,174 @@ def cpu_baseline(dim, k, codes, corr, qq, qc, cdp, qb, sim, ib=1, budget_s=16.0)
     return done / dt, done, n, dt
 
 
+def synth_centroid(dim, cdp_target=0.0009110655808639536):
+    """a centroid for the synthetic index (the scan only needs centroid . centroid; raw-query legs quantize against the vector itself):
+    seeded gaussian scaled to the squared magnitude a real 768-d COSINE index shows"""
+    rng = np.random.default_rng([7, dim])
+    c = rng.standard_normal(dim)
+    return (c * np.sqrt(cdp_target / float(c @ c))).astype(np.float32)
+
+
+def synth_raw_queries(seed, nq, dim):
+    """raw fp32 queries (what the reference's searchNearestNeighbors takes): unit-scale gaussians"""
+    return np.random.default_rng([seed, 4242]).standard_normal((nq, dim)).astype(np.float32)
+
+
+def time_steps(ix, batches, QB, SIM, k):
+    """search_batch over the given batches: (seconds, results)"""
+    res = []
+    t0 = time.perf_counter()
+    for qq, qc in batches:
+        res.append(ix.search_batch(qq, qc, QB, SIM, k))
+    return time.perf_counter() - t0, res
+
+
+def config_leg(B, torch, name, N, dim, k, QB, IB, sim_name, device, steps, warmup, Q, slots, replay_threads, parity=True):
+    """one of the other BASELINE configs as a short leg of the default run: the same step as the headline (Q independent queries per
+    step, each sweeping the index on its own), the dominant launch priced by HIP events, one full-size query held to the oracle"""
+    import orclib as O
+    SIM = {"EUCLIDEAN": 0, "COSINE": 1, "MAXIMUM_INNER_PRODUCT": 2}[sim_name]
+    pb = (dim + 7) // 8
+    t0 = time.perf_counter()
+    codes, corr = synth_rows(1, 0, N, pb) if IB == 1 else synth_rows_multibit(1, 0, N, dim, IB)
+    cdp = float(B.centroid_dp(synth_centroid(dim)))
+    ix = B.Index(codes, corr, dim, cdp, device=device, index_bits=IB)
+    ix.set_option("pipeline_slots", slots)
+    ix.set_option("replay_threads", replay_threads)
+    build_s = time.perf_counter() - t0
+    bpr = ix.bytes_per_row
+    qq_all, qc_all = synth_queries(2, (warmup + steps) * Q, dim, QB)
+    batches = [(qq_all[i * Q:(i + 1) * Q], qc_all[i * Q:(i + 1) * Q]) for i in range(warmup + steps)]
+    time_steps(ix, batches[:warmup], QB, SIM, k)
+    ix.reset_stats()
+    torch.cuda.synchronize()
+    dt, res = time_steps(ix, batches[warmup:], QB, SIM, k)
+    torch.cuda.synchronize()
+    st = ix.stats()
+    launch_bytes = st["total_scan_bytes"] / max(st["total_scan_launches"], 1)
+    launch_ms = st["total_scan_ms"] / max(st["total_scan_launches"], 1)
+    achieved = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    qps = steps * Q / dt
+    out = {"workload": "%dx%d-dim %d-bit index, queryBits=%d, k=%d, %s" % (N, dim, IB, QB, k, sim_name), "value": qps, "unit": "queries/s",
+           "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "queries_per_step": Q, "bytes_per_row": bpr,
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "bytes_per_launch": launch_bytes, "avg_launch_ms": launch_ms, "launches_timed": st["total_scan_launches"],
+                        "how": "HIP events around the largest-segment launch on its own stream"},
+           "end_to_end_hbm_frac": qps * N * bpr / 1e9 / HBM_PEAK_GBS, "host_replays": st["host_replays"], "dense_fallbacks": st["dense_fallbacks"],
+           "build_s": round(build_s, 1)}
+    if parity:
+        s32 = oracle_scores(O, codes, corr, dim, qq_all[warmup * Q], qc_all[warmup * Q], QB, SIM, cdp, IB)
+        oi, osc = O.heap_topk(s32, k)
+        gi, gs, _ = res[0]
+        out["parity_full_size"] = bool((gi[0] == oi).all() and (gs[0].view(np.uint32) == osc.view(np.uint32)).all())
+    if IB != 1 and QB not in (1, 4):
+        out["parity_note"] = "the reference throws for queryBits=%d on an indexBits=%d index: integer dot pinned by fixtures, float score parity unpinned" % (QB, IB)
+    ix.close()
+    return out
+
+
+def napi_leg(B, ix, centroid, dim, k, sim_name, SIM, QB, nq=256):
+    """the drop-in boundary at scale: the timed index is saved, a node process loads it through bbq_napi.node and runs the reference's
+    call shapes with RAW fp32 queries (tests/js/bench_scale.js); its answers must equal this process's ctypes answers bit for bit"""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("node") is None:
+        return {"error": "node not installed"}
+    addon = os.path.join(ROOT, "better-binary-quantization_amd", "lib", "bbq_napi.node")
+    if not os.path.exists(addon):
+        return {"error": "bbq_napi.node is not built"}
+    tmp = tempfile.mkdtemp(prefix="bbq_napi_")
+    try:
+        prefix = os.path.join(tmp, "index")
+        ix.save(prefix, centroid, SIM)
+        raw = synth_raw_queries(5, nq, dim)
+        raw.tofile(os.path.join(tmp, "queries.f32"))
+        qq, qc = B.quantize_queries(raw, centroid, SIM, QB)
+        gi, gs, gc = ix.search_batch(qq, qc, QB, SIM, k)
+        r = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "bench_scale.js"), prefix, os.path.join(tmp, "queries.f32"), str(dim), str(k),
+                            sim_name, os.path.join(tmp, "answers.bin"), "3", "200"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        if r.returncode != 0:
+            return {"error": ("node exited with %d: " % r.returncode) + r.stderr[-300:]}
+        js = json.loads(r.stdout.strip().splitlines()[-1])
+        blob = np.fromfile(os.path.join(tmp, "answers.bin"), np.uint8)
+        ji = blob[:nq * k * 4].view(np.int32).reshape(nq, k)
+        jsx = blob[nq * k * 4:nq * k * 8].view(np.uint32).reshape(nq, k)
+        jc = blob[nq * k * 8:].view(np.int32)
+        same = bool((jc == gc).all() and (ji == gi).all() and (jsx == gs.view(np.uint32)).all())
+        return {"value": js["batch_queries_per_s"], "unit": "queries/s", "call": "format.searchNearestNeighborsBatch(raw fp32 queries, values, k) through bbq_napi.node, %d queries per call" % nq,
+                "batch_ms_per_call": js["batch_ms_per_call"], "p50_ms": js["single_p50_ms"], "p99_ms": js["single_p99_ms"], "min_ms": js["single_min_ms"],
+                "single_call": "format.searchNearestNeighbors(raw fp32 query, values, k): normalise + quantize + sweep + top-k per call (src/binaryQuantizationFormat.ts:308-412)",
+                "single_queries_per_s": js["single_queries_per_s"], "single_equals_batch": js["single_equals_batch"], "identical_to_ctypes": same,
+                "index": "loaded by the node process from the .veb/.vemb pair this process saved (%d rows)" % js["rows"], "load_ms": js["load_ms"], "node": js["node"]}
+    except Exception as e:  # informational leg: never fail the bench for it
+        return {"error": str(e)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def inprocess_only(args):
+    """child process of an N-GPU run (rank 0 starts it after every rank has closed its index): the SAME synthetic index behind ONE
+    handle row-sharded over the N devices of this process (bbq_index_create_multi - what the TypeScript host uses), the same step.
+    A process of its own so that nothing it does can take the ranks' line down.  Prints one JSON object."""
+    import bbq_amd as B
+    N, dim, k, Q = args.rows, args.dim, args.k, args.batch if args.batch > 0 else min(2048, max(512, 256 * args.gpus))
+    SIM = {"EUCLIDEAN": 0, "COSINE": 1, "MAXIMUM_INNER_PRODUCT": 2}[args.sim]
+    QB, IB = args.query_bits, args.index_bits
+    pb = (dim + 7) // 8
+    codes, corr = synth_rows(1, 0, N, pb) if IB == 1 else synth_rows_multibit(1, 0, N, dim, IB)
+    cdp = float(B.centroid_dp(synth_centroid(dim)))
+    devices = [0] * args.gpus if args.same_device else list(range(args.gpus))
+    mx = B.Index.create_multi(codes, corr, dim, cdp, devices, index_bits=IB, pilot_rows=args.pilot)
+    mx.set_option("pipeline_slots", args.slots)
+    mx.set_option("replay_threads", args.replay_threads)
+    mx.set_option("round_queries", Q)
+    n_steps = args.warmup + args.steps
+    qq_all, qc_all = synth_queries(2, n_steps * Q, dim, QB)
+    batches = [(qq_all[i * Q:(i + 1) * Q], qc_all[i * Q:(i + 1) * Q]) for i in range(n_steps)]
+    # all steps in ONE call: the handle pipelines its rounds (round r + 1 is on the devices while round r is merged)
+    wq = np.concatenate([b[0] for b in batches[:args.warmup]]) if args.warmup else None
+    if wq is not None:
+        mx.search_batch(wq, np.concatenate([b[1] for b in batches[:args.warmup]]), QB, SIM, k)
+    mx.reset_stats()
+    tq, tc = np.concatenate([b[0] for b in batches[args.warmup:]]), np.concatenate([b[1] for b in batches[args.warmup:]])
+    t0 = time.perf_counter()
+    res = mx.search_batch(tq, tc, QB, SIM, k)
+    dt = time.perf_counter() - t0
+    st = mx.stats()
+    out = {"value": args.steps * Q / dt, "unit": "queries/s", "shards": mx.shards, "devices": devices, "queries_per_round": Q, "steps": args.steps,
+           "ms_per_step": dt / args.steps * 1e3, "host_replays": st["host_replays"], "dense_fallbacks": st["dense_fallbacks"],
+           "aggregate_dominant_GBps": st["total_scan_bytes"] / (st["total_scan_ms"] * 1e-3) / 1e9 if st["total_scan_ms"] > 0 else None,
+           "path": "bbq_index_create_multi: one handle, one process, a host thread per shard, answers merged on the calling thread"}
+    if not args.no_parity:
+        import orclib as O
+        s32 = oracle_scores(O, codes, corr, dim, tq[0], tc[0], QB, SIM, cdp, IB)
+        oi, osc = O.heap_topk(s32, k)
+        out["parity_full_size"] = bool((res[0][0] == oi).all() and (res[1][0].view(np.uint32) == osc.view(np.uint32)).all())
+    mx.close()
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+def run_inprocess_child(args):
+    """rank 0 of an N-GPU run: the in-process multi-device leg in a fresh process (see inprocess_only)"""
+    import subprocess
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                                   "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "HIP_VISIBLE_DEVICES",
+                                                                   "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")}
+    for k_ in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):   # a launcher that narrows devices per rank would hide the others
+        if k_ in os.environ and len(os.environ[k_].split(",")) >= args.gpus:
+            env[k_] = os.environ[k_]
+    cmd = [sys.executable, os.path.abspath(__file__), "--inprocess-only"] + [a for a in sys.argv[1:] if a != "--force-dist"]
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+        if r.returncode != 0:
+            return {"error": "child exited with %d: %s" % (r.returncode, r.stderr[-300:])}
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": str(e)[:300]}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks (one per GPU) with torch.distributed.run
     as a FRESH child process - before this process has made any GPU/HIP call - relay rank 0's JSON line (the children inherit
@@ -292,6 +460,14 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1: nccl (= RCCL) or gloo (rehearsal)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the sharded code path (process group, collectives) even with one rank")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short legs of BASELINE configs 2, 4 and 5 (default run on one GPU only)")
+    ap.add_argument("--no-napi", action="store_true", help="skip the Node/N-API leg (the drop-in boundary driven from node at the timed size)")
+    ap.add_argument("--no-raw", action="store_true", help="skip the raw-query leg (query quantization inside the timed region)")
+    ap.add_argument("--quantize-threads", type=int, default=16, help="host threads of bbq_quantize_queries in the raw-query leg")
+    ap.add_argument("--inprocess-shards", type=int, default=4,
+                    help="one GPU: also time the in-process multi-device index (bbq_index_create_multi) with this many shards, all on GPU 0 "
+                         "(prices the sharded pipeline's own overhead); 0 = skip.  With --gpus N the leg runs over the N devices instead")
+    ap.add_argument("--inprocess-only", action="store_true", help=argparse.SUPPRESS)   # child process of an N-GPU run, see inprocess_only()
     ap.add_argument("--dry-run", action="store_true",
                     help="launch rehearsal without a device: start the ranks, form the process group, run the barriers and the max-over-ranks "
                          "reduction, print the line with value null - NO measurement is made (CPU test of the --gpus N launch path)")
@@ -303,6 +479,8 @@ def main():
     elif args.config == "c5":
         args.rows, args.dim, args.query_bits, args.index_bits = 1_000_000, 1024, 8, 2
 
+    if args.inprocess_only:
+        raise SystemExit(inprocess_only(args))
     rc = self_launch(args)
     if rc is not None:
         raise SystemExit(rc)
@@ -355,7 +533,8 @@ def main():
     SIM = {"EUCLIDEAN": 0, "COSINE": 1, "MAXIMUM_INNER_PRODUCT": 2}[args.sim]
     QB, IB = args.query_bits, args.index_bits
     pb = (dim + 7) // 8
-    cdp = 0.0009110655808639536
+    centroid = synth_centroid(dim)
+    cdp = float(B.centroid_dp(centroid))   # getCentroidDP(undefined) = centroid . centroid
 
     def rows_of(a, b):
         return synth_rows(1, a, b, pb) if IB == 1 else synth_rows_multibit(1, a, b, dim, IB)
@@ -422,10 +601,21 @@ def main():
     if dist is not None:
         # where a batch's time goes on every rank (scan on the scanner thread, the rest next to it on the main thread): max over ranks
         mine = searcher.phases_ms()
-        keys = ["scan", "headers", "payload", "to_host", "replay", "answers"]
+        keys = ["scan", "exchange", "to_host", "merge", "answers", "lists"]
         tt = torch.tensor([mine[k_] for k_ in keys], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        sharded = {"max_over_ranks_ms_per_batch": {k_: round(float(v), 3) for k_, v in zip(keys, tt.tolist())}, "rank0": mine}
+        sharded = {"max_over_ranks_ms_per_batch": {k_: round(float(v), 3) for k_, v in zip(keys, tt.tolist())}, "rank0": mine,
+                   "what": "scan = sweep of a batch, enqueue to device-done (overlaps the previous batch's exchange + merge); exchange = all_to_all of the "
+                           "shard-local answers ((k + 3) x 8 B per shard and query); merge = bbq_merge_answers of the owner's block; answers = "
+                           "need-lists all_reduce + gather to rank 0; lists = the ABI-2 list exchange + heap replay, only for batches with equal "
+                           "scores in an answer"}
+        # per-rank roofline fraction of the dominant launch (HIP events on its own stream)
+        lb = st["total_scan_bytes"] / max(st["total_scan_launches"], 1)
+        lm = st["total_scan_ms"] / max(st["total_scan_launches"], 1)
+        fr = torch.tensor([lb / (lm * 1e-3) / 1e9 / HBM_PEAK_GBS if lm > 0 else 0.0], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        allf = [torch.zeros_like(fr) for _ in range(world)]
+        dist.all_gather(allf, fr)
+        sharded["frac_hipevent_per_rank"] = [round(float(x.item()), 4) for x in allf]
     batched = None
     if dist is None and args.shared_sweep in (4, 8, 32) and IB == 1:
         # API extension, reported separately: `shared_sweep` queries share one sweep of the index
@@ -442,10 +632,67 @@ def main():
         stb = ix.stats()
         lb = stb["total_scan_bytes"] / max(stb["total_scan_launches"], 1)
         lms = stb["total_scan_ms"] / max(stb["total_scan_launches"], 1)
-        batched = {"queries_per_sweep": args.shared_sweep, "value": args.steps * Q / dtb, "unit": "queries/s",
+        bq = args.steps * Q / dtb
+        stream_gbps = lb / (lms * 1e-3) / 1e9 if lms > 0 else None
+        # int8 MFMA work of the shared sweep: rows x dim x 2 ops per query (the popcount path is priced as the same contraction)
+        i8_peak = 5.0e15   # dense I8 = 2 x the 2.5 PFLOP/s bf16 figure of /opt/skills/guides/MI355X_MICROARCH.md
+        batched = {"queries_per_sweep": args.shared_sweep, "value": bq, "unit": "queries/s",
+                   "roofline": {"frac_hbm": (stream_gbps / HBM_PEAK_GBS) if stream_gbps else None,
+                                "frac_i8_mfma": bq * N * dim * 2 / i8_peak if args.shared_sweep == 32 else None,
+                                "bound": "neither: dependent LDS -> MFMA -> pre-filter latencies per tile (profiles/, DESIGN.md 'Shared sweeps')",
+                                "index_stream_GBps": stream_gbps, "i8_peak_ops": i8_peak},
                    "identical_to_unshared": same, "bound": "matrix cores + valu pre-filter (32 queries share each row load)" if args.shared_sweep == 32 else "valu (popcount + f64 bound per query; HBM bytes amortised over the sweep)",
                    "index_stream_GBps": lb / (lms * 1e-3) / 1e9 if lms > 0 else None}
         ix.set_option("sweep_share", 1)
+
+    raw = None
+    if dist is None and not args.no_raw:
+        # the reference's timed unit starts from the RAW query: searchNearestNeighbors normalises and quantizes it first
+        # (src/binaryQuantizationFormat.ts:337-347).  Same step as above with bbq_quantize_queries inside the timed region.
+        raw_all = synth_raw_queries(6, n_steps * Q, dim)
+        raw_batches = [raw_all[i * Q:(i + 1) * Q] for i in range(n_steps)]
+        for rb in raw_batches[:args.warmup]:
+            qq_r, qc_r = B.quantize_queries(rb, centroid, SIM, QB, n_threads=args.quantize_threads)
+            ix.search_batch(qq_r, qc_r, QB, SIM, k)
+        barrier()
+        tq = 0.0
+        tr = time.perf_counter()
+        for rb in raw_batches[args.warmup:]:
+            t1 = time.perf_counter()
+            qq_r, qc_r = B.quantize_queries(rb, centroid, SIM, QB, n_threads=args.quantize_threads)
+            tq += time.perf_counter() - t1
+            ix.search_batch(qq_r, qc_r, QB, SIM, k)
+        barrier()
+        dtr = time.perf_counter() - tr
+        raw = {"value": args.steps * Q / dtr, "unit": "queries/s", "ms_per_step": dtr / args.steps * 1e3,
+               "quantize_threads": args.quantize_threads, "quantize_us_per_query_wall": tq / (args.steps * Q) * 1e6,
+               "what": "the same step from raw fp32 queries: normalise + quantizeQueryVector (bbq_quantize_queries, host threads) + sweep + top-k; "
+                       "quantization is NOT overlapped with the sweep of the previous step here"}
+
+    inproc = None
+    if dist is None and args.inprocess_shards > 1:
+        # the in-process multi-device index (what the TS host uses, bbq_index_create_multi) with every shard on THIS GPU: the same
+        # rows, the same queries; prices the sharded pipeline's own overhead (pilot replicas, per-shard launch chains, answer merge)
+        try:
+            mx = B.Index.create_multi(codes, corr, dim, cdp, [device] * args.inprocess_shards, index_bits=IB, pilot_rows=args.pilot)
+            mx.set_option("pipeline_slots", args.slots)
+            mx.set_option("replay_threads", args.replay_threads)
+            mres = [mx.search_batch(qq, qc, QB, SIM, k) for qq, qc in batches[:max(1, args.warmup)]][0]
+            mx.reset_stats()
+            barrier()
+            tm = time.perf_counter()
+            for qq_m, qc_m in batches[args.warmup:]:
+                mx.search_batch(qq_m, qc_m, QB, SIM, k)
+            barrier()
+            dtm = time.perf_counter() - tm
+            mst = mx.stats()
+            inproc = {"value": args.steps * Q / dtm, "unit": "queries/s", "shards": mx.shards, "devices": "all shards on GPU %d (one-GPU run)" % device,
+                      "vs_single_index": (args.steps * Q / dtm) / (args.steps * Q / dt), "host_replays": mst["host_replays"],
+                      "dense_fallbacks": mst["dense_fallbacks"],
+                      "identical_to_single_index": bool((mres[0] == results[0][0]).all() and (mres[1].view(np.uint32) == results[0][1].view(np.uint32)).all())}
+            mx.close()
+        except Exception as e:  # informational leg
+            inproc = {"error": str(e)[:300]}
 
     latency = None
     if dist is None and args.latency_calls > 0:
@@ -493,7 +740,7 @@ def main():
                        else "queries/sec, %dx%d %d-bit index, queryBits=%d, k=%d, %s" % (N, dim, IB, QB, k, args.sim)),
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u64 popcount + f64 score epilogue" if IB == 1 else "u4/u8 packed integer dot (u32 accumulate) + f64 score epilogue",
+            "dtype": "u32 popcount + f64 score epilogue" if IB == 1 else "u4/u8 packed integer dot (u32 accumulate) + f64 score epilogue",
             "data": "synthetic",
             "config": {"workload": "%dx%d-dim %d-bit index, queryBits=%d, k=%d, %s, row-sharded over %d GPU(s)" % (N, dim, IB, QB, k, args.sim, world),
                        "queries_per_step": Q, "queries_per_launch": sub_batch, "sweeps_per_query": 1,
@@ -517,6 +764,12 @@ def main():
             out["latency"] = latency
         if batched is not None:
             out["batched"] = batched
+        if raw is not None:
+            out["raw_queries"] = raw
+        if inproc is not None:
+            out["inprocess_multi"] = inproc
+        if world == 1 and dist is None and not args.no_napi and IB == 1:
+            out["napi"] = napi_leg(B, ix, centroid, dim, k, args.sim, SIM, QB)
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed at N=1 only
             cqps, done, rows, secs = cpu_baseline(dim, k, codes, corr, qq_all, qc_all, cdp, QB, SIM, IB)
             model, ncpu = host_cpu()
@@ -555,15 +808,38 @@ def main():
         if IB != 1 and QB not in (1, 4):
             out["parity_note"] = ("the reference throws for queryBits=%d on an indexBits=%d index (src/binaryQuantizedScorer.ts:95-97): the integer dot "
                                   "product is pinned by fixtures of computeQuantizedDotProduct, the float score is its per-row 4-bit form - parity unpinned" % (QB, IB))
+        headline = (N, dim, k, QB, IB, args.sim) == (10_000_000, 768, 100, 4, 1, "COSINE")
+        if world == 1 and dist is None and headline and not args.no_configs:
+            # the other BASELINE configs as short legs of the same run (c3 = the headline line itself; c1 is the CPU-sized README case:
+            # tests/js/bench_c1.js).  Each leg builds its own synthetic index, so the headline index goes first.
+            ix.close()
+            del codes, corr
+            legs = {}
+            for name, (cN, cdim, cqb, cib, csim) in {"c2": (1_000_000, 768, 4, 1, "COSINE"), "c4": (10_000_000, 1536, 4, 1, "MAXIMUM_INNER_PRODUCT"),
+                                                     "c5": (1_000_000, 1024, 8, 2, "COSINE")}.items():
+                try:
+                    legs[name] = config_leg(B, torch, name, cN, cdim, k, cqb, cib, csim, device, args.steps, args.warmup, 256, args.slots, args.replay_threads,
+                                            parity=not args.no_parity)
+                except Exception as e:
+                    legs[name] = {"error": str(e)[:300]}
+                log("config leg %s: %s" % (name, json.dumps(legs[name])[:400]))
+            out["configs"] = legs
         if not args.no_recall and IB == 1:
             ix.close()   # the probe needs the memory (30.7 GB of fp32 at the headline size, twice on the device while the index is built)
             rec, desc = recall_probe(B, device, n=args.recall_rows if args.recall_rows > 0 else min(N, 10_000_000), dim=dim)
             out["recall_at_100"] = rec
             out["recall_config"] = desc
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ix.close()
     if dist is not None:
+        dist.barrier()   # every rank has released its shard
+        if rank == 0 and args.inprocess_shards != 0:
+            # the other deployment of the same sharding - one process, one handle over the N devices - timed by a child process while
+            # the ranks wait (their GPUs are idle now)
+            out["inprocess_multi"] = run_inprocess_child(args)
         dist.barrier()
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -348,7 +348,10 @@ int multi_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, 
         if (rc_all != BBQ_OK) err_all = bbq_last_error();
       }
       for (int32_t q = 0; q < nq && rc_all == BBQ_OK; ++q) {
-        if (status[(size_t)q] == 0) { ix->stats.candidates += keff; continue; }
+        if (status[(size_t)q] == 0) {  // answered from the shards' answers: the entries that were merged count as its candidates
+          for (int s = 0; s < S; ++s) ix->stats.candidates += (int64_t)(uint32_t)blocks[(size_t)s][(size_t)q * (size_t)strides[(size_t)s] + 1];
+          continue;
+        }
         const int64_t qi = q0 + q;
         bool flagged = status[(size_t)q] == 2;
         int64_t cand = 0;

@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(lib, n), "libbbq.so does not export %s" % n
     assert sorted(capi.SYMBOLS) == names, "capi.py binds a different set than include/bbq.h declares"
-    assert lib.bbq_abi_version() == 2
+    assert lib.bbq_abi_version() == 3
 
 
 def test_no_cpu_fallback_without_device():
@@ -35,6 +35,33 @@ def test_no_cpu_fallback_without_device():
         B.Index(np.zeros((4, 1), np.uint8), np.zeros((4, 4)), 8, 0.0)
     assert e.value.code == capi.ERR_NO_DEVICE
     assert "no CPU fallback" in str(e.value)
+
+
+def test_create_arguments_are_checked_before_the_device():
+    """argument errors that do not need a device: the dimension bound of the 31-bit integer dot product (dim * 255 for packed 1-bit
+    rows, dim * 255 * 255 for multi-bit fields) on both sides of the limit, and the creation options"""
+    if B.device_count() > 0:
+        pytest.skip("a HIP device is present: the accepted side would allocate")
+    z8, z64 = np.zeros((1, 8), np.uint8), np.zeros((1, 4))
+
+    def code_of(dim, ib, **kw):
+        with pytest.raises(B.BBQError) as e:
+            capi.Index(z8, z64, dim, 0.0, index_bits=ib, **kw)
+        return e.value.code
+
+    lim1 = 0x7fffffff // 255            # 8 421 504: largest 1-bit dimension
+    limm = 0x7fffffff // (255 * 255)    # 33 025: largest multi-bit dimension
+    assert code_of(limm + 1, 1) == capi.ERR_NO_DEVICE        # accepted for 1-bit rows (round 2 refused it): only the device is missing
+    assert code_of(lim1, 1) == capi.ERR_NO_DEVICE
+    assert code_of(lim1 + 1, 1) == capi.ERR_UNSUPPORTED
+    assert code_of(limm, 2) == capi.ERR_NO_DEVICE
+    assert code_of(limm + 1, 2) == capi.ERR_UNSUPPORTED
+    assert code_of(limm + 1, 8) == capi.ERR_UNSUPPORTED
+    assert code_of(64, 1, corrections=7) == capi.ERR_INVALID_ARG
+    assert code_of(64, 1, corrections="inline") == capi.ERR_NO_DEVICE
+    with pytest.raises(B.BBQError) as e:
+        capi.Index.build(np.zeros((2, 64), np.float32), 1, corrections=-5)
+    assert e.value.code == capi.ERR_INVALID_ARG
 
 
 def test_product_never_links_the_oracle():

@@ -87,7 +87,15 @@ def test_multi_device_rounds_dense_fallbacks_and_large_k():
                 oi, osc = O.heap_topk(want[i], k)
                 np.testing.assert_array_equal(idx[i, :cnt[i]], oi)
             st = ix.stats()
-            assert st["dense_fallbacks"] == 0 and st["candidates"] > nq * k and st["total_scan_launches"] > 0
+            assert st["dense_fallbacks"] == 0 and st["candidates"] >= nq * k and st["total_scan_launches"] > 0
+            assert st["host_replays"] == 0   # gaussian data has no equal scores in an answer: merged from the shard-local answers alone
+        # the ABI-2 path (every query replays its lists) is still there and agrees
+        ix.set_option("device_select", 0)
+        idx0, sc0, _ = ix.search_batch(qq, qc, 4, sim, k)
+        assert ix.stats()["host_replays"] == nq
+        ix.set_option("device_select", 1)
+        np.testing.assert_array_equal(idx0, idx)
+        np.testing.assert_array_equal(canon32(sc0), canon32(sc))
         for kk in (5000, n + 10):
             idx, sc = ix.search(qq[0], qc[0], 4, sim, kk)
             oi, osc = O.heap_topk(want[0], kk)
@@ -163,6 +171,144 @@ def test_multi_device_full_size_10m():
         got = ix.search_batch(qq, qc, 4, 1, k)
         np.testing.assert_array_equal(got[0], want[0])
         np.testing.assert_array_equal(canon32(got[1]), canon32(want[1]))
-        assert ix.stats()["dense_fallbacks"] == 0
+        st = ix.stats()
+        assert st["dense_fallbacks"] == 0 and st["host_replays"] == 0
+    finally:
+        ix.close()
+
+
+def _key_of(s32):
+    b = s32.view(np.uint32).astype(np.int64)
+    return np.where(b & 0x80000000, (~b) & 0xFFFFFFFF, b | 0x80000000)
+
+
+@pytest.mark.parametrize("name,pilot", [("big_20000x128_cos", 2048), ("ties_cos_qb4", 1024), ("big_50000x768_cos", 0)])
+def test_shard_answers_block_and_async_scans(name, pilot):
+    """bbq_shard_scan_begin / _wait on one shard: (a) the answer block is what include/bbq.h says - the cut is the (k+1)-th largest key
+    over the shard's own rows and its pilot replica, the entries are the shard's own rows above it, descending; (b) two batches in
+    flight give what two synchronous scans give; (c) merged with the root shard's block the answers are the reference's"""
+    import torch
+    g, sim, base, queries, codes, corr, cen, cdp = _case(name)
+    n, dim, qb = g["n"], g["dim"], g["qb"]
+    k = 10
+    half = (n // 2) // 512 * 512
+    P = min(pilot, half) // 512 * 512
+    root = B.Index(codes[:half], corr[:half], dim, cdp)
+    sh = B.Index(codes[half:], corr[half:], dim, cdp, row_base=half, pilot_codes=codes[:P] if P else None, pilot_corr=corr[:P] if P else None)
+    qs = [B.quantize_query(q, cen, sim, qb, g["lambda"], g["iters"]) for q in queries]
+    qq, qc = np.stack([a for a, _ in qs]), np.stack([b for _, b in qs])
+    nq, stride = len(qq), k + 3
+    try:
+        for ix in (root, sh):
+            ix.set_option("first_segment_rows", 1024)
+            ix.set_option("segment_growth", 2)
+            ix.set_option("batch_queries", 2)   # several sub-batches per batch: slots are reused while a batch is in flight
+
+        def bufs(ix):
+            cap = int(ix.shard_list_cap(k)) * nq
+            return {"cap": cap, "packed": torch.zeros(cap, dtype=torch.int64, device="cuda"), "off": torch.zeros(nq + 1, dtype=torch.int64, device="cuda"),
+                    "flags": torch.zeros(nq, dtype=torch.int32, device="cuda"), "ans": torch.zeros(nq * stride, dtype=torch.int64, device="cuda")}
+
+        def begin(ix, b, q0, q1):
+            ix.shard_scan_begin(qq[q0:q1], qc[q0:q1], qb, sim, k, b["packed"].data_ptr(), b["cap"], b["off"].data_ptr(), b["flags"].data_ptr(),
+                                b["ans"].data_ptr(), stride)
+
+        b1, b2, b3 = bufs(sh), bufs(sh), bufs(sh)
+        assert nq >= 2
+        m = nq // 2
+        begin(sh, b1, 0, m)          # two batches in flight on one index
+        begin(sh, b2, m, nq)
+        with pytest.raises(B.BBQError):
+            begin(sh, b3, 0, 1)      # a third one is refused
+        t1 = sh.shard_scan_wait()
+        t2 = sh.shard_scan_wait()
+        with pytest.raises(B.BBQError):
+            sh.shard_scan_wait()     # nothing in flight
+        begin(sh, b3, 0, nq)         # the same queries in one batch
+        t3 = sh.shard_scan_wait()
+        assert t1 + t2 == t3
+        a12 = np.concatenate([b1["ans"].cpu().numpy().view(np.uint64).reshape(nq, stride)[:m],
+                              b2["ans"].cpu().numpy().view(np.uint64).reshape(nq, stride)[:nq - m]])
+        a3 = b3["ans"].cpu().numpy().view(np.uint64).reshape(nq, stride)
+        np.testing.assert_array_equal(a12, a3)
+        p12 = np.concatenate([b1["packed"][:t1].cpu().numpy(), b2["packed"][:t2].cpu().numpy()])
+        np.testing.assert_array_equal(p12, b3["packed"][:t3].cpu().numpy())
+        # (a) the block against its definition
+        for q in range(nq):
+            _, _, s32 = O.score_all(codes, corr, dim, qq[q], qc[q], qb, sim, cdp)
+            if np.isnan(s32).any():
+                continue
+            keys = _key_of(s32)
+            seen = np.unique(np.concatenate([np.arange(0, P), np.arange(half, n)]))
+            ks = np.sort(keys[seen])[::-1]
+            cut = int(ks[k]) if len(ks) >= k + 1 else 0
+            own = np.arange(half, n)
+            own = own[keys[own] > cut]
+            blk = a3[q]
+            assert int(blk[0] >> np.uint64(32)) == 0 and int(blk[1] >> np.uint64(32)) == 0
+            assert int(blk[2]) == cut
+            mm = int(blk[1] & np.uint64(0xffffffff))
+            assert mm == len(own)
+            rows = (blk[3:3 + mm] >> np.uint64(32)).astype(np.int64)
+            assert sorted(rows.tolist()) == sorted(own.tolist())
+            got_keys = _key_of((blk[3:3 + mm] & np.uint64(0xffffffff)).astype(np.uint32).view(np.float32))
+            assert (np.diff(got_keys) <= 0).all()
+            np.testing.assert_array_equal((blk[3:3 + mm] & np.uint64(0xffffffff)).astype(np.uint32), s32[rows].view(np.uint32))
+        # (c) merged with the root shard
+        br = bufs(root)
+        begin(root, br, 0, nq)
+        tr = root.shard_scan_wait()
+        ar = br["ans"].cpu().numpy().view(np.uint64).reshape(nq, stride)
+        idx, sc, cnt, status = B.merge_answers([a3, ar], nq, n, k, 2)
+        lists = [br["packed"][:tr].cpu().numpy().view(np.uint64), b3["packed"][:t3].cpu().numpy().view(np.uint64)]
+        offs = [br["off"].cpu().numpy(), b3["off"].cpu().numpy()]
+        ri, rs, rc = B.replay_batch(lists, offs, nq, n, k, 2)
+        for q in range(nq):
+            _, _, s32 = O.score_all(codes, corr, dim, qq[q], qc[q], qb, sim, cdp)
+            oi, osc = O.heap_topk(s32, k)
+            np.testing.assert_array_equal(ri[q, :rc[q]], oi)                       # the lists (rank k + 1 supersets) replay to the reference's answer
+            np.testing.assert_array_equal(canon32(rs[q, :rc[q]]), canon32(osc))
+            if status[q] == 0:
+                np.testing.assert_array_equal(idx[q, :cnt[q]], oi)
+                np.testing.assert_array_equal(canon32(sc[q, :cnt[q]]), canon32(osc))
+            else:
+                top = np.sort(s32)[::-1][:k + 1].astype(np.float64)
+                assert len(np.unique(top)) < len(top)                              # only equal scores may send a query to the replay
+        if name.startswith("big_"):
+            assert (status == 0).all()
+        st = sh.stats()
+        assert st["total_scan_launches"] > 0
+    finally:
+        root.close()
+        sh.close()
+
+
+def test_shard_scan_begin_argument_errors():
+    rng = np.random.default_rng(3)
+    n, dim = 4096, 64
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    codes, corr, cen = B.quantize_vectors(base, 1)
+    ix = B.Index(codes, corr, dim, B.centroid_dp(cen))
+    import torch
+    qq, qc = B.quantize_queries(rng.standard_normal((2, dim)).astype(np.float32), cen, 1, 4)
+    d = torch.zeros(1 << 16, dtype=torch.int64, device="cuda")
+    try:
+        with pytest.raises(B.BBQError):   # stride too small for k
+            ix.shard_scan_begin(qq, qc, 4, 1, 10, d.data_ptr(), 1 << 15, d.data_ptr(), d.data_ptr(), d.data_ptr(), 12)
+        with pytest.raises(B.BBQError):   # answers beyond what the finalize launch selects
+            ix.shard_scan_begin(qq, qc, 4, 1, 2000, d.data_ptr(), 1 << 15, d.data_ptr(), d.data_ptr(), d.data_ptr(), 2003)
+        with pytest.raises(B.BBQError):
+            ix.shard_scan_wait()
+        # an index destroyed with a batch in flight settles it first
+        p, o, f = torch.zeros(1 << 16, dtype=torch.int64, device="cuda"), torch.zeros(3, dtype=torch.int64, device="cuda"), torch.zeros(2, dtype=torch.int32, device="cuda")
+        ix.shard_scan_begin(qq, qc, 4, 1, 10, p.data_ptr(), 1 << 16, o.data_ptr(), f.data_ptr(), None, 0)
+    finally:
+        ix.close()
+    # the device context is intact afterwards
+    ix = B.Index(codes, corr, dim, B.centroid_dp(cen))
+    try:
+        idx, sc = ix.search(qq[0], qc[0], 4, 1, 10)
+        _, _, s32 = O.score_all(codes, corr, dim, qq[0], qc[0], 4, 1, B.centroid_dp(cen))
+        np.testing.assert_array_equal(idx, O.heap_topk(s32, 10)[0])
     finally:
         ix.close()

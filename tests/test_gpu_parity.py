@@ -574,6 +574,88 @@ def test_full_size_10m_x_768_properties():
     np.testing.assert_array_equal(rs.view(np.uint32), sc.view(np.uint32))
 
 
+def test_config2_shape_1m_x_768_properties():
+    """BASELINE config 2 at its real size (1 M x 768-d, queryBits 4 / indexBits 1, k = 100): the plan the library picks below
+    2.5 M rows - 128 queries per sub-batch - held to the oracle for one query of every sub-batch position, and to the size-independent
+    properties for all 300: == dense replay, == host heap replay, == shared sweeps (VALU and matrix cores), == the single-query call
+    shape (latency plan, append mode), == inline layout, == a 3-shard split behind one handle"""
+    import bench
+    n, dim, k, pb = 1_000_000, 768, 100, 96
+    codes, corr = bench.synth_rows(1, 0, n, pb)
+    qq, qc = bench.synth_queries(2, 300, dim)      # 128 + 128 + 44: three sub-batches, the last one partial
+    cdp = float(B.centroid_dp(bench.synth_centroid(dim)))
+    ix = _make_index(codes, corr, dim, cdp, True)
+    try:
+        ix.set_option("pipeline_slots", 3)
+        idx, sc, cnt = ix.search_batch(qq, qc, 4, 1, k)
+        st = ix.stats()
+        assert (cnt == k).all() and st["dense_fallbacks"] == 0 and st["host_replays"] == 0
+        # 128 queries per dominant launch (the library's choice for this size): rows x queries of the last full sub-batch or the tail
+        assert st["last_scan_rows"] > 0
+        # (1) the oracle: first / last query of a sub-batch and one of the partial tail
+        for q in (0, 127, 128, 299):
+            _, _, s32 = O.score_all(codes, corr, dim, qq[q], qc[q], 4, 1, cdp)
+            oi, osc = O.heap_topk(s32, k)
+            np.testing.assert_array_equal(idx[q], oi)
+            np.testing.assert_array_equal(sc[q].view(np.uint32), osc.view(np.uint32))
+        # (2) returned scores are the rows' own scores, descending
+        for q in (5, 200):
+            for j in (0, 50, 99):
+                _, _, one = ix.score_rows(qq[q], qc[q], 4, 1, int(idx[q, j]), 1)
+                assert one[0].view(np.uint32) == sc[q, j].view(np.uint32)
+            assert (np.diff(sc[q]) <= 0).all()
+        # (3) dense replay == sparse segments
+        ix.set_option("force_dense", 1)
+        di, ds, _ = ix.search_batch(qq[126:130], qc[126:130], 4, 1, k)
+        ix.set_option("force_dense", 0)
+        np.testing.assert_array_equal(di, idx[126:130])
+        np.testing.assert_array_equal(ds.view(np.uint32), sc[126:130].view(np.uint32))
+        # (4) host heap replay of every query == device-selected answers
+        ix.set_option("device_select", 0)
+        hi, hs, _ = ix.search_batch(qq, qc, 4, 1, k)
+        assert ix.stats()["host_replays"] == 300
+        ix.set_option("device_select", 1)
+        np.testing.assert_array_equal(hi, idx)
+        np.testing.assert_array_equal(hs.view(np.uint32), sc.view(np.uint32))
+        # (5) shared sweeps == one sweep per query
+        for share in (8, 32):
+            ix.set_option("sweep_share", share)
+            si, ss, _ = ix.search_batch(qq, qc, 4, 1, k)
+            np.testing.assert_array_equal(si, idx)
+            np.testing.assert_array_equal(ss.view(np.uint32), sc.view(np.uint32))
+        ix.set_option("sweep_share", 1)
+        # (6) the reference's call shape: one query per call
+        for q in (0, 1, 150, 299):
+            i1, s1 = ix.search(qq[q], qc[q], 4, 1, k)
+            np.testing.assert_array_equal(i1, idx[q])
+            np.testing.assert_array_equal(s1.view(np.uint32), sc[q].view(np.uint32))
+        # (7) other sub-batch sizes give the same answers
+        for sub in (32, 100):
+            ix.set_option("batch_queries", sub)
+            bi, bs, _ = ix.search_batch(qq, qc, 4, 1, k)
+            np.testing.assert_array_equal(bi, idx)
+            np.testing.assert_array_equal(bs.view(np.uint32), sc.view(np.uint32))
+        ix.set_option("batch_queries", 0)
+    finally:
+        ix.close()
+    ix = _make_index(codes, corr, dim, cdp, False)
+    try:
+        ii, isc, _ = ix.search_batch(qq, qc, 4, 1, k)
+        np.testing.assert_array_equal(ii, idx)
+        np.testing.assert_array_equal(isc.view(np.uint32), sc.view(np.uint32))
+    finally:
+        ix.close()
+    mx = B.Index.create_multi(codes, corr, dim, cdp, [0, 0, 0], pilot_rows=32768)
+    try:
+        mx.set_option("round_queries", 128)
+        mi, ms, _ = mx.search_batch(qq, qc, 4, 1, k)
+        np.testing.assert_array_equal(mi, idx)
+        np.testing.assert_array_equal(ms.view(np.uint32), sc.view(np.uint32))
+        assert mx.stats()["host_replays"] == 0 and mx.stats()["dense_fallbacks"] == 0
+    finally:
+        mx.close()
+
+
 @pytest.mark.parametrize("dim,qb,sim", [(2000, 4, 1), (264, 8, 2), (4096, 2, 0), (520, 1, 1)])
 def test_generic_row_widths(dim, qb, sim):
     """dims whose packed rows are not one of the compile-time widths take the runtime-loop kernel; the shared-sweep
