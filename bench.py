@@ -550,8 +550,14 @@ def main():
             pilot = rows_of(0, P)
     ix = B.Index(codes, corr, dim, cdp, device=device, index_bits=IB, row_base=r0,
                  pilot_codes=None if pilot is None else pilot[0], pilot_corr=None if pilot is None else pilot[1])
-    # 0: the library's choice by the rows of the index / shard (bbq_core.cpp effective_batch): 32 from 6 M rows, 64 from 2.5 M, 128 below
-    sub_batch = min(args.sub_batch, Q) if args.sub_batch > 0 else min(Q, 32 if r1 - r0 >= 6_000_000 else 64 if r1 - r0 >= 2_500_000 else 128)
+    # 0: the library's choice by the rows of the index / shard and the queries of the call (bbq_core.cpp effective_batch): 32 from 6 M rows,
+    # 64 from 2.5 M, 128 below, halved while the call would have fewer than four sub-batches
+    if args.sub_batch > 0:
+        sub_batch = min(args.sub_batch, Q)
+    else:
+        sub_batch = 32 if r1 - r0 >= 6_000_000 else 64 if r1 - r0 >= 2_500_000 else 128
+        while sub_batch > 32 and Q < 4 * sub_batch:   # at least four sub-batches per call where possible
+            sub_batch //= 2
     ix.set_option("batch_queries", min(args.sub_batch, Q))
     ix.set_option("pipeline_slots", args.slots)
     ix.set_option("replay_threads", args.replay_threads)

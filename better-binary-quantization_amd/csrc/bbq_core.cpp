@@ -206,11 +206,15 @@ namespace {
 
 // queries per launch sequence (sub-batch).  The largest sweep of a sub-batch should run for about a millisecond: shorter ones pay the
 // device's dependent-launch gaps and their own ramp (1.25 M rows x 2048 queries: 52.5 K q/s with 32 per sub-batch, 56.5 K with 64,
-// 57 K with 96-128; at 10 M rows 32 is as good as 64 and needs half the workspace)
-int effective_batch(const bbq_index *ix) {
+// 57 K with 96-128; at 10 M rows 32 is as good as 64 and needs half the workspace).  A call should also be cut into at least four
+// sub-batches where it can: the first sub-batch's small segments run alone on the device and only the later ones hide theirs behind
+// another sub-batch's large sweep (1 M rows x 256 queries per call: 0.849 of the roofline end to end with 2 x 128, 0.855 with 4 x 64)
+int effective_batch(const bbq_index *ix, int64_t n_queries = 0) {
   if (ix->opt_batch > 0) return ix->opt_batch;
   const int64_t rows = ix->main.view.n_rows;
-  return rows >= 6000000 ? 32 : rows >= 2500000 ? 64 : 128;
+  int q = rows >= 6000000 ? 32 : rows >= 2500000 ? 64 : 128;
+  while (n_queries > 0 && q > 32 && n_queries < 4 * (int64_t)q) q >>= 1;
+  return q;
 }
 
 // ------------------------------------------------------------------------------------------------ plan
@@ -1139,7 +1143,7 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
   const int64_t final_k = (keff <= kFinalSelectMax && ix->opt_device_select) ? keff : 0;
   cs.k = final_k > 0 ? keff + 1 : keff;
   build_plan(ix, cs.k, final_k, final_k > 0 && n_queries <= ix->opt_latency_queries);
-  const int Q = effective_batch(ix);
+  const int Q = effective_batch(ix, n_queries);
   const int nslots = std::min(std::max(1, ix->opt_slots), kMaxSlots);
   const int64_t nsub = ((int64_t)n_queries + Q - 1) / Q;
   auto fail_out = [&](int code) {
@@ -1294,7 +1298,7 @@ int bbq_shard_scan_begin(bbq_index *ix, int32_t n_queries, const uint8_t *qquant
     set.q_cap = n_queries;
     set.list_cap = list_cap;
   }
-  const int Q = effective_batch(ix);
+  const int Q = effective_batch(ix, n_queries);
   const int nslots = std::min(std::max(1, ix->opt_slots), kMaxSlots);
   const int64_t nsub = ((int64_t)n_queries + Q - 1) / Q;
   auto bail = [&](int code) {

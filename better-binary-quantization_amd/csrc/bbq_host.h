@@ -11,6 +11,7 @@
 #include <atomic>
 #include <algorithm>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 #include "bbq_internal.h"
@@ -217,5 +218,12 @@ int multi_score_rows(bbq_index *ix, const uint8_t *qquant, const double *qcorr, 
 int multi_export(bbq_index *ix, uint8_t *codes, double *corr);
 int multi_set_option(bbq_index *ix, const char *name, int64_t v);
 int multi_get_stats(bbq_index *ix, bbq_stats *out);
+// persistence of a multi-device index: every shard as an ordinary file pair + a manifest (bbq_persist.cpp / bbq_multi.cpp)
+int multi_save(bbq_index *ix, const char *prefix, const float *centroid, int32_t sim);
+int multi_assemble(bbq_index *const *shards, const int32_t *devices, int32_t n_shards, int32_t dim, int32_t index_bits, int64_t n_rows,
+                   double centroid_dp, bbq_index **out);
+int write_manifest(const char *prefix, int32_t n_shards, const int64_t *bounds, int32_t dim, int32_t index_bits, int32_t sim, int64_t n_rows,
+                   double centroid_dp, int64_t pilot_rows, const float *centroid);
+std::string shard_file_prefix(const char *prefix, int s);
 int multi_reset_stats(bbq_index *ix);
 }  // namespace bbq

@@ -432,6 +432,67 @@ int multi_set_option(bbq_index *ix, const char *name, int64_t v) {
   return BBQ_OK;
 }
 
+// the handle's own fields from its shards (every shard decides has_x1 - and with it a fallback to the inline layout - on its own
+// rows: the handle reports the widest)
+static void adopt_shard_geometry(bbq_index *ix, MultiState *ms) {
+  ix->bytes_per_row = 0;
+  ix->has_x1 = 0;
+  for (const MultiShard &sh : ms->shards) {
+    if (sh.ix->bytes_per_row >= ix->bytes_per_row) {
+      ix->bytes_per_row = sh.ix->bytes_per_row;
+      ix->layout = sh.ix->layout;
+      ix->tile_stride = sh.ix->tile_stride;
+    }
+    ix->has_x1 = ix->has_x1 || sh.ix->has_x1;
+  }
+}
+
+// a multi-device handle over shard indexes that already exist (loaded from files); takes ownership of them on success
+int multi_assemble(bbq_index *const *shards, const int32_t *devices, int32_t n_shards, int32_t dim, int32_t index_bits, int64_t n_rows,
+                   double centroid_dp, bbq_index **out) {
+  if (n_shards < 1 || n_shards > 64 || !shards || !out) return fail(BBQ_ERR_INVALID_ARG, "multi_assemble: bad arguments");
+  std::unique_ptr<bbq_index> ix(new bbq_index());
+  ix->dim = dim;
+  ix->index_bits = index_bits;
+  ix->store_bits = dim == 1 ? 1 : store_bits_of(index_bits);
+  ix->pb = row_bytes_of(dim, ix->store_bits);
+  ix->w16 = (ix->pb + 15) / 16;
+  ix->n_rows = n_rows;
+  ix->centroid_dp = centroid_dp;
+  ix->device = devices[0];
+  std::unique_ptr<MultiState> ms(new MultiState());
+  for (int s = 0; s < n_shards; ++s) {
+    MultiShard sh;
+    sh.ix = shards[s];
+    sh.device = devices[s];
+    sh.r0 = shards[s]->row_base;
+    sh.r1 = sh.r0 + shards[s]->n_rows;
+    sh.worker.reset(new ShardWorker());
+    ms->shards.push_back(std::move(sh));
+  }
+  adopt_shard_geometry(ix.get(), ms.get());
+  ix->multi = ms.release();
+  *out = ix.release();
+  return BBQ_OK;
+}
+
+// every shard as an ordinary file pair <prefix>.s<NNN> (with its pilot replica) + the manifest <prefix>.vemb
+int multi_save(bbq_index *ix, const char *prefix, const float *centroid, int32_t sim) {
+  MultiState *ms = ix->multi;
+  std::lock_guard<std::mutex> lk(ms->mu);
+  std::vector<int64_t> bounds;
+  int64_t pilot = 0;
+  for (size_t s = 0; s < ms->shards.size(); ++s) {
+    MultiShard &sh = ms->shards[s];
+    int rc = bbq_index_save(sh.ix, shard_file_prefix(prefix, (int)s).c_str(), centroid, sim);
+    if (rc != BBQ_OK) return rc;
+    bounds.push_back(sh.r0);
+    bounds.push_back(sh.r1 - sh.r0);
+    if (sh.ix->has_pilot) pilot = std::max<int64_t>(pilot, sh.ix->pilot.view.n_rows);
+  }
+  return write_manifest(prefix, (int32_t)ms->shards.size(), bounds.data(), ix->dim, ix->index_bits, sim, ix->n_rows, ix->centroid_dp, pilot, centroid);
+}
+
 int multi_get_stats(bbq_index *ix, bbq_stats *out) {
   MultiState *ms = ix->multi;
   std::lock_guard<std::mutex> lk(ms->mu);
@@ -523,15 +584,7 @@ int bbq_index_create_multi_opts(const uint8_t *codes, const double *corr, int64_
     sh.worker.reset(new ShardWorker());
     ms->shards.push_back(std::move(sh));
   }
-  // every shard decides has_x1 (and with it a fallback to the inline layout) on its own rows: the handle reports the widest
-  for (const MultiShard &sh : ms->shards) {
-    if (sh.ix->bytes_per_row >= ix->bytes_per_row) {
-      ix->bytes_per_row = sh.ix->bytes_per_row;
-      ix->layout = sh.ix->layout;
-      ix->tile_stride = sh.ix->tile_stride;
-    }
-    ix->has_x1 = ix->has_x1 || sh.ix->has_x1;
-  }
+  adopt_shard_geometry(ix.get(), ms.get());
   ix->multi = ms.release();
   *out = ix.release();
   return BBQ_OK;

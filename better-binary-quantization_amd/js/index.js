@@ -508,18 +508,13 @@ class BinaryQuantizationFormat {
    */
   saveIndex(quantizedVectors, pathPrefix) {
     if (!quantizedVectors) throw new Error('目标向量集合不能为空');
-    const qv = quantizedVectors;
-    if (qv._codes && shardDevices(qv._size).length > 1) {
-      // the file pair holds ONE device layout: a sharded index is written from a single-device copy of its rows
-      const tmp = native.indexCreate(qv._codes, qv._corr, qv._size, qv.dimension(), qv._indexBits, qv.getCentroidDP(), Number(process.env.BBQ_DEVICE || 0));
-      try { native.indexSave(tmp, String(pathPrefix), qv.getCentroid(), simOrdinal(this.quantizer.similarityFunction)); } finally { native.indexDestroy(tmp); }
-      return;
-    }
+    // a multi-device index is written as one pair per shard (<prefix>.s000, ...) plus a manifest: loadIndex puts it back over BBQ_DEVICES
     native.indexSave(quantizedVectors._deviceIndex(), String(pathPrefix), quantizedVectors.getCentroid(), simOrdinal(this.quantizer.similarityFunction));
   }
   /** loads <prefix>.veb/.vemb straight into HBM; vectorValue()/getCorrectiveTerms() fetch the rows back lazily */
   loadIndex(pathPrefix) {
-    const r = native.indexLoad(String(pathPrefix), Number(process.env.BBQ_DEVICE || 0));
+    const devices = shardDevices(Infinity);
+    const r = native.indexLoad(String(pathPrefix), Number(process.env.BBQ_DEVICE || 0), devices.length > 1 ? Int32Array.from(devices) : undefined);
     if (r.sim !== simOrdinal(this.quantizer.similarityFunction)) {
       native.indexDestroy(r.handle);
       throw new Error('不支持的相似性函数: file was written for ordinal ' + r.sim);

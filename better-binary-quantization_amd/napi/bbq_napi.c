@@ -464,12 +464,19 @@ static napi_value IndexSave(napi_env env, napi_callback_info info) {
   napi_value u; napi_get_undefined(env, &u); return u;
 }
 
-/* indexLoad(prefix, device) -> {handle, centroid Float32Array, n, dim, sim, centroidDP, rowBase} */
+/* indexLoad(prefix, device[, devices Int32Array]) -> {handle, centroid Float32Array, n, dim, sim, centroidDP, rowBase, shards}
+ * devices given and the files hold a multi-device index (a manifest): its shards go over those devices (bbq_index_load_multi) */
 static napi_value IndexLoad(napi_env env, napi_callback_info info) {
-  napi_value a[2];
-  if (!get_args(env, info, 2, a)) return NULL;
+  napi_value a[3];
+  size_t argc = 3;
+  if (napi_get_cb_info(env, info, &argc, a, NULL, NULL) != napi_ok || argc < 2) { napi_throw_type_error(env, NULL, "bbq_napi: wrong number of arguments"); return NULL; }
   char path[4096]; int64_t dev;
   if (!get_path(env, a[0], path, sizeof path) || !get_i64(env, a[1], &dev)) return NULL;
+  void *devs = NULL; size_t ndevs = 0;
+  if (argc >= 3) {
+    napi_valuetype vt;
+    if (napi_typeof(env, a[2], &vt) == napi_ok && vt != napi_undefined && vt != napi_null && !get_typed(env, a[2], napi_int32_array, &devs, &ndevs)) return NULL;
+  }
   int64_t n = 0, rb = 0; int32_t dim = 0, sim = 0; double cdp = 0;
   int rc = bbq_index_file_info(path, &n, &dim, &sim, &cdp, &rb);
   if (rc != BBQ_OK) return throw_bbq(env, rc);
@@ -477,7 +484,9 @@ static napi_value IndexLoad(napi_env env, napi_callback_info info) {
   napi_value tcen = new_typed(env, napi_float32_array, (size_t)dim, 4, &cen);
   if (!tcen) { napi_throw_error(env, NULL, "bbq_napi: allocation failed"); return NULL; }
   bbq_index **box = (bbq_index **)calloc(1, sizeof *box);
-  rc = bbq_index_load(path, (int32_t)dev, box, (float *)cen);
+  const int32_t file_shards = bbq_index_file_shards(path);
+  if (devs && ndevs > 0 && file_shards > 1) rc = bbq_index_load_multi(path, (int32_t)ndevs, (const int32_t *)devs, box, (float *)cen);
+  else rc = bbq_index_load(path, (int32_t)dev, box, (float *)cen);
   if (rc != BBQ_OK) { free(box); return throw_bbq(env, rc); }
   napi_value ext, o, v;
   if (napi_create_external(env, box, finalize_index, NULL, &ext) != napi_ok) { bbq_index_destroy(*box); free(box); napi_throw_error(env, NULL, "bbq_napi: external"); return NULL; }
@@ -488,6 +497,7 @@ static napi_value IndexLoad(napi_env env, napi_callback_info info) {
   napi_create_double(env, (double)sim, &v); set_prop(env, o, "sim", v);
   napi_create_double(env, cdp, &v); set_prop(env, o, "centroidDP", v);
   napi_create_double(env, (double)rb, &v); set_prop(env, o, "rowBase", v);
+  napi_create_double(env, (double)file_shards, &v); set_prop(env, o, "shards", v);
   return o;
 }
 

@@ -24,7 +24,7 @@ SYMBOLS = [
     "bbq_vectors_dimension", "bbq_rerank_scores", "bbq_search_rerank_batch", "bbq_index_save", "bbq_index_file_info",
     "bbq_index_load", "bbq_index_export", "bbq_quantize_queries",
     "bbq_index_create_shard_opts", "bbq_index_create_multi_opts", "bbq_index_build_opts",
-    "bbq_shard_scan_begin", "bbq_shard_scan_wait", "bbq_merge_answers", "bbq_key_of_score",
+    "bbq_shard_scan_begin", "bbq_shard_scan_wait", "bbq_merge_answers", "bbq_key_of_score", "bbq_index_load_multi", "bbq_index_file_shards",
 ]
 
 
@@ -127,6 +127,9 @@ def lib():
     L.bbq_index_save.argtypes = [vp, C.c_char_p, vp, i32]
     L.bbq_index_file_info.argtypes = [C.c_char_p, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32), C.POINTER(dbl), C.POINTER(i64)]
     L.bbq_index_load.argtypes = [C.c_char_p, i32, C.POINTER(vp), vp]
+    L.bbq_index_load_multi.argtypes = [C.c_char_p, i32, vp, C.POINTER(vp), vp]
+    L.bbq_index_file_shards.argtypes = [C.c_char_p]
+    L.bbq_index_file_shards.restype = i32
     L.bbq_index_export.argtypes = [vp, vp, vp]
     _lib = L
     return L
@@ -270,6 +273,19 @@ class Index:
         self.index_bits = lib().bbq_index_bits(h)
         return self, cen, info
 
+    @classmethod
+    def load_multi(cls, path_prefix, devices=None):
+        """a saved multi-device index back over `devices` (None: shard s on device s modulo the visible ones): (index, centroid, info)"""
+        info = file_info(path_prefix)
+        cen = np.zeros(info["dim"], np.float32)
+        dev = None if devices is None else np.ascontiguousarray(devices, np.int32)
+        h = C.c_void_p()
+        _chk(lib().bbq_index_load_multi(os.fsencode(path_prefix), 0 if dev is None else len(dev), _ptr(dev), C.byref(h), _ptr(cen)))
+        self = cls.__new__(cls)
+        self._h, self.dim, self.n = h, info["dim"], info["n_rows"]
+        self.index_bits = lib().bbq_index_bits(h)
+        return self, cen, info
+
     def export(self):
         """(codes [n, ceil(dim/8)], corr [n, 4]) as vectorValue / getCorrectiveTerms would return them"""
         codes = np.zeros((self.n, (self.dim + 7) // 8 if self.index_bits == 1 else self.dim), np.uint8)
@@ -375,6 +391,10 @@ def merge_answers(blocks, n_queries, n_total, k, n_threads=1):
 
 def key_of_score(score):
     return int(lib().bbq_key_of_score(float(score)))
+
+
+def file_shards(path_prefix):
+    return int(lib().bbq_index_file_shards(os.fsencode(path_prefix)))
 
 
 def file_info(path_prefix):

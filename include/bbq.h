@@ -151,7 +151,7 @@ int bbq_index_create_shard_opts(const uint8_t *codes, const double *corr, int64_
  *   n_shards     1..64
  *   devices      [n_shards] HIP device ordinal of every shard (NULL: shard s on device s); a device may appear more than once
  *                (several shards on one GPU: how a single-GPU box tests the path)
- * bbq_index_save and bbq_shard_scan refuse such a handle.  Extra option: round_queries 1..65536 (512), queries per round. */
+ * bbq_shard_scan refuses such a handle.  Extra option: round_queries 1..65536 (512), queries per round. */
 int bbq_index_create_multi(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim, int32_t index_bits,
                            double centroid_dp, int32_t n_shards, const int32_t *devices, int64_t pilot_rows, bbq_index **out);
 int bbq_index_create_multi_opts(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t dim, int32_t index_bits,
@@ -277,14 +277,23 @@ int bbq_replay_batch(int32_t n_sources, const bbq_cand *const *packed, const int
  *   <prefix>.veb   the 64-row tile records (packed 1-bit codes + corrections per row = VectorDataFormat's
  *                  binaryValues, lowerInterval, upperInterval, additionalCorrection, quantizedComponentSum),
  *                  then the exact-corrections side array of the compact layout
- * Little-endian.  A shard with a pilot replica cannot be saved (save the whole index, or the shard's own rows).
+ * Little-endian.  A row shard is saved WITH its pilot replica (format version 3: three more header words, the replica's tile records
+ * behind the shard's own), so a one-process-per-GPU service restarts from files without the host rows.  A multi-device index is saved
+ * as one ordinary pair per shard, <prefix>.s000, <prefix>.s001, ..., plus the manifest <prefix>.vemb ("BVEM": shard count, the shards'
+ * row ranges, totals, centroid, checksum); bbq_index_load_multi puts it back over several devices, bbq_index_load over one.
  */
 int bbq_index_save(bbq_index *idx, const char *path_prefix, const float *centroid, int32_t similarity_ordinal);
 /* header of <prefix>.vemb; any output pointer may be NULL */
 int bbq_index_file_info(const char *path_prefix, int64_t *n_rows, int32_t *dim, int32_t *similarity_ordinal,
                         double *centroid_dp, int64_t *row_base);
-/* centroid_out [dim] (may be NULL).  Fails with BBQ_ERR_INVALID_ARG on a malformed, truncated or corrupted file. */
+/* centroid_out [dim] (may be NULL).  Fails with BBQ_ERR_INVALID_ARG on a malformed, truncated or corrupted file.  A manifest of a
+ * multi-device index loads as a multi-device handle with every shard on `device`. */
 int bbq_index_load(const char *path_prefix, int32_t device, bbq_index **out, float *centroid_out);
+/* a saved multi-device index over several devices: shard s on devices[s % n_devices] (n_devices 0 / devices NULL: shard s on device
+ * s modulo the visible devices).  The shards, their row ranges and pilot replicas are the ones that were saved. */
+int bbq_index_load_multi(const char *path_prefix, int32_t n_devices, const int32_t *devices, bbq_index **out, float *centroid_out);
+/* shards of a saved index: 1 for an ordinary pair, the manifest's count for a multi-device index, 0 if unreadable */
+int32_t bbq_index_file_shards(const char *path_prefix);
 /* the rows back in the reference's shape: codes [n*ceil(dim/8)] (multi-bit index: [n*dim]), corr [n*4] (either may be NULL) - what
  * vectorValue(ord) / getCorrectiveTerms(ord) return (src/binaryQuantizationFormat.ts:52-76) */
 int bbq_index_export(bbq_index *idx, uint8_t *codes, double *corr);

@@ -589,8 +589,11 @@ def test_config2_shape_1m_x_768_properties():
         ix.set_option("pipeline_slots", 3)
         idx, sc, cnt = ix.search_batch(qq, qc, 4, 1, k)
         st = ix.stats()
-        assert (cnt == k).all() and st["dense_fallbacks"] == 0 and st["host_replays"] == 0
-        # 128 queries per dominant launch (the library's choice for this size): rows x queries of the last full sub-batch or the tail
+        # the device answers every query itself except those with equal scores in or at the edge of the answer (f32 scores in a narrow
+        # range: a pair among the 101 best coincides now and then) - exactly those are replayed on the host
+        _, s101, _ = ix.search_batch(qq, qc, 4, 1, k + 1)
+        tied = sum(len(np.unique(s101[q].astype(np.float64))) != k + 1 for q in range(len(qq)))
+        assert (cnt == k).all() and st["dense_fallbacks"] == 0 and st["host_replays"] == tied and tied < 30
         assert st["last_scan_rows"] > 0
         # (1) the oracle: first / last query of a sub-batch and one of the partial tail
         for q in (0, 127, 128, 299):
@@ -651,7 +654,7 @@ def test_config2_shape_1m_x_768_properties():
         mi, ms, _ = mx.search_batch(qq, qc, 4, 1, k)
         np.testing.assert_array_equal(mi, idx)
         np.testing.assert_array_equal(ms.view(np.uint32), sc.view(np.uint32))
-        assert mx.stats()["host_replays"] == 0 and mx.stats()["dense_fallbacks"] == 0
+        assert mx.stats()["host_replays"] == tied and mx.stats()["dense_fallbacks"] == 0
     finally:
         mx.close()
 

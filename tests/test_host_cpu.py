@@ -161,6 +161,53 @@ def test_vemb_header_spec(tmp_path):
         B.file_info(str(tmp_path / "absent"))
 
 
+def test_vemb_shard_and_manifest_spec(tmp_path):
+    """format version 3 (a row shard with its pilot replica: three more words behind the 104-byte header) and the manifest of a
+    multi-device index ("BVEM"), as DESIGN.md documents them, parsed without a device"""
+    import struct
+    from bbqlib import bbq_amd as B
+
+    def fnv(data, h):
+        data = data + b"\0" * (-len(data) % 8)
+        for (w,) in struct.iter_unpack("<Q", data):
+            h = ((h ^ w) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+        return h
+
+    seed = 0xcbf29ce484222325
+    dim, n, row_base, pilot = 100, 1000, 4096, 1024
+    w16 = ((dim + 7) // 8 + 15) // 16
+    stride = w16 * 1024 + 256
+    nt, npt = (n + 63) // 64, (pilot + 63) // 64
+    tiles, exact = nt * stride, nt * 64 * 32 + nt * 8
+    ptiles, pexact = npt * stride, npt * 64 * 32 + npt * 8
+    hdr = struct.pack("<4sI4i3qd6i3q", b"BVEC", 3, 0, 0, 1, dim, 0, tiles + exact + ptiles + pexact, n, 0.125, 1, 1, w16, stride, 0, 64, tiles, exact, row_base)
+    ext = struct.pack("<3q", pilot, ptiles, pexact)
+    cen = np.arange(dim, dtype=np.float32).tobytes()
+    dsum = struct.pack("<Q", 0x77)
+    p = str(tmp_path / "shard")
+    open(p + ".vemb", "wb").write(hdr + ext + cen + dsum + struct.pack("<Q", fnv(dsum, fnv(cen, fnv(ext, fnv(hdr, seed))))))
+    assert B.file_info(p) == {"n_rows": n, "dim": dim, "sim": 1, "centroid_dp": 0.125, "row_base": row_base}
+    assert B.file_shards(p) == 1
+    bad_ext = struct.pack("<3q", row_base + 64, ptiles, pexact)   # more pilot rows than precede the shard
+    open(p + ".vemb", "wb").write(hdr + bad_ext + cen + dsum + struct.pack("<Q", fnv(dsum, fnv(cen, fnv(bad_ext, fnv(hdr, seed))))))
+    with pytest.raises(B.BBQError):
+        B.file_info(p)
+    # manifest: header (48 B), {rowBase, rows} per shard, centroid, checksum
+    bounds = struct.pack("<4q", 0, 512, 512, 488)
+    mh = struct.pack("<4sI4iqdq", b"BVEM", 1, 2, dim, 1, 1, n, 0.125, pilot)
+    assert len(mh) == 48
+    m = str(tmp_path / "multi")
+    open(m + ".vemb", "wb").write(mh + bounds + cen + struct.pack("<Q", fnv(cen, fnv(bounds, fnv(mh, seed)))))
+    assert B.file_info(m) == {"n_rows": n, "dim": dim, "sim": 1, "centroid_dp": 0.125, "row_base": 0}
+    assert B.file_shards(m) == 2
+    gap = struct.pack("<4q", 0, 512, 600, 400)                    # shards must be contiguous
+    open(m + ".vemb", "wb").write(mh + gap + cen + struct.pack("<Q", fnv(cen, fnv(gap, fnv(mh, seed)))))
+    with pytest.raises(B.BBQError):
+        B.file_info(m)
+    assert B.file_shards(m) == 0
+    assert B.file_shards(str(tmp_path / "absent")) == 0
+
+
 @pytest.mark.parametrize("sim,qb", [(0, 4), (1, 4), (2, 1), (1, 8)])
 def test_quantize_queries_batch_equals_one_by_one(sim, qb):
     """bbq_quantize_queries (host threads) = bbq_quantize_query per query, bit for bit; the first bad query is reported"""
