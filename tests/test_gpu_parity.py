@@ -946,11 +946,23 @@ def test_load_rejects_damaged_files(tmp_path):
         ix.save(str(tmp_path / "nodir" / "x"), cen, 1)
     with pytest.raises(B.BBQError):
         ix.save(prefix, cen[:10], 1)
-    # a shard with a pilot replica is refused
+    # a shard with a pilot replica is saved with it (format version 3) and its damaged variants are refused as well
     sh = B.Index(codes[512:], corr[512:], 64, B.centroid_dp(cen), row_base=512, pilot_codes=codes[:512], pilot_corr=corr[:512])
-    with pytest.raises(B.BBQError):
-        sh.save(prefix + "_shard", cen, 1)
+    sh.save(prefix + "_shard", cen, 1)
     sh.close()
+    sveb, svemb = open(prefix + "_shard.veb", "rb").read(), open(prefix + "_shard.vemb", "rb").read()
+    assert svemb[4:8] == (3).to_bytes(4, "little") and vemb[4:8] == (2).to_bytes(4, "little")
+    assert len(svemb) == len(vemb) + 24
+    pflip = bytearray(sveb)
+    pflip[-9] ^= 0x40        # a byte of the pilot replica's side section
+    ext = bytearray(svemb)
+    ext[104] ^= 0x01         # pilotRows
+    for p in (variant("pflip", bytes(pflip), svemb), variant("pshort", sveb[:-64], svemb), variant("pext", sveb, bytes(ext))):
+        with pytest.raises(B.BBQError):
+            B.Index.load(p)
+    back, _, info = B.Index.load(prefix + "_shard")
+    assert info["row_base"] == 512 and back.n == 700 - 512
+    back.close()
     ix.close()
 
 
