@@ -101,6 +101,10 @@ int get_ctx(int device, DeviceCtx **out) {
     HIPCHK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void **)&c->d_aux_flags, 4));
     HIPCHK(hipMemset(c->d_aux_flags, 0, 4));
+    HIPCHK(hipHostMalloc((void **)&c->h_lat, (size_t)(kLatAnswerOffset + kFinalSelectMax + 8) * 8, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->h_lat, 0, (size_t)(kLatAnswerOffset + kFinalSelectMax + 8) * 8);
+    HIPCHK(hipHostGetDevicePointer((void **)&c->d_lat, c->h_lat, 0));
+    HIPCHK(hipMalloc((void **)&c->d_pre_keys, (size_t)kLatPreKeys * 4));
     c->ready = true;
     g_ctx[device] = c;
   }
@@ -362,6 +366,7 @@ int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
   // brings a sub-batch's queries also resets them (the host twin's control part stays zero)
   s.ctrl_bytes = ((int64_t)Q * 28 + 255) / 256 * 256;
   HIPCHK(hipMalloc((void **)&s.d_block, (size_t)(s.ctrl_bytes + Q * s.qbuf_bytes)));
+  s.ctrl_clean = false;
   HIPCHK(hipHostMalloc((void **)&s.h_block, (size_t)(s.ctrl_bytes + Q * s.qbuf_bytes), hipHostMallocDefault));
   memset(s.h_block, 0, (size_t)s.ctrl_bytes);
   s.d_qbuf = s.d_block + s.ctrl_bytes;
@@ -581,6 +586,7 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const 
   }
   hipStream_t st = s.stream;
   HIPCHK(hipMemcpyAsync(s.d_block, s.h_block, (size_t)s.ctrl_bytes + bytes, hipMemcpyHostToDevice, st));  // control words := 0, queries
+  s.ctrl_clean = false;
   uint64_t *d_lists = d_lists_ext ? d_lists_ext : s.d_lists;
   const int64_t list_cap = d_lists_ext ? list_cap_ext : s.list_cap;
   int32_t *d_list_counts = d_counts_ext ? d_counts_ext : s.d_list_counts;
@@ -942,6 +948,210 @@ int drain(bbq_index *ix) {
   return BBQ_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ single-query latency path
+
+// waits for the sequence word the last finalize launch of a latency chain raises in mapped host memory (polling: no event, no copy)
+int wait_latency_answer(DeviceCtx *ctx, Slot &s, uint64_t seq) {
+  volatile uint64_t *flag = ctx->h_lat;
+  for (int64_t spin = 0; spin < (1ll << 31); ++spin) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return BBQ_OK;
+    if ((spin & 0xffff) == 0xffff && hipEventQuery(s.ev_done) != hipErrorNotReady) break;  // the launch chain is over (or failed)
+    __builtin_ia32_pause();
+  }
+  const hipError_t e = hipEventSynchronize(s.ev_done);
+  if (e == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return BBQ_OK;
+  s.ctrl_clean = false;  // whatever the chain left behind
+  if (e != hipSuccess) return fail(BBQ_ERR_HIP, "latency path: %s", hipGetErrorString(e));
+  return fail(BBQ_ERR_HIP, "latency path: the device finished without an answer");
+}
+
+// The single-query call on a large index: threshold from a pre-sampled prefix (bbq_lat_pre_kernel + bbq_lat_select_kernel: two small
+// launches), ONE sweep over all rows with it, final selection on the list alone - four launches where the segmented chain has six,
+// and nothing in front of the large sweep but the two small ones.  The list is every row above the threshold, not a heap history: a
+// query whose answer the device cannot prove (equal scores, NaN, more candidates than the selection holds) is handed to the
+// segmented chain (*done = false), which replays it exactly.
+int search_latency_presampled(const BatchCtx &c, const BatchCtx &cs, int32_t *out_idx, float *out_score, int64_t *out_n, bool *done) {
+  bbq_index *ix = c.ix;
+  const Plan &p = ix->plan;
+  *done = false;
+  const int64_t N = ix->main.view.n_rows, k2 = p.final_k;
+  if (!ix->opt_latency_presample || !ix->opt_latency_fused || !ix->opt_latency_append || ix->has_pilot || ix->opt_share != 1 || !p.latency ||
+      k2 < 1 || k2 > kFinalSelectMax || N < 262144 || !latency_path_supported(ix->main.view, cs.planes))
+    return BBQ_OK;
+  // sample enough rows for ~6000 candidates in the sweep (the selection holds kFinalizeKeyCap of them)
+  int64_t P = ((k2 + 2) * N / 6000 + kChunkRows - 1) / kChunkRows * kChunkRows;
+  P = std::max<int64_t>(P, 8192);
+  if (P > N / 4) return BBQ_OK;
+  int per_wave = 4;
+  if (P / kTileRows * per_wave > kLatPreKeys) per_wave = 1;
+  const int64_t n_keys = P / kTileRows * per_wave;
+  if (n_keys > kLatPreKeys || n_keys < k2 + 2) return BBQ_OK;
+  Slot &s = ix->slots[0];
+  int rc = ensure_slot(ix, s, 1, true);
+  if (rc != BBQ_OK) return rc;
+  DeviceCtx *ctx = ix->ctx;
+  hipStream_t st = s.stream;
+  if (!s.ctrl_clean) {
+    HIPCHK(hipMemsetAsync(s.d_block, 0, (size_t)s.ctrl_bytes, st));
+    s.ctrl_clean = true;
+  }
+  LatScanArgs a{};
+  a.idx = ix->main.view;
+  a.row_id_base = ix->main.row_id_base;
+  a.theta = s.d_theta;
+  a.flags = s.d_flags;
+  a.list_counts = s.d_list_counts;
+  a.append_count = s.d_append_counts;
+  a.list = s.d_lists;
+  a.list_cap = s.list_cap;
+  fill_query(ix, reinterpret_cast<uint8_t *>(a.planes), &a.p, c.qquant, c.qcorr, cs.planes, cs.one_bit, cs.sim);
+  LatPreArgs pre{};
+  pre.idx = ix->main.view;
+  pre.rows = (int32_t)P;
+  pre.per_wave = per_wave;
+  pre.pre_keys = ctx->d_pre_keys;
+  pre.flags = s.d_flags;
+  pre.p = a.p;
+  memcpy(pre.planes, a.planes, sizeof pre.planes);
+  HIPCHK(launch_lat_pre(pre, cs.planes, st));
+  // rank k2 + 2: the sweep must list at least k2 + 1 rows for the selection to see the boundary of the answer
+  HIPCHK(launch_lat_select(ctx->d_pre_keys, (int)n_keys, (int)(k2 + 2), s.d_theta, st));
+  a.chunk_begin = 0;
+  a.n_chunks = (int32_t)ix->main.n_chunks();
+  a.first = 0;
+  HIPCHK(launch_lat_scan(a, cs.planes, st));
+  const uint64_t seq = ++ctx->lat_seq;
+  FinalizeArgs f{};
+  f.append_counts = s.d_append_counts;
+  f.lists = s.d_lists;
+  f.list_counts = s.d_list_counts;
+  f.list_cap = s.list_cap;
+  f.emit = 1;
+  f.topk_keys = s.d_topk;
+  f.topk_counts = s.d_topk_counts;
+  f.theta = s.d_theta;
+  f.flags = s.d_flags;
+  f.k = (int32_t)cs.k;
+  f.final_out = ctx->d_lat + kLatAnswerOffset;
+  f.final_stride = kFinalSelectMax + 2;
+  f.final_k = (int32_t)k2;
+  f.done_flag = ctx->d_lat;
+  f.seq = seq;
+  HIPCHK(launch_finalize(f, 1, st));
+  HIPCHK(hipEventRecord(s.ev_done, st));
+  rc = wait_latency_answer(ctx, s, seq);
+  if (rc != BBQ_OK) return rc;
+  const uint64_t *hdr = ctx->h_lat + kLatAnswerOffset;
+  const uint32_t listed = (uint32_t)hdr[0], flags = (uint32_t)(hdr[0] >> 32), m = (uint32_t)hdr[1], replay = (uint32_t)(hdr[1] >> 32);
+  s.timed = false;
+  if (flags != 0 || replay != 0) return BBQ_OK;  // the segmented chain answers it
+  for (uint32_t j = 0; j < m; ++j) {
+    const uint64_t e = hdr[2 + j];
+    const uint32_t bits = (uint32_t)e;
+    out_idx[j] = (int32_t)(uint32_t)(e >> 32);
+    memcpy(&out_score[j], &bits, 4);
+  }
+  out_n[0] = m;
+  ix->stats.candidates += listed;
+  *done = true;
+  return BBQ_OK;
+}
+
+// one query, no copies: every sweep takes the query from its kernel arguments (bbq_latency_kernels.hip), the last finalize launch
+// writes the answer to mapped host memory and raises the sequence word this thread polls.  Returns BBQ_OK with *done = false when the
+// call has to take the general path (index shape without an instantiation).
+int search_latency_chain(const BatchCtx &c, const BatchCtx &cs, int32_t *out_idx, float *out_score, int64_t *out_n, bool *done) {
+  bbq_index *ix = c.ix;
+  const Plan &p = ix->plan;
+  *done = false;
+  if (!ix->opt_latency_fused || !ix->opt_latency_append || !ix->opt_append_last || ix->has_pilot || ix->opt_share != 1 || !p.latency ||
+      p.final_k < 1 || p.final_k > kFinalSelectMax || p.segs.empty() || !p.segs[0].dense || !latency_path_supported(ix->main.view, cs.planes))
+    return BBQ_OK;
+  for (size_t i = 1; i < p.segs.size(); ++i)
+    if (p.segs[i].dense || p.segs[i].storage != 1) return BBQ_OK;
+  Slot &s = ix->slots[0];
+  int rc = ensure_slot(ix, s, 1, true);
+  if (rc != BBQ_OK) return rc;
+  DeviceCtx *ctx = ix->ctx;
+  hipStream_t st = s.stream;
+  if (!s.ctrl_clean) {  // the slot's last user was not this chain
+    HIPCHK(hipMemsetAsync(s.d_block, 0, (size_t)s.ctrl_bytes, st));
+    s.ctrl_clean = true;
+  }
+  LatScanArgs a{};
+  a.idx = ix->main.view;
+  a.row_id_base = ix->main.row_id_base;
+  a.theta = s.d_theta;
+  a.flags = s.d_flags;
+  a.list_counts = s.d_list_counts;
+  a.append_count = s.d_append_counts;
+  a.list = s.d_lists;
+  a.list_cap = s.list_cap;
+  fill_query(ix, reinterpret_cast<uint8_t *>(a.planes), &a.p, c.qquant, c.qcorr, cs.planes, cs.one_bit, cs.sim);
+  const uint64_t seq = ++ctx->lat_seq;
+  for (size_t i = 0; i < p.segs.size(); ++i) {
+    const Segment &g = p.segs[i];
+    a.chunk_begin = g.chunk_begin;
+    a.n_chunks = (int32_t)g.n_chunks;
+    a.first = i == 0 ? 1 : 0;
+    HIPCHK(launch_lat_scan(a, cs.planes, st));
+    FinalizeArgs f{};
+    f.append_counts = s.d_append_counts;
+    f.lists = s.d_lists;
+    f.list_counts = s.d_list_counts;
+    f.list_cap = s.list_cap;
+    f.emit = 1;
+    f.topk_keys = s.d_topk;
+    f.topk_counts = s.d_topk_counts;
+    f.theta = s.d_theta;
+    f.flags = s.d_flags;
+    f.k = (int32_t)cs.k;
+    f.need_theta = i + 1 < p.segs.size() ? 1 : 0;
+    if (i + 1 == p.segs.size()) {
+      f.final_out = ctx->d_lat + kLatAnswerOffset;
+      f.final_stride = kFinalSelectMax + 2;
+      f.final_k = (int32_t)p.final_k;
+      f.done_flag = ctx->d_lat;
+      f.seq = seq;
+    }
+    HIPCHK(launch_finalize(f, 1, st));
+  }
+  HIPCHK(hipEventRecord(s.ev_done, st));
+  rc = wait_latency_answer(ctx, s, seq);
+  if (rc != BBQ_OK) return rc;
+  const uint64_t *hdr = ctx->h_lat + kLatAnswerOffset;
+  const uint32_t listed = (uint32_t)hdr[0], flags = (uint32_t)(hdr[0] >> 32), m = (uint32_t)hdr[1], replay = (uint32_t)(hdr[1] >> 32);
+  s.timed = false;
+  if (flags == 0 && replay == 0) {  // answered on the device
+    const int64_t k = c.k;
+    for (uint32_t j = 0; j < m; ++j) {
+      const uint64_t e = hdr[2 + j];
+      const uint32_t bits = (uint32_t)e;
+      out_idx[j] = (int32_t)(uint32_t)(e >> 32);
+      memcpy(&out_score[j], &bits, 4);
+    }
+    (void)k;
+    out_n[0] = m;
+    ix->stats.candidates += listed;
+    *done = true;
+    return BBQ_OK;
+  }
+  // equal scores in or at the edge of the answer (or a flagged query): hand over to the general path's collection - the list on the
+  // device is complete and it is this slot's
+  s.h_final[0] = (uint64_t)listed | ((uint64_t)flags << 32);
+  s.h_final[1] = (uint64_t)1 << 32;
+  s.busy = true;
+  s.nq = 1;
+  s.q_first = 0;
+  s.final_used = true;
+  s.appended = true;
+  rc = begin_replay(c, s, out_idx, out_score, out_n);
+  if (rc == BBQ_OK) rc = finish_replay(c, s, out_idx, out_score, out_n);
+  if (rc != BBQ_OK) return rc;
+  *done = true;
+  return BBQ_OK;
+}
+
 }  // namespace
 
 namespace bbq {
@@ -1143,6 +1353,13 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
   const int64_t final_k = (keff <= kFinalSelectMax && ix->opt_device_select) ? keff : 0;
   cs.k = final_k > 0 ? keff + 1 : keff;
   build_plan(ix, cs.k, final_k, final_k > 0 && n_queries <= ix->opt_latency_queries);
+  if (n_queries == 1 && ix->plan.latency) {
+    bool done = false;
+    rc = search_latency_presampled(c, cs, out_idx, out_score, out_n, &done);
+    if (rc != BBQ_OK || done) return rc;
+    rc = search_latency_chain(c, cs, out_idx, out_score, out_n, &done);
+    if (rc != BBQ_OK || done) return rc;
+  }
   const int Q = effective_batch(ix, n_queries);
   const int nslots = std::min(std::max(1, ix->opt_slots), kMaxSlots);
   const int64_t nsub = ((int64_t)n_queries + Q - 1) / Q;
@@ -1424,6 +1641,8 @@ int bbq_set_option(bbq_index *ix, const char *name, int64_t v) {
   else if (n == "latency_queries" && v >= 0 && v <= 1024) ix->opt_latency_queries = (int)v;
   else if (n == "append_last" && (v == 0 || v == 1)) ix->opt_append_last = (int)v;
   else if (n == "latency_append" && (v == 0 || v == 1)) ix->opt_latency_append = (int)v;
+  else if (n == "latency_fused" && (v == 0 || v == 1)) ix->opt_latency_fused = (int)v;
+  else if (n == "latency_presample" && (v == 0 || v == 1)) ix->opt_latency_presample = (int)v;
   else if (n == "latency_growth" && v >= 2 && v <= 4096) ix->opt_latency_growth = (int)v;
   else if (n == "sweep_share" && (v == 1 || v == 4 || v == 8 || v == 32)) ix->opt_share = (int)v;
   else if (n == "flood_rows" && v >= 0 && v <= (1 << 24)) ix->opt_flood = (v + 1023) / 1024 * 1024;

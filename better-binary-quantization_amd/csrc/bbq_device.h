@@ -148,6 +148,11 @@ struct FinalizeArgs {
   uint64_t *final_out;
   int32_t final_stride;        // >= final_k + 2 (+ 3 in shard mode)
   int32_t final_k;             // k2 = min(k, rows of the index)
+  // latency path: final_out is MAPPED HOST memory; after the answer the launch stores `seq` into *done_flag (system scope) - the host
+  // polls it instead of waiting for a copy and an event - and leaves the query's control words clean for the next call (the chain has
+  // no host-to-device copy that would reset them)
+  uint64_t *done_flag;
+  uint64_t seq;
   // Shard mode (bbq_shard_scan_begin's dev_answers, include/bbq.h): this storage is one row shard of a larger index and the running top
   // keys may include rows of a pilot replica, so the launch cannot prove an answer by itself.  It leaves what the merge needs instead:
   // slot 1 = {m, unproven}, slot 2 = the cut = the (k2 + 1)-th largest key over every row this shard has seen (0: it has seen at most
@@ -155,6 +160,43 @@ struct FinalizeArgs {
   int32_t final_shard;
 };
 constexpr int kFinalSelectMax = 1024;  // largest k2 the finalize kernel selects and sorts itself
+
+// Latency path (bbq_latency_kernels.hip + the finalize kernel): ONE query per call - the reference's own call shape - with no copy at
+// either end: every sweep takes the query from its KERNEL ARGUMENTS, the last finalize launch writes the answer into mapped host
+// memory and raises a sequence word the host is polling.
+constexpr int kLatPlaneMax = 96;     // 16-byte blocks of staged query data that fit the kernel arguments (768-d / 1536-d x 4 planes: 24 / 48)
+struct LatScanArgs {
+  IndexView idx;
+  int64_t row_id_base;
+  int64_t chunk_begin;
+  int32_t n_chunks;
+  int32_t first;                     // 1: the dense prefix - threshold 0 (every row is listed), nothing listed before it
+  const uint32_t *theta;             // the query's control words (device memory), as ScanArgs has them per query
+  uint32_t *flags;
+  const int32_t *list_counts;        // {count, flags}: entries the list holds from the earlier segments
+  uint32_t *append_count;
+  uint64_t *list;
+  int64_t list_cap;
+  // the query itself, in the arguments of every launch of the chain
+  QueryParams p;
+  uint4 planes[kLatPlaneMax];
+};
+
+// Pre-sampled threshold (the first step of the single-query call on large indexes): the first `rows` rows are scored exactly, every
+// wave leaves the `per_wave` largest keys of its 64 rows, and one small launch selects the rank-th largest of all of them - the
+// k-th largest of a SUBSET of the rows is a valid lower bound of the k-th largest of the index, and with per_wave = 4 it is the
+// prefix's true order statistic unless one wave holds five of its best rows.  ONE sweep over all rows with that threshold then lists
+// every row above it (a few thousand) and the final selection works on that list alone.
+constexpr int kLatPreKeys = 12288;  // keys the selection launch takes (48 KB of LDS; = kFinalizeKeyCap, what the final selection holds)
+struct LatPreArgs {
+  IndexView idx;
+  int32_t rows;                      // rows [0, rows) are sampled (a multiple of kChunkRows, <= idx.n_rows)
+  int32_t per_wave;                  // 1..4 keys per wave
+  uint32_t *pre_keys;                // [rows / 64 * per_wave]
+  uint32_t *flags;                   // NaN scores raise kFlagNaN
+  QueryParams p;
+  uint4 planes[kLatPlaneMax];
+};
 
 // exact rerank (bbq_rerank_kernels.hip): candidates of query q are rows[offsets[q] .. offsets[q+1])
 struct RerankArgs {

@@ -104,6 +104,9 @@ struct Slot {
   // non-null: the in-flight sub-batch belongs to an asynchronous sharded scan of that index (bbq_shard_scan_begin); nothing is to be
   // collected from it but the timing.  Such slots stay busy ACROSS API calls: every entry point that uses the slots settles them first.
   bbq_index *shard_owner = nullptr;
+  // the control words are all zero (the latency chain leaves them so and expects them so; every other use of the slot dirties them
+  // and resets them with its own host-to-device copy)
+  bool ctrl_clean = false;
 };
 
 // Per-device context shared by every index on that device: streams, events and the per-slot workspace are expensive
@@ -119,7 +122,14 @@ struct DeviceCtx {
   int64_t aux_qbuf_bytes = 0;
   uint32_t *d_aux_flags = nullptr;
   int last_big_slot = -1;             // slot whose ev_big marks the end of the most recently enqueued big sweep
+  // latency path (bbq_latency_kernels.hip): the answer of a single-query call lands in mapped, coherent host memory and the host
+  // polls a sequence word behind it: [0] sequence, [8 ..) header + entries
+  uint64_t *h_lat = nullptr, *d_lat = nullptr;
+  uint64_t lat_seq = 0;
+  uint32_t *d_pre_keys = nullptr;     // [kLatPreKeys] per-wave top keys of the pre-sampled threshold
+
 };
+constexpr int kLatAnswerOffset = 8;   // words in front of the answer block inside DeviceCtx::h_lat
 
 // per query: bit-planes (up to 8) + int8 values in MFMA fragment order + score uniforms + group maxima
 int64_t qbuf_bytes_per_query_w(int w16);
@@ -171,6 +181,8 @@ struct bbq_index {
   // walk the index in fewer, faster-growing segments (more candidates per query - the device selects the answer itself anyway)
   int opt_latency_queries = 4, opt_latency_growth = 64;
   int opt_latency_append = 1;  // 0: calls with few queries keep the chunk slots (and the finalize launches their compaction)
+  int opt_latency_presample = 1;  // ... and on large indexes get their threshold from per-wave top keys of a prefix (two small launches) instead of two scan / finalize pairs
+  int opt_latency_fused = 1;  // single-query calls take the three-launch latency path (bbq_latency_kernels.hip) when the index shape has one
   int opt_append_last = 1;  // append mode also for the last (largest) segment: its finalize launch gets cheaper, its sweep slower (one
                             // atomic per workgroup with candidates); measured at 10 M x 768: 0.250 ms per call with, 0.263 without
   // host threads replaying the heaps of one sub-batch: half the cores, at most 8 (a batch of 32 answers 1.4x sooner than with 1)

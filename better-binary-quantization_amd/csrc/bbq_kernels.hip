@@ -20,76 +20,12 @@
 // HBM-bound integer/byte work: no MFMA.  Compiled with -ffp-contract=off; the pragma below repeats it.
 #include <hip/hip_runtime.h>
 #include "bbq_device.h"
+#include "bbq_kernel_common.h"
 #include "bbq_launch.h"
 
 #pragma clang fp contract(off)
 
 namespace bbq {
-
-// streamed, read-once data: non-temporal loads (A/B on MI355X: see DESIGN.md); -DBBQ_PLAIN_LOADS for the experiment
-#ifdef BBQ_PLAIN_LOADS
-#define BBQ_STREAM_LOAD(p) (*(p))
-#else
-#define BBQ_STREAM_LOAD(p) __builtin_nontemporal_load(p)
-#endif
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef double f64x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t popc4(u32x4 v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
-
-// Math.max(x, 0) of the reference: NaN propagates, -0 -> +0
-__device__ __forceinline__ double js_max0(double x) { return (x != x) ? x : (x > 0.0 ? x : 0.0); }
-
-// src/batchDotProduct.ts:478-541 (one_bit) / :554-617 (every other queryBits); SURVEY App. A.4.
-// Parenthesised exactly as JavaScript evaluates the reference's expressions; no FMA contraction.
-__device__ __forceinline__ double score_f64(double qc, double ax, double ux, double xadd, double x1, const QueryParams &p) {
-  const double lx = ux - ax;
-  const double t1 = (ax * p.ay) * p.dimd;
-  const double t2 = (p.ay * lx) * x1;
-  const double t3 = (ax * p.ly) * p.y1;
-  const double t4 = (lx * p.ly) * qc;
-  const double s = ((t1 + t2) + t3) + t4;
-  if (p.sim == 0) {  // EUCLIDEAN
-    const double e = (p.qadd + xadd) - (2.0 * s);
-    return js_max0(1.0 / (1.0 + e));
-  }
-  const double t = p.one_bit ? (s + ((p.qadd + xadd) - p.cdp)) : (((s + p.qadd) + xadd) - p.cdp);
-  if (p.sim == 1) return js_max0((1.0 + t) / 2.0);  // COSINE
-  // scaleMaxInnerProductScore (src/utils.ts:171-176): the 1-bit batch form (:527-533) and the per-row scorer's form for
-  // every query width (src/binaryQuantizedScorer.ts:148-153, :207-209), which is what answers for multi-bit indexes
-  if (p.one_bit || p.mip_plain) return t < 0.0 ? 1.0 / (1.0 - t) : t + 1.0;
-  const double FBS = 1.0 / 15.0;  // FOUR_BIT_SCALE, src/constants.ts:20 - a true division by it, not *15
-  return t < 0.0 ? 1.0 / (1.0 - t / FBS) : t / FBS + 1.0;
-}
-
-// One tile = 64 rows, one row per lane.  W = compile-time number of 16-byte chunks per row (0: runtime).
-template <int QB, int W>
-__device__ __forceinline__ void tile_popcounts(const uint8_t *__restrict__ tp, int lane, int w16,
-                                               const u32x4 *__restrict__ s_planes, uint32_t (&acc)[QB], uint32_t &ones) {
-  const u32x4 *__restrict__ cp = reinterpret_cast<const u32x4 *>(tp) + lane;
-#pragma unroll
-  for (int p = 0; p < QB; ++p) acc[p] = 0;
-  ones = 0;
-  if constexpr (W > 0) {
-    u32x4 c[W];
-#pragma unroll
-    for (int j = 0; j < W; ++j) c[j] = BBQ_STREAM_LOAD(cp + j * kTileRows);
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-#pragma unroll
-      for (int p = 0; p < QB; ++p) acc[p] += popc4(c[j] & s_planes[j * QB + p]);
-      ones += popc4(c[j]);
-    }
-  } else {
-    for (int j = 0; j < w16; ++j) {
-      const u32x4 c = BBQ_STREAM_LOAD(cp + j * kTileRows);
-#pragma unroll
-      for (int p = 0; p < QB; ++p) acc[p] += popc4(c & s_planes[j * QB + p]);
-      ones += popc4(c);
-    }
-  }
-}
 
 // Multi-bit index rows (indexBits > 1): qcDist = sum_d q[d] * x[d] (computeQuantizedDotProduct, src/bitwiseDotProduct.ts:14-30)
 // over SB-bit fields with the packed-nibble / packed-byte dot instructions - 8 (v_dot8_u32_u4) or 4 (v_dot4_u32_u8) exact
@@ -146,53 +82,6 @@ __device__ __forceinline__ void tile_dot_multibit(const uint8_t *__restrict__ tp
     }
   }
   qc = lo + (hi << 4);
-}
-
-// Upper bound of the score when only the COMPACT corrections are known (kLayoutCompact).
-// The raw score s is linear in (lower, upper): with x1 and qcDist fixed,
-//     s(lower, upper) = lower * A + upper * B,   A = ay*(dim - x1) + ly*(y1 - qc),   B = ay*x1 + ly*qc,
-// so replacing (lower, upper, add) by their compact values (al, au, aadd) changes s by exactly
-// (lower-al)*A + (upper-au)*B and the additive term by (add-aadd).  |lower-al| <= |al|*kBf16Rel + kAbsSlack
-// (f32 rounding + truncation to the upper 16 bits), |add-aadd| <= |aadd|*2^-23 + kAbsSlack.  All three similarity
-// transforms are monotone in s (resp. in t), and a generous rounding allowance (kRoundRel, ~7 orders of magnitude
-// above the real f64 round-off of these ~20 operations) covers the difference between exact-arithmetic reasoning and
-// IEEE evaluation.  Returns a value U with  exact f64 score <= U  (NaN or +inf when no finite bound can be given:
-// the caller then takes the exact path).  tests/test_bound_math_cpu.py restates this in numpy and checks dominance.
-constexpr double kBf16Rel = 0.0078125 * (1.0 + 1.0 / 65536.0);  // 2^-7 (1 + 2^-16)
-constexpr double kF32Rel = 1.1920928955078125e-07;             // 2^-23
-constexpr double kAbsSlack = 1e-37;
-constexpr double kRoundRel = 1e-9;
-
-__device__ __forceinline__ double score_upper_bound(double qc, double al, double au, double aadd, double x1, const QueryParams &p) {
-  const double lx = au - al;
-  const double t1 = (al * p.ay) * p.dimd;
-  const double t2 = (p.ay * lx) * x1;
-  const double t3 = (al * p.ly) * p.y1;
-  const double t4 = (lx * p.ly) * qc;
-  const double s = ((t1 + t2) + t3) + t4;
-  const double A = p.ay * (p.dimd - x1) + p.ly * (p.y1 - qc);
-  const double B = p.ay * x1 + p.ly * qc;
-  const double mag = fabs(t1) + fabs(t2) + fabs(t3) + fabs(t4) + fabs(p.qadd) + fabs(aadd) + fabs(p.cdp) + 1.0;
-  if (!(mag < 1e290)) return __longlong_as_double(0x7ff8000000000000ll);  // non-finite / huge: no bound
-  const double es = fabs(A) * (fabs(al) * kBf16Rel + kAbsSlack) + fabs(B) * (fabs(au) * kBf16Rel + kAbsSlack);
-  const double eadd = fabs(aadd) * kF32Rel + kAbsSlack;
-  const double slop = kRoundRel * (mag + fabs(A) + fabs(B));
-  if (p.sim == 0) {  // EUCLIDEAN: score = max(1/(1+e), 0), decreasing in e while 1+e > 0
-    const double e_low = ((p.qadd + aadd) - (2.0 * s)) - (2.0 * es + eadd + slop);
-    const double den = 1.0 + e_low;
-    if (!(den > 0.0)) return __longlong_as_double(0x7ff0000000000000ll);  // +inf: cannot exclude a tiny positive denominator
-    const double u = 1.0 / den;
-    return u + kRoundRel * (u + 1.0);
-  }
-  const double t_up = (((s + p.qadd) + aadd) - p.cdp) + (es + eadd + slop);
-  double u;
-  if (p.sim == 1) u = js_max0((1.0 + t_up) / 2.0);
-  else if (p.one_bit || p.mip_plain) u = t_up < 0.0 ? 1.0 / (1.0 - t_up) : t_up + 1.0;
-  else {
-    const double FBS = 1.0 / 15.0;
-    u = t_up < 0.0 ? 1.0 / (1.0 - t_up / FBS) : t_up / FBS + 1.0;
-  }
-  return u + kRoundRel * (fabs(u) + 1.0);
 }
 
 // MODE: 0 sparse / inline corrections, 1 dense / inline, 2 sparse / compact corrections + exact gather, 3 dense / compact
@@ -487,111 +376,6 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_shared_kernel(const ScanA
 // ---------------------------------------------------------------------------------------------------
 // finalize: one workgroup (1024 threads) per query
 
-__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t *s_wave, uint32_t &total) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t incl = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t n = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += n;
-  }
-  if (lane == 63) s_wave[wave] = incl;
-  __syncthreads();
-  uint32_t wave_off = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < 16; ++w) {
-    const uint32_t x = s_wave[w];
-    if (w < wave) wave_off += x;
-    tot += x;
-  }
-  total = tot;
-  __syncthreads();
-  return wave_off + incl - v;
-}
-
-// k-th largest of the M keys in LDS (M >= k >= 1): radix select over the key bytes that actually vary, one 1024-thread workgroup;
-// every thread returns it.  s_hist: 2 x 256 words, s_wave: 16 words, s_scr: 8 words of scratch owned by this function.
-// Barriers are what this costs (16 waves: ~0.4 us each), so there are two per pass: the histogram of a pass is built in one of two
-// buffers while the other is being cleared, and every pass leaves its result in words of its own.
-__device__ __forceinline__ uint32_t block_select_kth_largest(const uint32_t *s_keys, uint32_t M, uint32_t k, uint32_t *s_hist, uint32_t *s_wave,
-                                                             uint32_t *s_scr) {
-  const int tid = threadIdx.x;
-  // Scores of one query live in a narrow range: the upper bytes of their keys are the same for (nearly) all of them, and a
-  // histogram pass over such a byte is thousands of atomic adds on ONE LDS word (measured: 10 us per pass at 6 K keys).
-  // Bytes that are constant over all keys are therefore skipped: they belong to the answer as they are.
-  uint32_t vary = 0;
-  {
-    const uint32_t key0 = s_keys[0];
-    for (uint32_t i = tid; i < M; i += kFinalizeThreads) vary |= s_keys[i] ^ key0;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) vary |= __shfl_xor(vary, d, 64);
-    if ((tid & 63) == 0) s_wave[tid >> 6] = vary;
-    if (tid < 512) s_hist[tid] = 0;
-    __syncthreads();
-    vary = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) vary |= s_wave[w];
-  }
-  uint32_t prefix = 0, mask = 0, kk = k;
-  int buf = 0;
-  for (int pass = 3; pass >= 0; --pass) {
-    const int sh = pass * 8;
-    if (((vary >> sh) & 255u) == 0u) {  // uniform: every key has the same byte here
-      prefix |= s_keys[0] & (255u << sh);
-      mask |= 255u << sh;
-      continue;
-    }
-    uint32_t *__restrict__ hist = s_hist + 256 * buf;
-    for (uint32_t i0 = 0; i0 < M; i0 += kFinalizeThreads) {  // whole waves iterate together (ballots below)
-      const uint32_t i = i0 + tid;
-      const bool in = i < M && (s_keys[i < M ? i : 0] & mask) == prefix;
-      const uint32_t bin = in ? (s_keys[i] >> sh) & 255u : 256u;
-      // a byte with few distinct values would still pile the adds on a few words: the lanes that share the first active lane's
-      // bin add once for all of them
-      const unsigned long long act = __ballot(in);
-      if (act) {
-        const uint32_t b0 = __shfl(bin, __ffsll((long long)act) - 1, 64);
-        const unsigned long long same = __ballot(in && bin == b0);
-        if (in && bin == b0) {
-          if ((tid & 63) == __ffsll((long long)same) - 1) atomicAdd(&hist[b0], (uint32_t)__popcll(same));
-        } else if (in) {
-          atomicAdd(&hist[bin], 1u);
-        }
-      }
-    }
-    __syncthreads();
-    if (tid < 64) {
-      // wave 0 finds the bin: lane l owns bins 4l..4l+3; suffix sums over lanes by shuffles (no LDS round trips)
-      const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
-      uint32_t suf = h0 + h1 + h2 + h3;  // becomes the sum over bins >= 4*tid
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t n = __shfl_down(suf, d, 64);
-        if (tid + d < 64) suf += n;
-      }
-      const uint32_t above = suf - (h0 + h1 + h2 + h3);  // bins > 4*tid+3
-      if (suf >= kk && above < kk) {                     // exactly one lane: the k-th largest lies in its 4 bins
-        uint32_t cum = above;
-        int b = 4 * tid + 3;
-        if (cum + h3 < kk) { cum += h3; b = 4 * tid + 2;
-          if (cum + h2 < kk) { cum += h2; b = 4 * tid + 1;
-            if (cum + h1 < kk) { cum += h1; b = 4 * tid; } } }
-        s_scr[2 * pass] = (uint32_t)b;
-        s_scr[2 * pass + 1] = kk - cum;
-      }
-    } else if (tid >= 256 && tid < 512) {
-      s_hist[256 * (buf ^ 1) + (tid - 256)] = 0;  // the other buffer, for the next pass
-    }
-    __syncthreads();
-    prefix |= s_scr[2 * pass] << sh;
-    mask |= 255u << sh;
-    kk = s_scr[2 * pass + 1];
-    buf ^= 1;
-  }
-  __syncthreads();  // the caller may reuse the scratch words and the keys
-  return prefix;
-}
-
 __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const FinalizeArgs a) {
   // dynamic LDS (kFinalizeLdsBytes, above the 64 KB a kernel gets without asking): keys | copy jobs | histogram | scratch
   extern __shared__ __attribute__((aligned(16))) unsigned char fin_smem[];
@@ -604,8 +388,13 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
   const int q = blockIdx.x;
   const int tid = threadIdx.x;
   uint32_t flags = 0;
+  // the query's control words, all fetched at once (each was a memory round trip of its own on the critical path of a launch that
+  // lasts ten microseconds): the scan launch that wrote them is over, nothing but thread 0 below changes them
   const int64_t base = a.emit ? a.list_counts[2 * q] : 0;
-  __syncthreads();  // every thread has read the running count before thread 0 rewrites it below
+  const uint32_t appended = a.append_counts ? a.append_counts[q] : 0u;
+  const uint32_t tcount0 = (uint32_t)a.topk_counts[q];
+  const uint32_t flags0 = a.flags[q];
+  __syncthreads();  // every thread has read them before thread 0 rewrites them below
   uint64_t *__restrict__ list = a.lists + (size_t)q * a.list_cap;
   uint32_t m_new = 0;
 
@@ -619,10 +408,10 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
     }
   } else if (a.append_counts) {
     // the scan launch appended its candidates to the list itself: only their keys are needed here
-    m_new = a.append_counts[q];
-    __syncthreads();  // every thread has the count before thread 0 resets it for the next segment
+    m_new = appended;
     if (tid == 0) a.append_counts[q] = 0u;
     if (base + m_new > a.list_cap) m_new = 0;  // the workgroups that did not fit have flagged the query: it takes the dense path
+#pragma unroll 4
     for (uint32_t j = tid; j < m_new && j < (uint32_t)kFinalizeKeyCap; j += kFinalizeThreads) s_keys[j] = key_of_bits((uint32_t)list[base + j]);
     __syncthreads();
   } else {
@@ -708,7 +497,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
   }
 
   if (a.need_theta) {
-    const uint32_t tcount = (uint32_t)a.topk_counts[q];
+    const uint32_t tcount = tcount0;
     uint32_t *__restrict__ tk = a.topk_keys + (size_t)q * a.k;
     {
       // more new keys than the LDS buffer holds (a flood): select among the ones that fit.  The k-th largest of any
@@ -738,8 +527,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
       }
     }
   }
-  const uint32_t f_all = a.flags[q] | flags;  // every thread: uniform (the flags word is only written by thread 0 below, after this read ...)
-  __syncthreads();                             // ... which this barrier orders
+  const uint32_t f_all = flags0 | flags;  // every thread: uniform
   if (tid == 0) {
     a.flags[q] = f_all;
     a.list_counts[2 * q + 1] = (int32_t)f_all;
@@ -750,7 +538,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
     const bool shard = a.final_shard != 0;
     const int hdr_slots = shard ? 3 : 2;
     const int64_t total = base + m_new;  // entries of the complete list
-    const uint32_t tcount = (uint32_t)a.topk_counts[q];
+    const uint32_t tcount = a.need_theta ? (uint32_t)a.topk_counts[q] : tcount0;  // need_theta (never set on a last segment) would have rewritten it
     bool ok = f_all == 0 && a.emit && total <= a.list_cap && k2 >= 1 && k2 <= kFinalSelectMax && k2 + hdr_slots <= a.final_stride &&
               m_new <= (uint32_t)kFinalizeKeyCap - tcount && a.k == k2 + 1;
     uint64_t *__restrict__ s_sel = reinterpret_cast<uint64_t *>(s_jobs);  // the copy jobs are done with
@@ -794,12 +582,21 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
     if (ok) {
       if (tid == 0) { s_misc[2] = 0; s_misc[3] = 0; }
       __syncthreads();
-      for (int64_t i = tid; i < total; i += kFinalizeThreads) {
-        const uint64_t ent = list[i];
-        const uint32_t key = key_of_bits((uint32_t)ent);
-        if (take_all || key > th1) {
-          const uint32_t slot = atomicAdd(&s_misc[2], 1u);
-          if (slot < (uint32_t)kFinalSelectMax) s_sel[slot] = ((uint64_t)key << 32) | (ent >> 32);
+      for (int64_t i0 = 0; i0 < total; i0 += 4 * kFinalizeThreads) {  // four independent loads in flight per thread
+        uint64_t ent[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t i = i0 + (int64_t)u * kFinalizeThreads + tid;
+          ent[u] = i < total ? list[i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t i = i0 + (int64_t)u * kFinalizeThreads + tid;
+          const uint32_t key = key_of_bits((uint32_t)ent[u]);
+          if (i < total && (take_all || key > th1)) {
+            const uint32_t slot = atomicAdd(&s_misc[2], 1u);
+            if (slot < (uint32_t)kFinalSelectMax) s_sel[slot] = ((uint64_t)key << 32) | (ent[u] >> 32);
+          }
         }
       }
       __syncthreads();
@@ -829,12 +626,26 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
       __syncthreads();
       ok = s_misc[3] == 0;
     }
+    if (a.done_flag) {  // latency path: the entries above went to mapped host memory - they must be there before the header and the sequence word
+      __threadfence_system();
+      __syncthreads();
+    }
     if (tid == 0) {
       uint64_t *__restrict__ hdr = a.final_out + (size_t)q * a.final_stride;
       const uint32_t listed = a.emit ? (uint32_t)min((int64_t)(base + m_new), a.list_cap) : 0u;
       hdr[0] = (uint64_t)listed | ((uint64_t)f_all << 32);
       hdr[1] = (uint64_t)(ok ? n_sel : 0u) | ((uint64_t)(ok ? 0u : 1u) << 32);
       if (shard) hdr[2] = (ok && !take_all) ? (uint64_t)th1 : 0ull;
+      if (a.done_flag) {
+        // the next call's chain starts without a copy that would reset the control words: leave them clean
+        a.flags[q] = 0u;
+        a.theta[q] = 0u;
+        a.topk_counts[q] = 0;
+        a.list_counts[2 * q] = 0;
+        a.list_counts[2 * q + 1] = 0;
+        __threadfence_system();
+        __hip_atomic_store(a.done_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }

@@ -29,6 +29,13 @@ hipError_t launch_tile_add_range(const double *exact, int64_t n_rows, float *add
 hipError_t launch_check_x1(const uint8_t *codes, const double *corr, int64_t n_rows, int32_t pb, uint32_t *mismatch,
                            hipStream_t s);
 
+// latency path (bbq_latency_kernels.hip): false when this index shape has no instantiation (the caller takes the general path)
+bool latency_path_supported(const IndexView &v, int planes);
+hipError_t launch_lat_scan(const LatScanArgs &a, int planes, hipStream_t s);
+// pre-sampled threshold: per-wave top keys of the first rows, then theta := the rank-th largest of them (0 when there are fewer)
+hipError_t launch_lat_pre(const LatPreArgs &a, int planes, hipStream_t s);
+hipError_t launch_lat_select(const uint32_t *pre_keys, int n_keys, int rank, uint32_t *theta, hipStream_t s);
+
 // index build on the device (bbq_build_kernels.hip); vT4 is the [ceil(dim/4)][npad] float4 transposed copy
 hipError_t launch_build_transpose(const float *in, int64_t n, int32_t dim, int64_t npad, float *vT4, hipStream_t s);
 hipError_t launch_build_normalize(float *vT4, int64_t n, int32_t dim, int64_t npad, hipStream_t s);

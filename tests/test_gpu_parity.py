@@ -1293,3 +1293,62 @@ def test_device_select_boundary_ties_and_duplicates():
             np.testing.assert_array_equal(canon32(sc), canon32(osc))
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("dim,qb,sim,compact,n", [(768, 4, 1, True, 150_000), (768, 4, 0, False, 150_000), (1024, 1, 2, True, 150_000),
+                                                  (1536, 4, 2, True, 90_000), (768, 8, 1, True, 150_000), (1024, 2, 0, True, 150_000),
+                                                  (1536, 8, 1, False, 90_000), (768, 1, 1, False, 150_000), (768, 4, 1, True, 600_000),
+                                                  (1024, 4, 2, False, 400_000), (1536, 4, 0, True, 300_000)])
+def test_latency_fused_path_equals_general_path(dim, qb, sim, compact, n):
+    """the single-query call without copies (bbq_latency_kernels.hip: query in the kernel arguments of every sweep, answer polled from
+    mapped host memory) - with the pre-sampled threshold (indexes of 262144 rows and more) and as the segmented chain - against the
+    oracle and against the general path (latency_fused 0), on rows with duplicates (equal scores -> host replay of the complete
+    list), for k from 1 to 500"""
+    rng = np.random.default_rng(dim * 10 + qb + sim)
+    pb = dim // 8
+    codes = rng.integers(0, 256, size=(n, pb), dtype=np.uint8)
+    corr = np.empty((n, 4))
+    corr[:, 0] = -0.04 * (0.9 + 0.2 * rng.random(n))
+    corr[:, 1] = 0.04 * (0.9 + 0.2 * rng.random(n))
+    corr[:, 2] = 1e-4 * (2 * rng.random(n) - 1)
+    corr[:, 3] = np.unpackbits(codes, axis=1).sum(axis=1)
+    dup = rng.integers(0, n, 4000)
+    codes[dup[2000:]] = codes[dup[:2000]]      # duplicated rows: equal scores, some of them inside an answer
+    corr[dup[2000:]] = corr[dup[:2000]]
+    cdp = 0.0009
+    qq = rng.integers(0, 1 << qb, size=(12, dim), dtype=np.uint8)
+    qc = np.empty((12, 4))
+    qc[:, 0] = -0.15 * (0.9 + 0.2 * rng.random(12))
+    qc[:, 1] = 0.148 * (0.9 + 0.2 * rng.random(12))
+    qc[:, 2] = -0.0028 * rng.random(12)
+    qc[:, 3] = qq.sum(axis=1)
+    ix = _make_index(codes, corr, dim, cdp, compact)
+    try:
+        replays = 0
+        for q in range(12):
+            _, _, s32 = O.score_all(codes, corr, dim, qq[q], qc[q], qb, sim, cdp)
+            for k in ((1, 10, 100, 500) if q < 3 else (100,)):
+                oi, osc = O.heap_topk(s32, k)
+                for fused, presample in ((1, 1), (1, 0), (0, 0)):
+                    ix.set_option("latency_fused", fused)
+                    ix.set_option("latency_presample", presample)
+                    fi, fs = ix.search(qq[q], qc[q], qb, sim, k)
+                    replays += ix.stats()["host_replays"]
+                    np.testing.assert_array_equal(fi, oi, err_msg="fused %d presample %d q%d k=%d" % (fused, presample, q, k))
+                    np.testing.assert_array_equal(fs.view(np.uint32), osc.view(np.uint32))
+        # a NaN row flags the query: dense path, still exact
+        corr2 = corr.copy()
+        corr2[n // 2, 0] = np.nan
+        ix.close()
+        ix = _make_index(codes, corr2, dim, cdp, compact)
+        ix.set_option("latency_fused", 1)
+        ix.set_option("latency_presample", 1)
+        _, _, s32 = O.score_all(codes, corr2, dim, qq[0], qc[0], qb, sim, cdp)
+        oi, osc = O.heap_topk(s32, 50)
+        fi, fs = ix.search(qq[0], qc[0], qb, sim, 50)
+        np.testing.assert_array_equal(fi, oi)
+        assert ix.stats()["dense_fallbacks"] == 1
+        # k beyond the path's limit takes the general path
+        oi, _ = O.heap_topk(s32, 50)
+    finally:
+        ix.close()
