@@ -595,7 +595,7 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const 
   const bool use_final = !d_lists_ext && p.final_k > 0 && !p.segs.empty();
   // few queries: the sparse launches append their candidates to the list themselves (ScanArgs::append_lists)
   const bool append = use_final && p.latency && ix->opt_latency_append && !ix->has_pilot && ix->opt_share == 1;
-  s.appended = append;
+  s.appended = append || (use_mfma && !d_lists_ext);
   s.timed = false;
   for (const Segment &g : p.segs) {
     const Storage &sto = g.storage == 0 ? ix->pilot : ix->main;
@@ -617,7 +617,9 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const 
     a.ovf_cap = (int32_t)p.flood_cap;
     a.dense_score32 = g.dense ? s.d_dense0 : nullptr;
     a.dense_stride = s.dense_cap;
-    const bool append_here = append && !g.dense && (ix->opt_append_last || &g != &p.segs.back());
+    // the matrix-core shared sweep appends as well whenever the lists are this slot's own: its waves then never wait for each other
+    const bool mfma_append = use_mfma && !g.dense && !d_lists_ext;
+    const bool append_here = (append && !g.dense && (ix->opt_append_last || &g != &p.segs.back())) || mfma_append;
     if (append_here) {
       a.append_lists = d_lists;
       a.append_base = d_list_counts;

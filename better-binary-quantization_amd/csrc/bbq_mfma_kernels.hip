@@ -9,6 +9,14 @@
 // The k -> dimension assignment is free as long as A and B agree, so the host lays the query bytes out in the order the
 // code bits fall out of the packed words (fill_query_mfma in bbq_core.cpp).
 //
+// Operand roles (round 3): the QUERIES are the A operand (M = 32 queries) and the index ROWS the B operand (N = 32 rows), so a
+// lane's 16 accumulators are 16 queries against ONE row (column lane%32) - its own row, or its half-wave partner's.  The row's
+// pre-filter constants therefore sit in the lane's registers, and only the per-query constants (one float4, the same for the whole
+// half-wave) come from LDS: 32 reads per tile where the rows-as-A layout needed 128 (two float4 per pair, from a per-row table).
+// The kernel is bound by the CU's LDS bandwidth (PMC: waves wait on LDS more than half of the time; a ds_read_b128 occupies the LDS
+// for 8 clocks): per 64-row tile and wave 48 query-fragment reads + 128 row-constant reads = 1408 clocks of LDS per tile and CU
+// before, 48 + 32 = 640 now - profiles/r03_mfma_*.
+//
 // Per (row, query) pair a cheap, provably conservative f32 pre-filter in "z-space" (the monotone argument of the
 // similarity transform) rejects almost everything; the rare survivors go through the f64 bound and the exact f64 score of
 // the one-sweep kernel, so the emitted candidates - and therefore the results - are identical.
@@ -88,8 +96,6 @@ struct MfmaArgs {
   int32_t nq_total;
 };
 
-// row constants of the pre-filter, per tile row (LDS): 2 x float4
-//   c0 = {R1, Rdx, x1, al}   c1 = {lx, addz + slack, ea, eu}
 // Pairs that pass the pre-filter are pushed to a per-wave LDS queue (packed qc | row-in-tile << 20 | query << 26) and
 // scored exactly afterwards by ONE copy of the exact code, 64 pairs at a time.
 constexpr int kMfmaQueueCap = 512;
@@ -101,8 +107,9 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
   constexpr int NW = kChunkRows / 64;
   constexpr int WORDS = W * 4;
   u32x4m *s_B = reinterpret_cast<u32x4m *>(smem);                                    // [WORDS*2][32]
-  f32x4m *s_row = reinterpret_cast<f32x4m *>(smem + (size_t)WORDS * 2 * 32 * 16);    // [NW][64][2]
-  uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_row + NW * 64 * 2);             // [NW][kMfmaQueueCap]
+  f32x4m *s_qk = reinterpret_cast<f32x4m *>(smem + (size_t)WORDS * 2 * 32 * 16);     // [32] per-query pre-filter constants {cs*ay, cs*ly, y1, zth - margin}
+  float *s_x1 = reinterpret_cast<float *>(s_qk + kMfmaQueries);                      // [NW][64] popcount of every tile row (exact in f32), for the survivors' exact scores
+  uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_x1 + NW * 64);                  // [NW][kMfmaQueueCap]
   uint32_t *s_qcount = s_queue + NW * kMfmaQueueCap;                                 // [NW] (+ padding to 16 B)
   QueryParams *s_qp = reinterpret_cast<QueryParams *>(s_qcount + 8);                 // [32]
   double *s_zth = reinterpret_cast<double *>(s_qp + kMfmaQueries);                   // [32]
@@ -124,8 +131,16 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
       if (tid < nb) { p = a.s.qparams[q0 + tid]; th = a.s.theta[q0 + tid]; }
       s_qp[tid] = p;
       s_theta[tid] = th;
-      s_zth[tid] = tid < nb ? z_threshold(th, p) : DBL_MAX;
+      const double zt = tid < nb ? z_threshold(th, p) : DBL_MAX;
+      s_zth[tid] = zt;
       s_cnt[tid] = 0;
+      // what the pre-filter compares with, per query: cs = 2 for EUCLIDEAN (z = 2s - xadd), 1 otherwise.  Lanes without a query get a
+      // threshold nothing passes.  (float)zt rounds; the compare carries its own margin
+      const float csf = p.sim == 0 ? 2.0f : 1.0f;
+      const float zth = (float)zt;
+      f32x4m qk;
+      qk.x = csf * (float)p.ay; qk.y = csf * (float)p.ly; qk.z = (float)p.y1; qk.w = zth - 1e-6f * (fabsf(zth) + 1.0f);
+      s_qk[tid] = qk;
     }
     if (tid < NW) s_qcount[tid] = 0;
   }
@@ -162,14 +177,8 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
   const int64_t tile = chunk * kTilesPerChunk + wave;
 
   if (tile < n_tiles) {  // wave-uniform
-    const QueryParams p = s_qp[n];          // this lane's query (column n of the C tile)
-    const float zth = (float)s_zth[n];       // rounded; the compare below carries its own margin
-    const float zth_margin = 1e-6f * (fabsf(zth) + 1.0f);
-    const int sim = s_qp[0].sim;            // uniform over the call (lanes without a query hold zeros in p)
-    // per-query pre-filter constants, scaled into z-space (c_s = 2 for EUCLIDEAN, 1 otherwise)
-    const float cs = sim == 0 ? 2.0f : 1.0f;
-    const float ayq = (float)p.ay, lyq = (float)p.ly, y1q = (float)p.y1;
-    const float ayz = cs * ayq, lyz = cs * lyq;
+    const int sim = s_qp[0].sim;            // uniform over the call (lanes without a query hold zeros)
+    const float inv_cs = sim == 0 ? 0.5f : 1.0f;  // s_qk holds cs*ay, cs*ly (cs = 2 for EUCLIDEAN, 1 otherwise): exact scalings
     const float *__restrict__ gm = a.qmax + (size_t)group * 4;
     const float AYmax = gm[0], LYmax = gm[1], Y1max = gm[2];
 
@@ -217,7 +226,10 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
     for (int j = 0; j < W; ++j) ones += __popc(c[j].x) + __popc(c[j].y) + __popc(c[j].z) + __popc(c[j].w);
     double x1row = (double)ones;  // quantizedComponentSum of a 1-bit row is its popcount ...
     if (a.s.idx.has_x1) x1row = reinterpret_cast<const double *>(cr + 1536)[lane];  // ... unless the index says otherwise
-    {  // row constants of the pre-filter for MY row -> LDS (read back per C element by the lanes that own it)
+    // row constants of the pre-filter for MY row (tile row `lane`), in registers:
+    //   k0 = {R1, D - x1, x1, al}   k1 = {lx, ca*add + slack, cs*ea, cs*eu}
+    f32x4m k0, k1;
+    {
       const double D = s_qp[0].dimd;   // same for every query of the batch
       const double x1 = x1row, lx = au - al;
       const double R1 = al * D + lx * x1;
@@ -225,20 +237,16 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
       // f32 evaluation slack: 8 roundings of terms bounded with the group's largest query constants, doubled
       const double F = (double)AYmax * fabs(R1) + (double)LYmax * (double)Y1max * (fabs(al) + fabs(lx)) + fabs(aadd) + 1.0;
       const double slack = cs_d * (2e-6 * F + 1e-3 * (ea + eu) * ((double)AYmax * D + 2.0 * (double)LYmax * (double)Y1max)) + eadd * 1.001;
-      f32x4m k0, k1;
       k0.x = (float)R1; k0.y = (float)(D - x1); k0.z = (float)x1; k0.w = (float)al;
       // non-finite or huge rows: force a pass (an infinite slack makes every compare below fail to reject)
       const bool weird = !(fabs(R1) + fabs(al) + fabs(lx) + fabs(aadd) < 1e30);
       const float slack32 = weird ? __uint_as_float(0x7f800000u) : (float)slack * 1.001f + 1e-30f;
       k1.x = (float)lx; k1.y = (float)(ca_d * aadd) + slack32; k1.z = (float)(cs_d * ea * 1.001); k1.w = (float)(cs_d * eu * 1.001);
       // (float)(ca*aadd) + slack32 rounds once more: one extra ulp of |ca*aadd| is inside the 1.001 factors of slack (eadd part)
-      f32x4m *dst = s_row + ((size_t)wave * 64 + lane) * 2;
-      dst[0] = k0; dst[1] = k1;
+      s_x1[wave * 64 + lane] = k0.z;   // for the survivors' exact scores (any lane may score any row of the tile)
     }
-
-    // ---- the contraction, one row group (32 rows x 32 queries) at a time: WORDS k-steps of 32 dims, then the
-    //      pre-filter of its 16 x 64 pairs; keeping only one accumulator tile live keeps the kernel under 128 VGPRs
-    const bool have_q = n < nb;
+    // ---- the contraction, one row group at a time: C[m = query][n = row of the group] over WORDS k-steps of 32 dims, then the
+    //      pre-filter of its 32 x 32 pairs (a lane: 16 queries x its column's row); one accumulator tile live keeps the kernel under 128 VGPRs
     uint32_t *__restrict__ queue = s_queue + (size_t)wave * kMfmaQueueCap;
     const int rows_here = (int)min((int64_t)kTileRows, a.s.idx.n_rows - tile * kTileRows);
 #pragma unroll 1
@@ -248,38 +256,61 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
       for (int g = 0; g < WORDS; ++g) {
         const uint32_t w = (g & 3) == 0 ? c[g >> 2].x : (g & 3) == 1 ? c[g >> 2].y : (g & 3) == 2 ? c[g >> 2].z : c[g >> 2].w;
         // v_permlane32_swap(w, w): [0] = {own | partner (lane-32)}, [1] = {partner (lane+32) | own}: exactly the word of
-        // A row m = lane%32 for row group 0 resp. 1 (lanes of the other half borrow their partner's row)
+        // tile row 32*rg + lane%32 (lanes of the other half borrow their partner's row)
         const auto sw2 = __builtin_amdgcn_permlane32_swap(w, w, false, false);
         const uint32_t aw = (rg == 0 ? sw2[0] : sw2[1]) >> (4 * h);
         // this half supplies 16 of the word's 32 dims: bits 4h+c+8i -> byte i of dword c (one shift + one AND per dword;
         // the host lays the query bytes out in the same order, fill_query_mfma)
-        i32x4m A;
-        A.x = (int)(aw & 0x01010101u); A.y = (int)((aw >> 1) & 0x01010101u);
-        A.z = (int)((aw >> 2) & 0x01010101u); A.w = (int)((aw >> 3) & 0x01010101u);
+        i32x4m R;
+        R.x = (int)(aw & 0x01010101u); R.y = (int)((aw >> 1) & 0x01010101u);
+        R.z = (int)((aw >> 2) & 0x01010101u); R.w = (int)((aw >> 3) & 0x01010101u);
         const u32x4m bq = s_B[(g * 2 + h) * 32 + n + lds_off];
-        i32x4m Bf;
-        Bf.x = (int)bq.x; Bf.y = (int)bq.y; Bf.z = (int)bq.z; Bf.w = (int)bq.w;
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, Bf, acc, 0, 0, 0);
+        i32x4m Q;
+        Q.x = (int)bq.x; Q.y = (int)bq.y; Q.z = (int)bq.z; Q.w = (int)bq.w;
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Q, R, acc, 0, 0, 0);   // A = queries (m), B = rows (n)
       }
-      // per (row, query) pre-filter; this lane owns query n and 16 rows of the group
+      // per (query, row) pre-filter; this lane owns tile row rit and 16 queries of the group
+      const int rit = 32 * rg + n;
+      const bool row_ok = rit < rows_here;
+      // the constants of tile row rit: my own row when rg == h, otherwise my half-wave partner's (fetched here, per row group, so that
+      // only one set is live).  swap(v, v): [0] = {own | partner(lane - 32)}, [1] = {partner(lane + 32) | own}
+      f32x4m r0 = k0, r1 = k1;
+      {  // every lane takes part in the swaps (a swap under a half-wave branch would read inactive lanes); the select follows
+        const bool other = rg != h;
+        const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(k0.x), __float_as_uint(k0.x), false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(k0.y), __float_as_uint(k0.y), false, false);
+        const auto sz = __builtin_amdgcn_permlane32_swap(__float_as_uint(k0.z), __float_as_uint(k0.z), false, false);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(k0.w), __float_as_uint(k0.w), false, false);
+        const auto tx = __builtin_amdgcn_permlane32_swap(__float_as_uint(k1.x), __float_as_uint(k1.x), false, false);
+        const auto ty = __builtin_amdgcn_permlane32_swap(__float_as_uint(k1.y), __float_as_uint(k1.y), false, false);
+        const auto tz = __builtin_amdgcn_permlane32_swap(__float_as_uint(k1.z), __float_as_uint(k1.z), false, false);
+        const auto tw = __builtin_amdgcn_permlane32_swap(__float_as_uint(k1.w), __float_as_uint(k1.w), false, false);
+        if (other) {
+          r0.x = __uint_as_float(h ? sx[0] : sx[1]); r0.y = __uint_as_float(h ? sy[0] : sy[1]);
+          r0.z = __uint_as_float(h ? sz[0] : sz[1]); r0.w = __uint_as_float(h ? sw[0] : sw[1]);
+          r1.x = __uint_as_float(h ? tx[0] : tx[1]); r1.y = __uint_as_float(h ? ty[0] : ty[1]);
+          r1.z = __uint_as_float(h ? tz[0] : tz[1]); r1.w = __uint_as_float(h ? tw[0] : tw[1]);
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int rit = 32 * rg + (r & 3) + 8 * (r >> 2) + 4 * h;  // row in tile
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * h;  // query of this accumulator
         const int qc = acc[r];
-        const f32x4m *__restrict__ rc = s_row + ((size_t)wave * 64 + rit) * 2;
-        const f32x4m k0 = rc[0], k1 = rc[1];
+        const f32x4m qk = s_qk[m];                    // {cs*ay, cs*ly, y1, zth - margin}: the same address for the whole half-wave
+        const float ayz = qk.x, lyz = qk.y, y1q = qk.z;
+        const float ayq = ayz * inv_cs, lyq = lyz * inv_cs;
         const float qcf = (float)qc;
-        const float u = fmaf(k1.x, qcf, k0.w * y1q);                 // al*y1 + lx*qc
-        const float z = fmaf(lyz, u, fmaf(ayz, k0.x, k1.y));         // cs*(ay*R1 + ly*u) + ca*add + slack
-        const float Ae = fmaf(lyq, y1q - qcf, ayq * k0.y);           // ay*(D-x1) + ly*(y1-qc)
-        const float Be = fmaf(lyq, qcf, ayq * k0.z);                 // ay*x1 + ly*qc
-        const float zu = fmaf(fabsf(Ae), k1.z, fmaf(fabsf(Be), k1.w, z));
+        const float u = fmaf(r1.x, qcf, r0.w * y1q);                 // al*y1 + lx*qc
+        const float z = fmaf(lyz, u, fmaf(ayz, r0.x, r1.y));         // cs*(ay*R1 + ly*u) + ca*add + slack
+        const float Ae = fmaf(lyq, y1q - qcf, ayq * r0.y);           // ay*(D-x1) + ly*(y1-qc)
+        const float Be = fmaf(lyq, qcf, ayq * r0.z);                 // ay*x1 + ly*qc
+        const float zu = fmaf(fabsf(Ae), r1.z, fmaf(fabsf(Be), r1.w, z));
         // NaN anywhere => the compare fails => pass; an overflowed (infinite) zu proves nothing either: pass
-        const bool pass = have_q && rit < rows_here && (!(zu <= (zth - zth_margin)) || !(fabsf(zu) <= 3.0e38f));
+        const bool pass = m < nb && row_ok && (!(zu <= qk.w) || !(fabsf(zu) <= 3.0e38f));
         if (pass) {
           const uint32_t slot = atomicAdd(&s_qcount[wave], 1u);
-          if (slot < (uint32_t)kMfmaQueueCap) queue[slot] = (uint32_t)qc | ((uint32_t)rit << 20) | ((uint32_t)n << 26);
-          else atomicOr(a.s.flags + q0 + n, kFlagOverflow);  // more survivors than the queue holds: this query goes dense
+          if (slot < (uint32_t)kMfmaQueueCap) queue[slot] = (uint32_t)qc | ((uint32_t)rit << 20) | ((uint32_t)m << 26);
+          else atomicOr(a.s.flags + q0 + m, kFlagOverflow);  // more survivors than the queue holds: this query goes dense
         }
       }
     }
@@ -299,19 +330,32 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
         up = reinterpret_cast<const double *>(cr)[2 * rit + 1];
         ad = reinterpret_cast<const double *>(cr + 1024)[rit];
       }
-      double x1d = (double)s_row[((size_t)wave * 64 + rit) * 2].z;  // popcount of the row: exact in f32 (<= 2^24)
+      double x1d = (double)s_x1[wave * 64 + rit];  // popcount of the row: exact in f32 (<= 2^24)
       if (a.s.idx.has_x1) x1d = reinterpret_cast<const double *>(cr + 1536)[rit];  // explicit sums may not be f32-exact
       const double s64 = m_score_f64((double)qc, lo, up, ad, x1d, pq);
       const float s32 = (float)s64;
       const uint32_t bits = __float_as_uint(s32);
       if (s32 != s32) atomicOr(a.s.flags + q0 + qn, kFlagNaN);
       else if (key_of_bits(bits) > s_theta[qn]) {
-        const uint32_t slot = atomicAdd(&s_cnt[qn], 1u);
-        if (slot < (uint32_t)a.s.cap) s_ent[(size_t)qn * a.s.cap + slot] = ((uint64_t)(uint32_t)(a.s.row_id_base + row) << 32) | bits;
+        const uint64_t ent = ((uint64_t)(uint32_t)(a.s.row_id_base + row) << 32) | bits;
+        if (a.s.append_lists) {
+          // append mode: straight into the query's list (unordered inside the segment; the finalize launch takes its keys from there
+          // and the rare host replay sorts).  No per-chunk staging, so the waves of a workgroup never wait for each other: the three
+          // barriers per tile of the slot mode were most of the 48 % of their time the waves spent parked (profiles/r03_mfma_pmc.md)
+          const uint32_t slot = atomicAdd(a.s.append_counts + q0 + qn, 1u);
+          const int64_t at = (int64_t)a.s.append_base[2 * (q0 + qn)] + slot;
+          if (at < a.s.append_cap) a.s.append_lists[(size_t)(q0 + qn) * a.s.append_cap + at] = ent;
+          else atomicOr(a.s.flags + q0 + qn, kFlagOverflow);
+        } else {
+          const uint32_t slot = atomicAdd(&s_cnt[qn], 1u);
+          if (slot < (uint32_t)a.s.cap) s_ent[(size_t)qn * a.s.cap + slot] = ent;
+        }
       }
     }
     (void)row_l;
+    if (a.s.append_lists) s_qcount[wave] = 0;  // this wave's queue is its own: ready for its next tile
   }
+  if (a.s.append_lists) continue;  // workgroup-uniform: nothing to flush, nobody to wait for
   __syncthreads();
   for (int b = wave; b < nb; b += NW) {  // each wave writes the lists of its share of the queries
     uint32_t cnt = s_cnt[b];
@@ -341,7 +385,7 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
 template <int W, bool COMPACT>
 static hipError_t launch_mfma_t(const MfmaArgs &a, int nq, int nc, hipStream_t s) {
   constexpr int NW = kChunkRows / 64;
-  const size_t smem = (size_t)W * 4 * 2 * 32 * 16 + (size_t)NW * 64 * 2 * 16 + (size_t)NW * kMfmaQueueCap * 4 + 32 +
+  const size_t smem = (size_t)W * 4 * 2 * 32 * 16 + (size_t)kMfmaQueries * 16 + (size_t)NW * 64 * 4 + (size_t)NW * kMfmaQueueCap * 4 + 32 +
                       kMfmaQueries * (sizeof(QueryParams) + 8 + 4 + 4) + (size_t)kMfmaQueries * a.s.cap * 8 + 64;
   dim3 grid((unsigned)((nc + kMfmaChunksPerBlock - 1) / kMfmaChunksPerBlock), (unsigned)((nq + kMfmaQueries - 1) / kMfmaQueries), 1),
       block(kChunkRows, 1, 1);
