@@ -824,8 +824,10 @@ def main():
             for name, (cN, cdim, cqb, cib, csim) in {"c2": (1_000_000, 768, 4, 1, "COSINE"), "c4": (10_000_000, 1536, 4, 1, "MAXIMUM_INNER_PRODUCT"),
                                                      "c5": (1_000_000, 1024, 8, 2, "COSINE")}.items():
                 try:
-                    legs[name] = config_leg(B, torch, name, cN, cdim, k, cqb, cib, csim, device, args.steps, args.warmup, 256, args.slots, args.replay_threads,
-                                            parity=not args.no_parity)
+                    # a step of a 1 M-row config lasts 4-10 ms: more steps than the headline's, so that a leg times at least ~0.2 s
+                    leg_steps = args.steps if cN >= 10_000_000 else max(args.steps * 8, 40)
+                    legs[name] = config_leg(B, torch, name, cN, cdim, k, cqb, cib, csim, device, leg_steps, max(args.warmup, 4), 256, args.slots,
+                                            args.replay_threads, parity=not args.no_parity)
                 except Exception as e:
                     legs[name] = {"error": str(e)[:300]}
                 log("config leg %s: %s" % (name, json.dumps(legs[name])[:400]))

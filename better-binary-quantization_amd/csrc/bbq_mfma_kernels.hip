@@ -178,7 +178,6 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
 
   if (tile < n_tiles) {  // wave-uniform
     const int sim = s_qp[0].sim;            // uniform over the call (lanes without a query hold zeros)
-    const float inv_cs = sim == 0 ? 0.5f : 1.0f;  // s_qk holds cs*ay, cs*ly (cs = 2 for EUCLIDEAN, 1 otherwise): exact scalings
     const float *__restrict__ gm = a.qmax + (size_t)group * 4;
     const float AYmax = gm[0], LYmax = gm[1], Y1max = gm[2];
 
@@ -227,7 +226,7 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
     double x1row = (double)ones;  // quantizedComponentSum of a 1-bit row is its popcount ...
     if (a.s.idx.has_x1) x1row = reinterpret_cast<const double *>(cr + 1536)[lane];  // ... unless the index says otherwise
     // row constants of the pre-filter for MY row (tile row `lane`), in registers:
-    //   k0 = {R1, D - x1, x1, al}   k1 = {lx, ca*add + slack, cs*ea, cs*eu}
+    //   k0 = {R1, D - x1, x1, al}   k1 = {lx, ca*add + slack, ea, eu}
     f32x4m k0, k1;
     {
       const double D = s_qp[0].dimd;   // same for every query of the batch
@@ -241,7 +240,7 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
       // non-finite or huge rows: force a pass (an infinite slack makes every compare below fail to reject)
       const bool weird = !(fabs(R1) + fabs(al) + fabs(lx) + fabs(aadd) < 1e30);
       const float slack32 = weird ? __uint_as_float(0x7f800000u) : (float)slack * 1.001f + 1e-30f;
-      k1.x = (float)lx; k1.y = (float)(ca_d * aadd) + slack32; k1.z = (float)(cs_d * ea * 1.001); k1.w = (float)(cs_d * eu * 1.001);
+      k1.x = (float)lx; k1.y = (float)(ca_d * aadd) + slack32; k1.z = (float)(ea * 1.001); k1.w = (float)(eu * 1.001);   // unscaled: the pair loop carries cs in A and B
       // (float)(ca*aadd) + slack32 rounds once more: one extra ulp of |ca*aadd| is inside the 1.001 factors of slack (eadd part)
       s_x1[wave * 64 + lane] = k0.z;   // for the survivors' exact scores (any lane may score any row of the tile)
     }
@@ -298,12 +297,13 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
         const int qc = acc[r];
         const f32x4m qk = s_qk[m];                    // {cs*ay, cs*ly, y1, zth - margin}: the same address for the whole half-wave
         const float ayz = qk.x, lyz = qk.y, y1q = qk.z;
-        const float ayq = ayz * inv_cs, lyq = lyz * inv_cs;
         const float qcf = (float)qc;
         const float u = fmaf(r1.x, qcf, r0.w * y1q);                 // al*y1 + lx*qc
         const float z = fmaf(lyz, u, fmaf(ayz, r0.x, r1.y));         // cs*(ay*R1 + ly*u) + ca*add + slack
-        const float Ae = fmaf(lyq, y1q - qcf, ayq * r0.y);           // ay*(D-x1) + ly*(y1-qc)
-        const float Be = fmaf(lyq, qcf, ayq * r0.z);                 // ay*x1 + ly*qc
+        // the error terms in the same scaling: cs*A, cs*B against ea, eu (cs is 1 or 2: scaling by it commutes with every rounding,
+        // so this is bit for bit |A|*(cs*ea) + |B|*(cs*eu) with A, B from the unscaled ay, ly - two multiplications per pair less)
+        const float Ae = fmaf(lyz, y1q - qcf, ayz * r0.y);           // cs*(ay*(D-x1) + ly*(y1-qc))
+        const float Be = fmaf(lyz, qcf, ayz * r0.z);                 // cs*(ay*x1 + ly*qc)
         const float zu = fmaf(fabsf(Ae), r1.z, fmaf(fabsf(Be), r1.w, z));
         // NaN anywhere => the compare fails => pass; an overflowed (infinite) zu proves nothing either: pass
         const bool pass = m < nb && row_ok && (!(zu <= qk.w) || !(fabsf(zu) <= 3.0e38f));

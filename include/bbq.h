@@ -179,6 +179,9 @@ int32_t bbq_index_bytes_per_row(const bbq_index *idx);
  *   out_idx/out_score [k]  (only min(k, size) entries are written); *out_n = number written
  * k == 0 -> *out_n = 0.  k < 0 -> BBQ_ERR_NEGATIVE_K.  k > 4096 is answered by the dense path (every f32 score to the
  * host; 16 ms per 10 M-row query instead of 0.15-4 ms).
+ * Multi-bit index (index_bits > 1) with query_bits other than 1 and 4: the reference throws (src/binaryQuantizedScorer.ts:95-97); this
+ * entry point scores it with the per-row 4-bit form - integer dot product pinned by fixtures, float score PARITY UNPINNED (the JS and
+ * Python hosts throw like the reference).
  */
 int bbq_search(bbq_index *idx, const uint8_t *qquant, const double *qcorr, int32_t query_bits, int32_t sim,
                int64_t k, int32_t *out_idx, float *out_score, int64_t *out_n);
@@ -382,7 +385,10 @@ int bbq_reset_stats(bbq_index *idx);
  *   compare equal - then the reference heap provably returns that order - and the host replays the heap only for the rest)
  *   latency_queries 0..1024 (4), latency_growth 2..4096 (64): calls with at most latency_queries queries walk the index in
  *   segments that grow by latency_growth instead of segment_growth (fewer dependent launches, more candidates per query) and their
- *   sweeps append the candidates to the query's list themselves (one atomic per workgroup; append_last 0|1 (1): also the last segment) */
+ *   sweeps append the candidates to the query's list themselves (one atomic per workgroup; append_last 0|1 (1): also the last segment)
+ *   latency_fused 0|1 (1): a call with ONE query runs without a copy at either end (query in the kernel arguments of every sweep, answer
+ *   polled from mapped host memory); latency_presample 0|1 (1): and, from 262144 rows, with its threshold from per-wave top keys of a
+ *   prefix - four launches in all (DESIGN.md "The single-query call") */
 int bbq_set_option(bbq_index *idx, const char *name, int64_t value);
 
 #ifdef __cplusplus

@@ -5,8 +5,11 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda e: e[0])
-# a call starts with its dense first-segment sweep (scan kernel MODE 1 / 3) and the host-to-device copy right before it
+# a call starts with its first launch: the pre-sampling kernel of the latency path (round 3), or - the general path - the dense
+# first-segment sweep (scan kernel MODE 1 / 3) and the host-to-device copy right before it
 def is_dense(name):
+    if "bbq_lat_pre_kernel" in name:
+        return True
     if "bbq_scan_kernel<" not in name:
         return False
     mode = name.split("bbq_scan_kernel<")[1].split(">")[0].split(",")[2].strip()

