@@ -306,6 +306,24 @@ def test_shard_scan_begin_argument_errors():
         ix.shard_scan_begin(qq, qc, 4, 1, 10, p.data_ptr(), 1 << 16, o.data_ptr(), f.data_ptr(), None, 0)
     finally:
         ix.close()
+    # another index of the same device is searched while a shard's batch is still in flight: the entry point settles the busy slots first
+    sh = B.Index(codes[2048:], corr[2048:], dim, B.centroid_dp(cen), row_base=2048, pilot_codes=codes[:1024], pilot_corr=corr[:1024])
+    other = B.Index(codes, corr, dim, B.centroid_dp(cen))
+    try:
+        p, o, f = torch.zeros(1 << 16, dtype=torch.int64, device="cuda"), torch.zeros(3, dtype=torch.int64, device="cuda"), torch.zeros(2, dtype=torch.int32, device="cuda")
+        a = torch.zeros(2 * 13, dtype=torch.int64, device="cuda")
+        sh.shard_scan_begin(qq, qc, 4, 1, 10, p.data_ptr(), 1 << 16, o.data_ptr(), f.data_ptr(), a.data_ptr(), 13)
+        idx, sc = other.search(qq[1], qc[1], 4, 1, 10)
+        _, _, s32 = O.score_all(codes, corr, dim, qq[1], qc[1], 4, 1, B.centroid_dp(cen))
+        np.testing.assert_array_equal(idx, O.heap_topk(s32, 10)[0])
+        total = sh.shard_scan_wait()
+        assert total == int(o.cpu().numpy()[2]) and int(f.abs().sum().item()) == 0
+        blk = a.cpu().numpy().view(np.uint64).reshape(2, 13)
+        assert (blk[:, 1] >> np.uint64(32) == 0).all()          # proven shard-local answers
+        assert sh.stats()["total_scan_launches"] > 0            # timings were booked when the slots were settled
+    finally:
+        sh.close()
+        other.close()
     # the device context is intact afterwards
     ix = B.Index(codes, corr, dim, B.centroid_dp(cen))
     try:

@@ -62,3 +62,27 @@ def test_js_multi_gpu_and_multibit_example():
     print(r.stdout[-2000:])
     assert r.returncode == 0, r.stdout[-4000:]
     assert "shards: 2" in r.stdout and "batch agrees: true" in r.stdout and "bytes per row on the device: 68" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_js_bench_scale_matches_ctypes(tmp_path):
+    """tests/js/bench_scale.js (what bench.py's `napi` leg runs at 10 M rows) at a small size: an index saved through ctypes is loaded by
+    a node process through the N-API addon, searched with RAW fp32 queries through the reference-named API - batch and one call per
+    query - and its answers equal the ctypes answers bit for bit"""
+    import json
+    import numpy as np
+    import bench
+    from bbqlib import bbq_amd as B
+    n, dim, k, nq = 300_000, 768, 100, 24
+    codes, corr = bench.synth_rows(1, 0, n, dim // 8)
+    cen = bench.synth_centroid(dim)
+    ix = B.Index(codes, corr, dim, float(B.centroid_dp(cen)))
+    try:
+        res = bench.napi_leg(B, ix, cen, dim, k, "COSINE", 1, 4, nq=nq)
+    finally:
+        ix.close()
+    assert "error" not in res, res
+    assert res["identical_to_ctypes"] is True and res["single_equals_batch"] is True
+    assert res["value"] > 0 and res["p50_ms"] > 0
+    json.dumps(res)
