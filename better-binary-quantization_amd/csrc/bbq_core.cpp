@@ -512,18 +512,73 @@ void fill_query_mfma(const bbq_index *ix, uint8_t *dst, int q_in_batch, const ui
 }
 
 int validate_query_args(const bbq_index *ix, int32_t nq, const uint8_t *qquant, const double *qcorr, int32_t query_bits,
-                        int32_t sim, int64_t k) {
+                        int32_t sim, int64_t k, bool values_pending = false) {
   if (!ix) return fail(BBQ_ERR_INVALID_ARG, "目标向量集合不能为空");
   if (nq < 0) return fail(BBQ_ERR_INVALID_ARG, "n_queries < 0");
   if (nq > 0 && (!qquant || !qcorr)) return fail(BBQ_ERR_INVALID_ARG, "查询向量不能为空");
   if (k < 0) return fail(BBQ_ERR_NEGATIVE_K, "k值不能为负数");
   if (query_bits < 1 || query_bits > 8) return fail(BBQ_ERR_INVALID_ARG, "queryBits必须在1-8之间");
   if (sim < 0 || sim > 2) return fail(BBQ_ERR_INVALID_ARG, "不支持的相似性函数: %d", sim);
-  if (query_bits == 1)
+  if (query_bits == 1 && !values_pending)  // (values_pending: the library's own quantizer is still producing them)
     for (int64_t i = 0; i < (int64_t)nq * ix->dim; ++i)
       if (qquant[i] > 1) return fail(BBQ_ERR_INVALID_ARG, "1位量化值必须为0或1");
   return BBQ_OK;
 }
+
+// Raw queries of bbq_search_raw_batch being quantized on host threads, chunk by chunk, while the sub-batches in front are already
+// on the device: the quantizer (~15 us per 768-d query and core) never stands in front of a sweep except for the first chunk.
+struct RawFeed {
+  const float *queries = nullptr, *centroid = nullptr;
+  int32_t n = 0, dim = 0, sim = 0, qb = 0, iters = 0, chunk = 8;  // small chunks: the first sub-batch waits for its own queries only (8 x ~15 us)
+  double lambda = 0;
+  uint8_t *qq = nullptr;
+  double *qc = nullptr;
+  std::unique_ptr<std::atomic<int>[]> ready;  // per chunk: 0 pending, 1 done, 2 failed
+  std::atomic<int> next{0};
+  std::vector<std::thread> threads;
+  int n_chunks() const { return (n + chunk - 1) / chunk; }
+  void start(int n_threads) {
+    ready.reset(new std::atomic<int>[(size_t)n_chunks()]);
+    for (int i = 0; i < n_chunks(); ++i) ready[(size_t)i].store(0);
+    const int T = std::max(1, std::min(n_threads, n_chunks()));
+    for (int t = 0; t < T; ++t)
+      threads.emplace_back([this] {
+        for (;;) {
+          const int ci = next.fetch_add(1);
+          if (ci >= n_chunks()) return;
+          int state = 1;
+          for (int i = ci * chunk; i < std::min(n, (ci + 1) * chunk); ++i)
+            if (bbq_quantize_query(queries + (size_t)i * dim, dim, centroid, sim, qb, lambda, iters, qq + (size_t)i * dim, qc + (size_t)i * 4) != BBQ_OK) {
+              state = 2;
+              break;
+            }
+          ready[(size_t)ci].store(state, std::memory_order_release);
+        }
+      });
+  }
+  // blocks until queries [first, first + count) are quantized; on a failed query returns its index through *bad
+  int wait(int64_t first, int count, int32_t *bad) {
+    for (int ci = (int)(first / chunk); ci <= (int)((first + count - 1) / chunk); ++ci) {
+      int st;
+      while ((st = ready[(size_t)ci].load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+      if (st == 2) {
+        // which query, and its message on THIS thread (the worker's is thread-local)
+        for (int i = ci * chunk; i < std::min(n, (ci + 1) * chunk); ++i) {
+          const int rc = bbq_quantize_query(queries + (size_t)i * dim, dim, centroid, sim, qb, lambda, iters, qq + (size_t)i * dim, qc + (size_t)i * 4);
+          if (rc != BBQ_OK) { if (bad) *bad = i; return rc; }
+        }
+        return fail(BBQ_ERR_INVALID_ARG, "query quantization failed");
+      }
+    }
+    return BBQ_OK;
+  }
+  void join() {
+    next.store(1 << 30);
+    for (auto &t : threads) t.join();
+    threads.clear();
+  }
+  ~RawFeed() { join(); }
+};
 
 // ------------------------------------------------------------------------------------------------ enqueue / complete
 
@@ -1309,10 +1364,13 @@ int32_t bbq_index_dimension(const bbq_index *ix) { return ix ? ix->dim : 0; }
 int32_t bbq_index_bytes_per_row(const bbq_index *ix) { return ix ? ix->bytes_per_row : 0; }
 int32_t bbq_index_bits(const bbq_index *ix) { return ix ? ix->index_bits : 0; }
 
-int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, const double *qcorr, int32_t query_bits,
-                     int32_t sim, int64_t k, int32_t *out_idx, float *out_score, int64_t *out_n) {
-  clear_error();
-  int rc = validate_query_args(ix, n_queries, qquant, qcorr, query_bits, sim, k);
+}  // extern "C"
+
+// bbq_search_batch, and - with `feed` - bbq_search_raw_batch: the quantized queries of a sub-batch are waited for right before it is
+// enqueued
+static int search_batch_impl(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, const double *qcorr, int32_t query_bits,
+                             int32_t sim, int64_t k, int32_t *out_idx, float *out_score, int64_t *out_n, RawFeed *feed, int32_t *bad_query) {
+  int rc = validate_query_args(ix, n_queries, qquant, qcorr, query_bits, sim, k, feed != nullptr);
   if (rc != BBQ_OK) return rc;
   if (n_queries > 0 && !out_n) return fail(BBQ_ERR_INVALID_ARG, "out_n is null");
   for (int32_t i = 0; i < n_queries; ++i) out_n[i] = 0;
@@ -1336,12 +1394,20 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
   ix->stats.host_replays = 0;
   if (ix->n_rows == 0) return BBQ_OK;
 
-  BatchCtx c{ix, qquant, qcorr, planes_of_call(ix, qquant, (int64_t)n_queries * ix->dim, query_bits == 1), query_bits == 1 ? 1 : 0, sim, k};
-  c.maxq = c.planes <= 4 ? 15 : max_value(qquant, (int64_t)n_queries * ix->dim);
+  BatchCtx c{ix, qquant, qcorr, 0, query_bits == 1 ? 1 : 0, sim, k};
+  if (feed) {  // the values are still being produced: the kernel variant follows from the bit width they are quantized to
+    const int pq = query_bits <= 1 ? 1 : query_bits <= 2 ? 2 : query_bits <= 4 ? 4 : 8;
+    c.planes = ix->store_bits == 1 ? pq : ix->store_bits == 8 ? 8 : (query_bits <= 4 ? 4 : 8);
+    c.maxq = (1 << query_bits) - 1;
+  } else {
+    c.planes = planes_of_call(ix, qquant, (int64_t)n_queries * ix->dim, query_bits == 1);
+    c.maxq = c.planes <= 4 ? 15 : max_value(qquant, (int64_t)n_queries * ix->dim);
+  }
   const int64_t keff = std::min<int64_t>(k, ix->n_rows);
   c.k = k;
   if (keff > kMaxFastK || ix->opt_force_dense) {
     for (int32_t i = 0; i < n_queries; ++i) {
+      if (feed && (rc = feed->wait(i, 1, bad_query)) != BBQ_OK) return rc;
       rc = dense_search_one(c, i, out_idx + (int64_t)i * k, out_score + (int64_t)i * k, out_n + i);
       if (rc != BBQ_OK) return rc;
     }
@@ -1355,7 +1421,7 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
   const int64_t final_k = (keff <= kFinalSelectMax && ix->opt_device_select) ? keff : 0;
   cs.k = final_k > 0 ? keff + 1 : keff;
   build_plan(ix, cs.k, final_k, final_k > 0 && n_queries <= ix->opt_latency_queries);
-  if (n_queries == 1 && ix->plan.latency) {
+  if (n_queries == 1 && ix->plan.latency && !feed) {
     bool done = false;
     rc = search_latency_presampled(c, cs, out_idx, out_score, out_n, &done);
     if (rc != BBQ_OK || done) return rc;
@@ -1379,6 +1445,7 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
     const int nq = (int)std::min<int64_t>(Q, n_queries - i * Q);
     rc = ensure_slot(ix, s, nq, true);
     if (rc != BBQ_OK) return fail_out(rc);
+    if (feed && (rc = feed->wait(i * Q, nq, bad_query)) != BBQ_OK) return fail_out(rc);
     rc = enqueue_subbatch(cs, s, i * Q, nq, nullptr);
     if (rc != BBQ_OK) return fail_out(rc);
     // hand finished sub-batches to the replay workers as early as possible (their slot is needed again soon)
@@ -1395,6 +1462,54 @@ int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, co
     if (rc != BBQ_OK) return fail_out(rc);
   }
   return BBQ_OK;
+}
+
+extern "C" {
+
+int bbq_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, const double *qcorr, int32_t query_bits,
+                     int32_t sim, int64_t k, int32_t *out_idx, float *out_score, int64_t *out_n) {
+  clear_error();
+  return search_batch_impl(ix, n_queries, qquant, qcorr, query_bits, sim, k, out_idx, out_score, out_n, nullptr, nullptr);
+}
+
+int bbq_search_raw_batch(bbq_index *ix, int32_t n_queries, const float *queries, const float *centroid, int32_t sim, int32_t query_bits,
+                         double lambda, int32_t iters, int32_t n_threads, int64_t k, int32_t *out_idx, float *out_score, int64_t *out_n,
+                         uint8_t *qquant_out, double *qcorr_out, int32_t *bad_query) {
+  clear_error();
+  if (bad_query) *bad_query = -1;
+  if (!ix) return fail(BBQ_ERR_INVALID_ARG, "目标向量集合不能为空");
+  if (n_queries < 0) return fail(BBQ_ERR_INVALID_ARG, "n_queries < 0");
+  if (n_queries > 0 && (!queries || !centroid)) return fail(BBQ_ERR_INVALID_ARG, "查询向量不能为空");
+  if (k < 0) return fail(BBQ_ERR_NEGATIVE_K, "k值不能为负数");
+  if (query_bits < 1 || query_bits > 8) return fail(BBQ_ERR_INVALID_ARG, "queryBits必须在1-8之间");
+  if (n_queries == 0) return BBQ_OK;
+  const int dim = ix->dim;
+  std::vector<uint8_t> own_q;
+  std::vector<double> own_c;
+  uint8_t *qq = qquant_out;
+  double *qc = qcorr_out;
+  if (!qq) { own_q.resize((size_t)n_queries * dim); qq = own_q.data(); }
+  if (!qc) { own_c.resize((size_t)n_queries * 4); qc = own_c.data(); }
+  const int T = n_threads > 0 ? n_threads : (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 2));
+  // few queries, k == 0 (the quantizer's errors still surface, as in the reference's order of checks) or a multi-device handle
+  // (its rounds take whole arrays): quantize first, then search
+  if (n_queries <= 64 || k == 0 || ix->multi) {
+    int rc = bbq_quantize_queries(queries, n_queries, dim, centroid, sim, query_bits, lambda, iters, T, qq, qc, bad_query);
+    if (rc != BBQ_OK) return rc;
+    return search_batch_impl(ix, n_queries, qq, qc, query_bits, sim, k, out_idx, out_score, out_n, nullptr, nullptr);
+  }
+  RawFeed feed;
+  feed.queries = queries; feed.centroid = centroid; feed.n = n_queries; feed.dim = dim; feed.sim = sim; feed.qb = query_bits;
+  feed.lambda = lambda; feed.iters = iters; feed.qq = qq; feed.qc = qc;
+  // the argument checks of the quantizer, once, on this thread (the workers would only report "failed")
+  {
+    int rc = bbq_quantize_query(queries, dim, centroid, sim, query_bits, lambda, iters, qq, qc);
+    if (rc != BBQ_OK) { if (bad_query) *bad_query = 0; return rc; }
+  }
+  feed.start(T);
+  int rc = search_batch_impl(ix, n_queries, qq, qc, query_bits, sim, k, out_idx, out_score, out_n, &feed, bad_query);
+  feed.join();
+  return rc;
 }
 
 int bbq_search(bbq_index *ix, const uint8_t *qquant, const double *qcorr, int32_t query_bits, int32_t sim, int64_t k,

@@ -12,10 +12,10 @@
 // Operand roles (round 3): the QUERIES are the A operand (M = 32 queries) and the index ROWS the B operand (N = 32 rows), so a
 // lane's 16 accumulators are 16 queries against ONE row (column lane%32) - its own row, or its half-wave partner's.  The row's
 // pre-filter constants therefore sit in the lane's registers, and only the per-query constants (one float4, the same for the whole
-// half-wave) come from LDS: 32 reads per tile where the rows-as-A layout needed 128 (two float4 per pair, from a per-row table).
-// The kernel is bound by the CU's LDS bandwidth (PMC: waves wait on LDS more than half of the time; a ds_read_b128 occupies the LDS
-// for 8 clocks): per 64-row tile and wave 48 query-fragment reads + 128 row-constant reads = 1408 clocks of LDS per tile and CU
-// before, 48 + 32 = 640 now - profiles/r03_mfma_*.
+// half-wave) come from LDS: 48 + 32 = 80 ds_read_b128 per tile and wave where the rows-as-A layout needed 48 + 128.
+// What binds the kernel (profiles/r03_mfma_pmc.json, DESIGN.md "Shared sweeps"): VALU issue - 1 411 vector instructions per tile
+// and wave next to 48 MFMAs, SQ_ACTIVE_INST_VALU = 86 % of the launch's SIMD time, the matrix cores 22 % busy.  The pre-filter
+// (~16 instructions per pair) and the bit -> int8 expansion (9 per MFMA) are that load.
 //
 // Per (row, query) pair a cheap, provably conservative f32 pre-filter in "z-space" (the monotone argument of the
 // similarity transform) rejects almost everything; the rare survivors go through the f64 bound and the exact f64 score of
@@ -340,8 +340,8 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
         const uint64_t ent = ((uint64_t)(uint32_t)(a.s.row_id_base + row) << 32) | bits;
         if (a.s.append_lists) {
           // append mode: straight into the query's list (unordered inside the segment; the finalize launch takes its keys from there
-          // and the rare host replay sorts).  No per-chunk staging, so the waves of a workgroup never wait for each other: the three
-          // barriers per tile of the slot mode were most of the 48 % of their time the waves spent parked (profiles/r03_mfma_pmc.md)
+          // and the rare host replay sorts).  No per-chunk staging, so the waves of a workgroup never wait for each other (the slot
+          // mode has three barriers per tile): 49.6 -> 53.6 K q/s at 10 M x 768
           const uint32_t slot = atomicAdd(a.s.append_counts + q0 + qn, 1u);
           const int64_t at = (int64_t)a.s.append_base[2 * (q0 + qn)] + slot;
           if (at < a.s.append_cap) a.s.append_lists[(size_t)(q0 + qn) * a.s.append_cap + at] = ent;

@@ -455,11 +455,11 @@ class BinaryQuantizationFormat {
       if (v.length !== dim) throw new Error('查询向量维度与目标向量维度不匹配');
       flat.set(v, i * dim);
     }
-    // searchNearestNeighbors normalises for COSINE and quantizeQueryVector normalises again (:337-347, :279-281); a batch is
-    // quantized on host threads (one 768-d query costs ~50 us on one core, more than its sweep of 1 M rows on the device)
-    const qz = native.quantizeQueries(flat, nq, targetVectors.getCentroid(), sim, this.config.queryBits, q.lambda, q.iters, Number(process.env.BBQ_THREADS || 0));
-    const qq = qz.quantized, qc = qz.corrections;
-    const r = native.searchBatch(targetVectors._deviceIndex(), nq, qq, qc, this.config.queryBits, sim, k);
+    // searchNearestNeighbors normalises for COSINE and quantizeQueryVector normalises again (:337-347, :279-281); both happen behind
+    // bbq_search_raw_batch, on host threads, chunk by chunk while the sub-batches in front are already on the device (one 768-d query
+    // costs ~15 us on one core, more than its sweep of 1 M rows on the device)
+    const r = native.searchRawBatch(targetVectors._deviceIndex(), nq, flat, targetVectors.getCentroid(), sim, this.config.queryBits, q.lambda, q.iters,
+      Number(process.env.BBQ_THREADS || 0), k);
     const out = [];
     for (let i = 0; i < nq; i++) {
       const res = [], n = r.counts[i], base = i * r.stride;

@@ -272,6 +272,41 @@ static napi_value SearchBatch(napi_env env, napi_callback_info info) {
   return o;
 }
 
+/* searchRawBatch(handle, nq, flat Float32Array[nq*dim] raw queries, centroid Float32Array[dim], sim, queryBits, lambda, iters, threads, k)
+ *   -> {indices, scores, counts, stride}   (bbq_search_raw_batch: quantization on host threads pipelined with the sweeps) */
+static napi_value SearchRawBatch(napi_env env, napi_callback_info info) {
+  napi_value a[10];
+  if (!get_args(env, info, 10, a)) return NULL;
+  bbq_index *ix = unbox(env, a[0]);
+  if (!ix) return NULL;
+  void *q, *cen; size_t ql, cl;
+  int64_t nq, sim, qb, iters, threads, k; double lambda;
+  if (!get_i64(env, a[1], &nq) || !get_typed(env, a[2], napi_float32_array, &q, &ql) || !get_typed(env, a[3], napi_float32_array, &cen, &cl) ||
+      !get_i64(env, a[4], &sim) || !get_i64(env, a[5], &qb) || !get_f64(env, a[6], &lambda) || !get_i64(env, a[7], &iters) ||
+      !get_i64(env, a[8], &threads) || !get_i64(env, a[9], &k)) return NULL;
+  if (nq < 0 || cl != (size_t)bbq_index_dimension(ix) || ql != (size_t)nq * cl) {
+    napi_throw_error(env, "BBQ6", "查询向量维度与目标向量维度不匹配"); return NULL;
+  }
+  if (k < 0) { napi_throw_error(env, "BBQ7", "k值不能为负数"); return NULL; }
+  int64_t keff = k < bbq_index_size(ix) ? k : bbq_index_size(ix);
+  void *oi, *os, *on;
+  napi_value ti = new_typed(env, napi_int32_array, (size_t)(nq * keff), 4, &oi);
+  napi_value ts = new_typed(env, napi_float32_array, (size_t)(nq * keff), 4, &os);
+  napi_value tn = new_typed(env, napi_float64_array, (size_t)nq, 8, &on);
+  if (!ti || !ts || !tn) { napi_throw_error(env, NULL, "bbq_napi: allocation failed"); return NULL; }
+  int64_t *cnt = (int64_t *)calloc((size_t)nq + 1, sizeof(int64_t));
+  int rc = bbq_search_raw_batch(ix, (int32_t)nq, (const float *)q, (const float *)cen, (int32_t)sim, (int32_t)qb, lambda, (int32_t)iters,
+                                (int32_t)threads, keff, (int32_t *)oi, (float *)os, cnt, NULL, NULL, NULL);
+  if (rc != BBQ_OK) { free(cnt); return throw_bbq(env, rc); }
+  for (int64_t i = 0; i < nq; ++i) ((double *)on)[i] = (double)cnt[i];
+  free(cnt);
+  napi_value o;
+  NAPI_CALL(env, napi_create_object(env, &o));
+  set_prop(env, o, "indices", ti); set_prop(env, o, "scores", ts); set_prop(env, o, "counts", tn);
+  napi_value kv; napi_create_double(env, (double)keff, &kv); set_prop(env, o, "stride", kv);
+  return o;
+}
+
 /* scoreRows(handle, qquant, qcorr, queryBits, sim, rowBegin, rowCount) -> {qcDist Int32Array, score64 Float64Array, score32 Float32Array} */
 static napi_value ScoreRows(napi_env env, napi_callback_info info) {
   napi_value a[7];
@@ -557,6 +592,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"indexBuild", NULL, IndexBuild, NULL, NULL, NULL, napi_default, NULL},
       {"indexDestroy", NULL, IndexDestroy, NULL, NULL, NULL, napi_default, NULL},
       {"searchBatch", NULL, SearchBatch, NULL, NULL, NULL, napi_default, NULL},
+      {"searchRawBatch", NULL, SearchRawBatch, NULL, NULL, NULL, napi_default, NULL},
       {"scoreRows", NULL, ScoreRows, NULL, NULL, NULL, napi_default, NULL},
       {"setOption", NULL, SetOption, NULL, NULL, NULL, napi_default, NULL},
       {"stats", NULL, Stats, NULL, NULL, NULL, napi_default, NULL},

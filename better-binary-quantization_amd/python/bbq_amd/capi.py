@@ -25,6 +25,7 @@ SYMBOLS = [
     "bbq_index_load", "bbq_index_export", "bbq_quantize_queries",
     "bbq_index_create_shard_opts", "bbq_index_create_multi_opts", "bbq_index_build_opts",
     "bbq_shard_scan_begin", "bbq_shard_scan_wait", "bbq_merge_answers", "bbq_key_of_score", "bbq_index_load_multi", "bbq_index_file_shards",
+    "bbq_search_raw_batch",
 ]
 
 
@@ -95,6 +96,7 @@ def lib():
     L.bbq_index_bits.restype = i32
     L.bbq_search.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp, vp]
     L.bbq_search_batch.argtypes = [vp, i32, vp, vp, i32, i32, i64, vp, vp, vp]
+    L.bbq_search_raw_batch.argtypes = [vp, i32, vp, vp, i32, i32, dbl, i32, i32, i64, vp, vp, vp, vp, vp, C.POINTER(i32)]
     L.bbq_score_rows.argtypes = [vp, vp, vp, i32, i32, i64, i64, vp, vp, vp]
     L.bbq_shard_scan.argtypes = [vp, i32, vp, vp, i32, i32, i64, vp, i64, vp, vp, C.POINTER(i64)]
     L.bbq_shard_scan_begin.argtypes = [vp, i32, vp, vp, i32, i32, i64, vp, i64, vp, vp, vp, i64]
@@ -335,6 +337,25 @@ class Index:
         cnt = np.zeros(nq, np.int64)
         _chk(lib().bbq_search_batch(self._h, nq, _ptr(qq), _ptr(qc), query_bits, sim, k, _ptr(idx), _ptr(sc), _ptr(cnt)))
         return idx, sc, cnt
+
+    def search_raw_batch(self, queries, centroid, sim, query_bits, k, lam=0.1, iters=5, n_threads=0, want_quantized=False):
+        """searchNearestNeighbors from raw fp32 queries [nq, dim]: quantization on host threads pipelined with the sweeps
+        (bbq_search_raw_batch).  Returns (idx, score, count[, qquant, qcorr])."""
+        q = np.ascontiguousarray(queries, np.float32)
+        cen = np.ascontiguousarray(centroid, np.float32)
+        if q.ndim != 2 or q.shape[1] != self.dim or cen.shape != (self.dim,):
+            raise BBQError(ERR_DIM_MISMATCH, "查询向量维度与目标向量维度不匹配")
+        nq = q.shape[0]
+        kk = max(int(k), 0)
+        idx = np.zeros((nq, kk), np.int32)
+        sc = np.zeros((nq, kk), np.float32)
+        cnt = np.zeros(nq, np.int64)
+        qq = np.zeros((nq, self.dim), np.uint8) if want_quantized else None
+        qc = np.zeros((nq, 4), np.float64) if want_quantized else None
+        bad = C.c_int32(-1)
+        _chk(lib().bbq_search_raw_batch(self._h, nq, _ptr(q), _ptr(cen), sim, query_bits, lam, iters, n_threads, k, _ptr(idx), _ptr(sc), _ptr(cnt),
+                                       _ptr(qq), _ptr(qc), C.byref(bad)))
+        return (idx, sc, cnt, qq, qc) if want_quantized else (idx, sc, cnt)
 
     def score_rows(self, qquant, qcorr, query_bits, sim, row_begin=0, row_count=None):
         qq = np.ascontiguousarray(qquant, np.uint8)

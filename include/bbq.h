@@ -193,6 +193,18 @@ int bbq_search_batch(bbq_index *idx, int32_t n_queries, const uint8_t *qquant, c
                      int32_t query_bits, int32_t sim, int64_t k, int32_t *out_idx, float *out_score,
                      int64_t *out_n);
 
+/* searchNearestNeighbors from the RAW query (src/binaryQuantizationFormat.ts:337-411) for n_queries queries: normalisation (COSINE) +
+ * quantizeQueryVector exactly as bbq_quantize_query does them, then bbq_search_batch - but pipelined: the queries are quantized on
+ * n_threads host threads (0: half the cores, at most 16) chunk by chunk while the sub-batches in front are already on the device, so
+ * the quantizer (~15 us per 768-d query and core) only stands in front of the first sweep.  Results are bit-identical to
+ * bbq_quantize_queries followed by bbq_search_batch.
+ *   queries [n_queries*dim] raw fp32, centroid [dim] (getCentroid()), lambda / iters: the quantizer's (0.1 / 5 by default in the reference)
+ *   qquant_out [n_queries*dim], qcorr_out [n_queries*4]: optional, the quantized queries (what quantizeQueryVector returns)
+ *   *bad_query (may be NULL): the first query the quantizer refused (NaN / Infinity input, ...), with its error as the return value */
+int bbq_search_raw_batch(bbq_index *idx, int32_t n_queries, const float *queries, const float *centroid, int32_t sim,
+                         int32_t query_bits, double lambda, int32_t iters, int32_t n_threads, int64_t k, int32_t *out_idx,
+                         float *out_score, int64_t *out_n, uint8_t *qquant_out, double *qcorr_out, int32_t *bad_query);
+
 /* Per-row results of computeBatchQuantizedScores (src/binaryQuantizedScorer.ts:389-400) for the
  * contiguous ords [row_begin, row_begin+row_count): bitDotProduct (integer qcDist), the f64 score and
  * its f32 rounding (src/binaryQuantizationFormat.ts:353,378).  Any output pointer may be NULL. */

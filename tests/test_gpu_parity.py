@@ -1355,3 +1355,46 @@ def test_latency_fused_path_equals_general_path(dim, qb, sim, compact, n):
         oi, _ = O.heap_topk(s32, 50)
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("sim,qb,nq", [(1, 4, 200), (0, 4, 70), (2, 1, 130), (1, 8, 65), (1, 4, 5)])
+def test_search_raw_batch_equals_quantize_then_search(sim, qb, nq):
+    """bbq_search_raw_batch (quantization on host threads pipelined with the sweeps) == bbq_quantize_queries + bbq_search_batch, bit for
+    bit, quantized queries included; a query the quantizer refuses is reported with its index; k = 0 and the multi-device handle work"""
+    rng = np.random.default_rng(sim * 100 + qb)
+    n, dim, k = 40_000, 96, 30
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    ix, codes, corr, cen = B.Index.build(base, sim)
+    try:
+        ix.set_option("batch_queries", 32)        # several sub-batches: the later ones are enqueued while their queries are still being quantized
+        qq, qc = B.quantize_queries(queries, cen, sim, qb)
+        want = ix.search_batch(qq, qc, qb, sim, k)
+        for threads in (1, 7):
+            idx, sc, cnt, rq, rc = ix.search_raw_batch(queries, cen, sim, qb, k, n_threads=threads, want_quantized=True)
+            np.testing.assert_array_equal(rq, qq)
+            np.testing.assert_array_equal(rc.view(np.uint64), qc.view(np.uint64))
+            np.testing.assert_array_equal(idx, want[0])
+            np.testing.assert_array_equal(sc.view(np.uint32), want[1].view(np.uint32))
+            np.testing.assert_array_equal(cnt, want[2])
+        _, _, s32 = O.score_all(codes, corr, dim, qq[0], qc[0], qb, sim, B.centroid_dp(cen))
+        np.testing.assert_array_equal(want[0][0], O.heap_topk(s32, k)[0])
+        idx0, _, cnt0 = ix.search_raw_batch(queries, cen, sim, qb, 0)
+        assert idx0.shape == (nq, 0) and (cnt0 == 0).all()
+        bad = queries.copy()
+        bad[nq - 2, 5] = np.nan
+        with pytest.raises(B.BBQError) as e:
+            ix.search_raw_batch(bad, cen, sim, qb, k, n_threads=3)
+        assert e.value.code == B.capi.ERR_NAN_INPUT
+        # the index is usable afterwards
+        idx, sc, cnt = ix.search_raw_batch(queries, cen, sim, qb, k)
+        np.testing.assert_array_equal(idx, want[0])
+    finally:
+        ix.close()
+    mx = B.Index.create_multi(codes, corr, dim, B.centroid_dp(cen), [0, 0], pilot_rows=1024)
+    try:
+        idx, sc, cnt = mx.search_raw_batch(queries, cen, sim, qb, k)
+        np.testing.assert_array_equal(idx, want[0])
+        np.testing.assert_array_equal(sc.view(np.uint32), want[1].view(np.uint32))
+    finally:
+        mx.close()
