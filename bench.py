@@ -613,8 +613,8 @@ def main():
         sharded = {"max_over_ranks_ms_per_batch": {k_: round(float(v), 3) for k_, v in zip(keys, tt.tolist())}, "rank0": mine,
                    "what": "scan = sweep of a batch, enqueue to device-done (overlaps the previous batch's exchange + merge); exchange = all_to_all of the "
                            "shard-local answers ((k + 3) x 8 B per shard and query); merge = bbq_merge_answers of the owner's block; answers = "
-                           "need-lists all_reduce + gather to rank 0; lists = the ABI-2 list exchange + heap replay, only for batches with equal "
-                           "scores in an answer"}
+                           "all_gather of the owners' per-query status + gather to rank 0; lists = the candidate lists of the queries with equal "
+                           "scores in their answer (those queries only) to rank 0 + their heap replay"}
         # per-rank roofline fraction of the dominant launch (HIP events on its own stream)
         lb = st["total_scan_bytes"] / max(st["total_scan_launches"], 1)
         lm = st["total_scan_ms"] / max(st["total_scan_launches"], 1)

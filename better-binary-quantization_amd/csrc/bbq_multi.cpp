@@ -89,6 +89,7 @@ struct ShardBuf {  // one round's output of one shard: answers + packed lists on
   int32_t q_cap = 0;
   int64_t total = 0;
   bool lists_on_host = false;
+  std::vector<int64_t> h_list_at;   // per query of the round: offset of its fetched list inside h_packed, -1 if it was not fetched
   int rc = BBQ_OK;
   std::string err;
 };
@@ -175,19 +176,37 @@ int shard_finish(MultiShard &sh, ShardBuf &b) {
   return BBQ_OK;
 }
 
-// the round's packed lists to host memory (only when some query of the round needs its heap replayed)
-int shard_fetch_lists(MultiShard &sh, ShardBuf &b, int32_t nq) {
+// the packed lists of the queries that need their heap replayed (status != 0), to host memory: the offsets first, then one small
+// copy per such query - a round's whole packed buffer is ~9 KB per query, and nearly every round of a few hundred queries holds one
+// with equal scores in its answer
+int shard_fetch_lists(MultiShard &sh, ShardBuf &b, int32_t nq, const std::vector<uint8_t> &status, bool all) {
   HIPCHK(hipSetDevice(sh.device));
-  if (b.h_packed_cap < std::max<int64_t>(b.total, 1)) {
+  // the round's packing has completed (bbq_shard_scan_wait).  The null stream: the shard's own streams are non-blocking, and its
+  // auxiliary stream may already hold the NEXT round's packing, which waits for that round's sweeps
+  hipStream_t st = nullptr;
+  HIPCHK(hipMemcpyAsync(b.h_offsets, b.d_offsets, (size_t)(nq + 1) * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(b.h_flags, b.d_flags, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  int64_t need = 0;
+  for (int32_t q = 0; q < nq; ++q)
+    if (all || status[(size_t)q] != 0) need += b.h_offsets[q + 1] - b.h_offsets[q];
+  if (b.h_packed_cap < std::max<int64_t>(need, 1)) {
     if (b.h_packed) HIPCHK(hipHostFree(b.h_packed));
     b.h_packed = nullptr;
-    b.h_packed_cap = std::max<int64_t>(b.total, 1024) * 5 / 4;
+    b.h_packed_cap = std::max<int64_t>(need, 1024) * 5 / 4;
     HIPCHK(hipHostMalloc((void **)&b.h_packed, (size_t)b.h_packed_cap * 8, hipHostMallocDefault));
   }
-  // a stream of its own would be one more object per shard: the null stream serves this rare path (the shard's other streams are non-blocking)
-  HIPCHK(hipMemcpy(b.h_offsets, b.d_offsets, (size_t)(nq + 1) * 8, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(b.h_flags, b.d_flags, (size_t)nq * 4, hipMemcpyDeviceToHost));
-  if (b.total > 0) HIPCHK(hipMemcpy(b.h_packed, b.d_packed, (size_t)b.total * 8, hipMemcpyDeviceToHost));
+  // h_list_at[q] = where query q's entries sit in h_packed (-1: not fetched)
+  b.h_list_at.assign((size_t)nq, -1);
+  int64_t at = 0;
+  for (int32_t q = 0; q < nq; ++q) {
+    if (!(all || status[(size_t)q] != 0)) continue;
+    const int64_t cnt = b.h_offsets[q + 1] - b.h_offsets[q];
+    b.h_list_at[(size_t)q] = at;
+    if (cnt > 0) HIPCHK(hipMemcpyAsync(b.h_packed + at, b.d_packed + b.h_offsets[q], (size_t)cnt * 8, hipMemcpyDeviceToHost, st));
+    at += cnt;
+  }
+  HIPCHK(hipStreamSynchronize(st));
   b.lists_on_host = true;
   return BBQ_OK;
 }
@@ -284,7 +303,7 @@ int multi_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, 
     ms->done_cv.wait(dl, [&] { return ms->done_count[(size_t)r] == S; });
   };
   // the lists of round r on the host (rare): every worker copies its shard's, the caller waits for all of them
-  auto fetch_lists = [&](int64_t r, int32_t nq) -> int {
+  auto fetch_lists = [&](int64_t r, int32_t nq, const std::vector<uint8_t> *need) -> int {
     {
       std::lock_guard<std::mutex> dl(ms->done_mu);
       ms->fetch_count = 0;
@@ -292,9 +311,9 @@ int multi_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, 
     for (int s = 0; s < S; ++s) {
       MultiShard *sh = &ms->shards[(size_t)s];
       ShardBuf *b = &sh->buf[r & 1];
-      sh->worker->post([ms, sh, b, nq] {
+      sh->worker->post([ms, sh, b, nq, need, answers] {
         if (!b->lists_on_host) {
-          b->rc = shard_fetch_lists(*sh, *b, nq);
+          b->rc = shard_fetch_lists(*sh, *b, nq, *need, !answers);
           if (b->rc != BBQ_OK) b->err = bbq_last_error();
         }
         {
@@ -344,7 +363,7 @@ int multi_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, 
       bool need_lists = false;
       for (int32_t q = 0; q < nq; ++q) need_lists = need_lists || status[(size_t)q] != 0;
       if (rc_all == BBQ_OK && need_lists) {
-        rc_all = fetch_lists(r, nq);
+        rc_all = fetch_lists(r, nq, &status);
         if (rc_all != BBQ_OK) err_all = bbq_last_error();
       }
       for (int32_t q = 0; q < nq && rc_all == BBQ_OK; ++q) {
@@ -357,7 +376,7 @@ int multi_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, 
         int64_t cand = 0;
         for (int s = 0; s < S; ++s) {
           const ShardBuf &b = ms->shards[(size_t)s].buf[r & 1];
-          lists[(size_t)s] = b.h_packed + b.h_offsets[q];
+          lists[(size_t)s] = b.h_packed + std::max<int64_t>(b.h_list_at[(size_t)q], 0);
           counts[(size_t)s] = b.h_offsets[q + 1] - b.h_offsets[q];
           cand += counts[(size_t)s];
         }

@@ -6,17 +6,19 @@ Per batch of Q queries every rank sweeps its shard and leaves, in device memory,
 above its cut, at most k entries, k + 3 words (include/bbq.h) - and (b) its candidate lists, packed and ordered by query.  The MERGE is
 sharded too: rank r owns the queries of block r (Qb = ceil(Q / world) consecutive queries).
 
-  fast path (every batch):
+  every batch:
     1. all_to_all_single, EQUAL splits: the answer blocks of owner block d go to rank d - [Qb, k + 3] words per pair of ranks, fixed
        size, so there is no header round and no host sync before the payload
     2. each owner merges its Qb queries on the host (bbq_merge_answers: a world-way merge of sorted k-entry lists plus the proof that
        the reference heap returns exactly that order)
-    3. all_reduce(MAX) of one word: did any owner meet a query it could not prove (equal scores in or at the edge of the answer, a
-       shard that flagged the query)?
+    3. all_gather of the owners' per-query status (W x Qb bytes): which queries could not be proven (equal scores in or at the edge of
+       the answer: about 1 % of the queries at 1 M rows, so nearly every batch of a few hundred has one) or were flagged by a shard
     4. gather to rank 0: [Qb, 2k+1] int32 per rank (indices | f32 score bits | count)
-  list path (only for a batch where step 3 says so; what every batch did before ABI 3):
-    headers by all_to_all (equal splits) -> packed entries of block d to rank d by all_to_all (uneven splits) -> heap replay per
-    owner (bbq_replay_batch) -> gather; queries a shard flagged are scored densely by every rank and replayed on rank 0.
+  only for the queries step 3 names (not for their batch):
+    their packed lists go from every shard to rank 0 (an all_gather of the counts, one uneven all_to_all), rank 0 replays the reference
+    heap over them in shard order (bbq_replay); queries a shard flagged are scored densely by every rank and replayed on rank 0.
+  k > 1024 (no shard-local answers): the whole batch takes the list exchange of ABI 2 (headers + uneven payload all_to_all, heap
+  replay per owner).
 
 A scanner thread enqueues batch i+1's sweep (bbq_shard_scan_begin returns at once) while batch i is still running on the device, so the
 device never drains between batches; the main thread waits for batch i, exchanges and merges it.
@@ -72,7 +74,6 @@ class ShardedSearcher:
         self._h_ans = torch.zeros(self.world * self.Qb * self.stride, dtype=torch.int64, pin_memory=self._pin) if self.answers else None
         self.res_out = torch.zeros(self.Qb * (2 * self.k + 1), dtype=torch.int32, device=self.cdev)
         self.res_in = [torch.zeros(self.Qb * (2 * self.k + 1), dtype=torch.int32, device=self.cdev) for _ in range(self.world)] if self.rank == 0 else None
-        self._need = torch.zeros(1, dtype=torch.int32, device=self.cdev)
         self._recv = None        # grow-only landing buffer of the packed entries of my block (collective device)
         self._h_recv = None      # its pinned host twin
         self._in_flight = threading.Semaphore(2)   # libbbq keeps at most two batches of one index in flight
@@ -163,31 +164,70 @@ class ShardedSearcher:
         ph["to_host"] += t2 - t1
         # ---- 2. merge of my block
         res = np.zeros((Qb, 2 * k + 1), np.int32)
-        need = 0
+        status = np.zeros(0, np.uint8)
         if nqb > 0:
             blocks = self._h_ans.numpy().view(np.uint64).reshape(W, Qb, self.stride)
             idx, sc, cnt, status = capi.merge_answers([blocks[s] for s in range(W)], nqb, self.n_total, k, self.threads)
-            need = int(status.max())
             res[:nqb, :k] = idx
             res[:nqb, k:2 * k] = sc.view(np.int32)
             res[:nqb, 2 * k] = cnt
         t3 = clock()
         ph["merge"] += t3 - t2
-        # ---- 3. does any owner need the lists?
-        self._need.fill_(need)
-        dist.all_reduce(self._need, op=dist.ReduceOp.MAX)
-        any_need = int(self._need.item())
-        self.last_exchange = {"answer_words_per_pair": int(Qb * self.stride), "block_queries": int(nqb), "list_path": bool(any_need)}
-        if any_need:
+        # ---- 3. which queries could their owner not prove?  Every owner's status of its block, to everybody (W x Qb bytes)
+        st_local = t.zeros(Qb, dtype=t.uint8)
+        if nqb > 0:
+            st_local[:nqb] = t.from_numpy(status)
+        st_all = t.empty(W * Qb, dtype=t.uint8, device=self.cdev)
+        dist.all_gather_into_tensor(st_all, st_local.to(self.cdev))
+        st = st_all.cpu().numpy()[:nq]                               # the one host sync of the fast path
+        need = np.nonzero(st == 1)[0]                                  # equal scores in or at the edge of the answer: replay the lists
+        dense = np.nonzero(st == 2)[0]                                 # a shard flagged the query: dense path
+        self.last_exchange = {"answer_words_per_pair": int(Qb * self.stride), "block_queries": int(nqb), "replayed_queries": int(len(need)),
+                              "dense_queries": int(len(dense))}
+        # ---- 4. the answers of every block to rank 0
+        out = self._gather_answers(res, nq)
+        ph["answers"] += clock() - t3
+        if len(need):   # rare: only THOSE queries' lists travel, to rank 0, which replays the reference heap over them
             t4 = clock()
-            out = self._merge_lists(buf, nq, total, qq, qc)   # the whole batch the ABI-2 way: rare (equal scores / flagged queries)
+            self._replay_on_root(buf, need, out)
             ph["lists"] += clock() - t4
             self.list_batches += 1
-        else:
-            out = self._gather_answers(res, nq)
-            ph["answers"] += clock() - t3
+        if len(dense):
+            self._merge_dense(dense.tolist(), qq, qc, out)
         ph["batches"] += 1
         return out
+
+    def _replay_on_root(self, buf, need, res):
+        """the candidate lists of the queries in `need` (global indices into the batch, the same on every rank) from every shard to
+        rank 0, which replays the reference heap over them in shard order and overwrites those rows of `res`"""
+        t, dist, W, k = self.torch, self.dist, self.world, self.k
+        n_need = len(need)
+        idx_t = t.as_tensor(need, dtype=t.int64, device=buf["offsets"].device)
+        se = t.stack([buf["offsets"][idx_t], buf["offsets"][idx_t + 1]]).cpu().numpy()      # my slices of the packed buffer
+        counts = (se[1] - se[0]).astype(np.int64)
+        cnt_all = t.empty(W * n_need, dtype=t.int64, device=self.cdev)
+        dist.all_gather_into_tensor(cnt_all, t.from_numpy(counts).to(self.cdev))
+        cnt_all = cnt_all.cpu().numpy().reshape(W, n_need)
+        parts = [buf["packed"][int(a):int(b)] for a, b in zip(se[0], se[1]) if b > a]
+        send = (t.cat(parts) if parts else buf["packed"][:0]).to(self.cdev)
+        in_splits = [int(cnt_all[r].sum()) for r in range(W)] if self.rank == 0 else [0] * W
+        out_splits = [int(counts.sum())] + [0] * (W - 1)
+        n_in = int(sum(in_splits))
+        recv = self._grow(n_in)[:n_in]
+        dist.all_to_all_single(recv, send, output_split_sizes=in_splits, input_split_sizes=out_splits)
+        if self.rank != 0:
+            return
+        self._h_recv[:n_in].copy_(recv, non_blocking=True)
+        if recv.is_cuda:
+            t.cuda.current_stream().synchronize()
+        hp = self._h_recv[:n_in].numpy().view(np.uint64)
+        idx, sc, cnt = res
+        base = np.concatenate([[0], np.cumsum(in_splits)])
+        within = np.concatenate([np.zeros((W, 1), np.int64), np.cumsum(cnt_all, axis=1)], axis=1)
+        for j, q in enumerate(need.tolist()):
+            lists = [hp[base[r] + within[r, j]: base[r] + within[r, j + 1]] for r in range(W)]
+            i1, s1 = capi.replay(lists, self.n_total, k)
+            idx[q, :len(i1)], sc[q, :len(i1)], cnt[q] = i1, s1, len(i1)
 
     def _merge_lists(self, buf, nq, total, qq, qc):
         """headers -> packed entries of my block from every shard -> heap replay of my block -> gather; dense path for flagged queries"""

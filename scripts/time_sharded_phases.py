@@ -1,5 +1,7 @@
-"""where does a sharded batch spend its time (one rank, RCCL process group of size 1)?  scan = bbq_shard_scan on the scanner
-thread, merge = all_gathers + D2H + replay on the main thread."""
+"""where does a sharded batch spend its time (one rank, RCCL process group of size 1)?  The searcher's own phase clock: scan =
+bbq_shard_scan_begin -> device done (overlaps the previous batch's exchange + merge), exchange / to_host / merge / answers = the
+shard-local answers' way to rank 0, lists = the list path (only batches with equal scores in an answer):
+  python scripts/time_sharded_phases.py [rows] [queries per batch]"""
 import os
 import sys
 import time
@@ -28,37 +30,18 @@ codes, corr = bench.synth_rows(1, 0, n, dim // 8)
 ix = B.Index(codes, corr, dim, 0.01)
 ix.set_option("pipeline_slots", 3)
 S = ShardedSearcher(ix, n, k, Q, replay_threads=16, device="cuda:0")
-T = {"scan": [], "merge": []}
-scan0, merge0 = S._scan, S._merge
-
-
-def scan(*a):
-    t = time.perf_counter()
-    r = scan0(*a)
-    T["scan"].append(time.perf_counter() - t)
-    return r
-
-
-def merge(*a):
-    t = time.perf_counter()
-    r = merge0(*a)
-    T["merge"].append(time.perf_counter() - t)
-    return r
-
-
-S._scan, S._merge = scan, merge
 batches = [bench.synth_queries(10 + i, Q, dim, 4) for i in range(6)]
 S.search_stream(batches[:2])
-T["scan"].clear()
-T["merge"].clear()
+S.phases_ms()   # forget the warm-up
 t0 = time.perf_counter()
-S.search_stream(batches)
+res = S.search_stream(batches)
 dt = time.perf_counter() - t0
+phases = S.phases_ms()
 ix.reset_stats()
 t1 = time.perf_counter()
-for qq, qc in batches:
-    ix.search_batch(qq, qc, 4, 1, k)
+direct = [ix.search_batch(qq, qc, 4, 1, k) for qq, qc in batches]
 dd = time.perf_counter() - t1
-print({"queries_per_batch": Q, "sharded_ms_per_batch": round(dt / 6 * 1e3, 2), "scan_ms": round(np.mean(T["scan"]) * 1e3, 2),
-       "merge_ms": round(np.mean(T["merge"]) * 1e3, 2), "direct_ms_per_batch": round(dd / 6 * 1e3, 2)})
+same = all((a[0] == b[0]).all() and (a[1].view(np.uint32) == b[1].view(np.uint32)).all() for a, b in zip(res, direct))
+print({"queries_per_batch": Q, "sharded_ms_per_batch": round(dt / 6 * 1e3, 2), "direct_ms_per_batch": round(dd / 6 * 1e3, 2),
+       "identical_to_direct": bool(same), "phases_ms_per_batch": phases})
 dist.destroy_process_group()
