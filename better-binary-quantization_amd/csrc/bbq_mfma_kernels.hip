@@ -13,8 +13,8 @@
 // lane's 16 accumulators are 16 queries against ONE row (column lane%32) - its own row, or its half-wave partner's.  The row's
 // pre-filter constants therefore sit in the lane's registers, and only the per-query constants (one float4, the same for the whole
 // half-wave) come from LDS: 48 + 32 = 80 ds_read_b128 per tile and wave where the rows-as-A layout needed 48 + 128.
-// What binds the kernel (profiles/r03_mfma_pmc.json, DESIGN.md "Shared sweeps"): VALU issue - 1 411 vector instructions per tile
-// and wave next to 48 MFMAs, SQ_ACTIVE_INST_VALU = 86 % of the launch's SIMD time, the matrix cores 22 % busy.  The pre-filter
+// What binds the kernel (profiles/r03_mfma_pmc.json, DESIGN.md "Shared sweeps"): VALU issue - 1 349 vector instructions per tile
+// and wave next to 48 MFMAs, SQ_ACTIVE_INST_VALU = 88 % of the launch's SIMD time, the matrix cores 24 % busy.  The pre-filter
 // (~16 instructions per pair) and the bit -> int8 expansion (9 per MFMA) are that load.
 //
 // Per (row, query) pair a cheap, provably conservative f32 pre-filter in "z-space" (the monotone argument of the
