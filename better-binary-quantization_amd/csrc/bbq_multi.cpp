@@ -110,7 +110,6 @@ struct MultiState {
   std::mutex done_mu;
   std::condition_variable done_cv;
   std::vector<int> done_count;  // per round: shards finished
-  int fetch_count = 0;          // shards that have landed their lists for the round being merged
 };
 
 }  // namespace bbq
@@ -302,32 +301,16 @@ int multi_search_batch(bbq_index *ix, int32_t n_queries, const uint8_t *qquant, 
     std::unique_lock<std::mutex> dl(ms->done_mu);
     ms->done_cv.wait(dl, [&] { return ms->done_count[(size_t)r] == S; });
   };
-  // the lists of round r on the host (rare): every worker copies its shard's, the caller waits for all of them
+  // the lists of round r's unproven queries to the host, on THIS thread: the shards' workers are FIFOs that already hold finish(r + 1),
+  // which blocks until round r + 1 has been swept - a fetch posted behind it would stall this round's merge (and with it begin(r + 2))
+  // for a whole round.  Null-stream copies out of buffers nothing writes before begin(r + 2).
   auto fetch_lists = [&](int64_t r, int32_t nq, const std::vector<uint8_t> *need) -> int {
-    {
-      std::lock_guard<std::mutex> dl(ms->done_mu);
-      ms->fetch_count = 0;
-    }
     for (int s = 0; s < S; ++s) {
-      MultiShard *sh = &ms->shards[(size_t)s];
-      ShardBuf *b = &sh->buf[r & 1];
-      sh->worker->post([ms, sh, b, nq, need, answers] {
-        if (!b->lists_on_host) {
-          b->rc = shard_fetch_lists(*sh, *b, nq, *need, !answers);
-          if (b->rc != BBQ_OK) b->err = bbq_last_error();
-        }
-        {
-          std::lock_guard<std::mutex> dl(ms->done_mu);
-          ms->fetch_count += 1;
-        }
-        ms->done_cv.notify_all();
-      });
-    }
-    std::unique_lock<std::mutex> dl(ms->done_mu);
-    ms->done_cv.wait(dl, [&] { return ms->fetch_count == S; });
-    for (int s = 0; s < S; ++s) {
-      ShardBuf &b = ms->shards[(size_t)s].buf[r & 1];
-      if (b.rc != BBQ_OK) return fail(b.rc, "%s", b.err.c_str());
+      MultiShard &sh = ms->shards[(size_t)s];
+      ShardBuf &b = sh.buf[r & 1];
+      if (b.lists_on_host) continue;
+      int rc = shard_fetch_lists(sh, b, nq, *need, !answers);
+      if (rc != BBQ_OK) return rc;
     }
     return BBQ_OK;
   };
