@@ -264,7 +264,7 @@ def config_leg(B, torch, name, N, dim, k, QB, IB, sim_name, device, steps, warmu
     return out
 
 
-def napi_leg(B, ix, centroid, dim, k, sim_name, SIM, QB, nq=256):
+def napi_leg(B, ix, centroid, dim, k, sim_name, SIM, QB, nq=512):
     """the drop-in boundary at scale: the timed index is saved, a node process loads it through bbq_napi.node and runs the reference's
     call shapes with RAW fp32 queries (tests/js/bench_scale.js); its answers must equal this process's ctypes answers bit for bit"""
     import shutil
@@ -284,7 +284,7 @@ def napi_leg(B, ix, centroid, dim, k, sim_name, SIM, QB, nq=256):
         qq, qc = B.quantize_queries(raw, centroid, SIM, QB)
         gi, gs, gc = ix.search_batch(qq, qc, QB, SIM, k)
         r = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "bench_scale.js"), prefix, os.path.join(tmp, "queries.f32"), str(dim), str(k),
-                            sim_name, os.path.join(tmp, "answers.bin"), "3", "200"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+                            sim_name, os.path.join(tmp, "answers.bin"), "10", "200"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         if r.returncode != 0:
             return {"error": ("node exited with %d: " % r.returncode) + r.stderr[-300:]}
         js = json.loads(r.stdout.strip().splitlines()[-1])

@@ -176,7 +176,7 @@ struct bbq_index {
   } shard_set[2];
   int64_t shard_begun = 0, shard_waited = 0;  // batches begun / waited for: ticket t uses set t & 1
   // options
-  int opt_batch = 0 /* 0: by index size, effective_batch() */, opt_slots = 2, opt_growth = 8, opt_force_dense = 0, opt_share = 1, opt_device_select = 1;
+  int opt_batch = 0 /* 0: by index size, effective_batch() */, opt_slots = 3, opt_growth = 8, opt_force_dense = 0, opt_share = 1, opt_device_select = 1;
   // a call with few queries is latency-bound: every segment costs a dependent scan + finalize launch pair (~15-20 us), so such calls
   // walk the index in fewer, faster-growing segments (more candidates per query - the device selects the answer itself anyway)
   int opt_latency_queries = 4, opt_latency_growth = 64;
@@ -186,7 +186,7 @@ struct bbq_index {
   int opt_append_last = 1;  // append mode also for the last (largest) segment: its finalize launch gets cheaper, its sweep slower (one
                             // atomic per workgroup with candidates); measured at 10 M x 768: 0.250 ms per call with, 0.263 without
   // host threads replaying the heaps of one sub-batch: half the cores, at most 8 (a batch of 32 answers 1.4x sooner than with 1)
-  int opt_replay_threads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
+  int opt_replay_threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 2));
   int64_t opt_s0 = 4096;
   // flood tier: candidates one query may pile up beyond the planned list (rows stored cluster by cluster make the
   // query's own cluster beat a threshold that was derived from other clusters) before it has to take the dense path

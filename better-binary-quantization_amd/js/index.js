@@ -460,11 +460,11 @@ class BinaryQuantizationFormat {
     // costs ~15 us on one core, more than its sweep of 1 M rows on the device)
     const r = native.searchRawBatch(targetVectors._deviceIndex(), nq, flat, targetVectors.getCentroid(), sim, this.config.queryBits, q.lambda, q.iters,
       Number(process.env.BBQ_THREADS || 0), k);
-    const out = [];
+    const out = new Array(nq), indices = r.indices, scores = r.scores, stride = r.stride;
     for (let i = 0; i < nq; i++) {
-      const res = [], n = r.counts[i], base = i * r.stride;
-      for (let j = 0; j < n; j++) res.push({ index: r.indices[base + j], score: r.scores[base + j] });
-      out.push(res);
+      const n = r.counts[i], base = i * stride, res = new Array(n);
+      for (let j = 0; j < n; j++) res[j] = { index: indices[base + j], score: scores[base + j] };
+      out[i] = res;
     }
     return out;
   }

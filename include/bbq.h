@@ -390,8 +390,8 @@ typedef struct {
 int bbq_get_stats(bbq_index *idx, bbq_stats *out);
 int bbq_reset_stats(bbq_index *idx);
 /* tuning knobs; returns BBQ_ERR_INVALID_ARG for unknown names or values out of range (DESIGN.md "Knobs"):
- *   batch_queries 0..1024 (0 = by index size: 32 from 6 M rows, 64 from 2.5 M, 128 below)   pipeline_slots 1..4 (2)   segment_growth 2..1024 (8)   first_segment_rows 1024..8192 (4096)
- *   replay_threads 1..256 (half the host cores, at most 8)   flood_rows 0..2^24 (262144)   force_dense 0|1 (0)
+ *   batch_queries 0..1024 (0 = by index size: 32 from 6 M rows, 64 from 2.5 M, 128 below)   pipeline_slots 1..4 (3)   segment_growth 2..1024 (8)   first_segment_rows 1024..8192 (4096)
+ *   replay_threads 1..256 (half the host cores, at most 16)   flood_rows 0..2^24 (262144)   force_dense 0|1 (0)
  *   sweep_share 1|4|8|32 (1: every query sweeps the index itself; 32: shared sweep on the matrix cores)
  *   device_select 0|1 (1: for k <= 1024 the device selects and sorts the answer itself whenever no two scores in or at the edge of it
  *   compare equal - then the reference heap provably returns that order - and the host replays the heap only for the rest)
