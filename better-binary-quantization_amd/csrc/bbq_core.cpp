@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -213,6 +214,39 @@ namespace {
 // 57 K with 96-128; at 10 M rows 32 is as good as 64 and needs half the workspace).  A call should also be cut into at least four
 // sub-batches where it can: the first sub-batch's small segments run alone on the device and only the later ones hide theirs behind
 // another sub-batch's large sweep (1 M rows x 256 queries per call: 0.849 of the roofline end to end with 2 x 128, 0.855 with 4 x 64)
+// The view a launch gets: the stored view + how much of the index is loaded cache-resident.  The indexes that have launched sweeps
+// on the device lately (kCacheWindow) share its 256 MiB Infinity Cache: each keeps a prefix in proportion to its size
+// (resident_mb >= 0: that many MiB, whatever else is there).  Called with the device context locked.
+constexpr int64_t kResidentAutoBytes = 224ll << 20;  // measured: 10 M x 768 gains up to 256 MiB, a 260 MB index kept whole gains nothing (248 MiB resident: all of the gain lost)
+constexpr uint64_t kCacheWindow = 100'000'000;  // ns: an index that has launched nothing for 0.1 s is not competing for the cache
+static int64_t cache_sharers_bytes(bbq_index *ix, int64_t own) {
+  DeviceCtx *c = ix->ctx;
+  if (!c) return own;
+  const uint64_t now = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  int64_t all = 0;
+  bool found = false;
+  for (size_t i = 0; i < c->cache_users.size();) {
+    DeviceCtx::CacheUser &u = c->cache_users[i];
+    if (u.index == ix) { u.bytes = own; u.tick = now; found = true; }
+    if (now - u.tick > kCacheWindow) { c->cache_users.erase(c->cache_users.begin() + (long)i); continue; }
+    all += u.bytes;
+    ++i;
+  }
+  if (!found) { c->cache_users.push_back({ix, own, now}); all += own; }
+  return all;
+}
+static IndexView launch_view(bbq_index *ix, const Storage &sto) {
+  IndexView v = sto.view;
+  const int64_t tiles = (v.n_rows + kTileRows - 1) / kTileRows;
+  const int64_t own = ((ix->main.view.n_rows + kTileRows - 1) / kTileRows) * (int64_t)ix->main.view.tile_stride;
+  const int64_t all = std::max<int64_t>(1, cache_sharers_bytes(ix, own));
+  const int64_t budget = ix->opt_resident_mb >= 0 ? ((int64_t)ix->opt_resident_mb << 20)
+                                                  : (int64_t)((double)kResidentAutoBytes * ((double)own / (double)all));
+  v.resident_tiles = std::min(tiles, budget / std::max(1, v.tile_stride)) / kTilesPerChunk * kTilesPerChunk;  // decided per chunk (workgroup)
+  if (&sto == &ix->main) ix->stats.resident_bytes = v.resident_tiles * (int64_t)v.tile_stride;
+  return v;
+}
+
 int effective_batch(const bbq_index *ix, int64_t n_queries = 0) {
   if (ix->opt_batch > 0) return ix->opt_batch;
   const int64_t rows = ix->main.view.n_rows;
@@ -655,7 +689,7 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const 
   for (const Segment &g : p.segs) {
     const Storage &sto = g.storage == 0 ? ix->pilot : ix->main;
     ScanArgs a{};
-    a.idx = sto.view;
+    a.idx = launch_view(ix, sto);
     a.qplanes = reinterpret_cast<const uint4 *>(s.d_qbuf);
     a.qparams = reinterpret_cast<const QueryParams *>(s.d_qbuf + (size_t)nq * qb);
     a.chunk_begin = g.chunk_begin;
@@ -795,7 +829,7 @@ int dense_scores_one(const BatchCtx &c, int64_t qi, float *out) {
   HIPCHK(hipMemcpyAsync(ix->ctx->d_aux_qbuf, hb.data(), hb.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
   ScanArgs a{};
-  a.idx = ix->main.view;
+  a.idx = launch_view(ix, ix->main);
   a.qplanes = reinterpret_cast<const uint4 *>(ix->ctx->d_aux_qbuf);
   a.qparams = reinterpret_cast<const QueryParams *>(ix->ctx->d_aux_qbuf + qb);
   a.chunk_begin = 0;
@@ -1053,7 +1087,7 @@ int search_latency_presampled(const BatchCtx &c, const BatchCtx &cs, int32_t *ou
     s.ctrl_clean = true;
   }
   LatScanArgs a{};
-  a.idx = ix->main.view;
+  a.idx = launch_view(ix, ix->main);
   a.row_id_base = ix->main.row_id_base;
   a.theta = s.d_theta;
   a.flags = s.d_flags;
@@ -1063,7 +1097,7 @@ int search_latency_presampled(const BatchCtx &c, const BatchCtx &cs, int32_t *ou
   a.list_cap = s.list_cap;
   fill_query(ix, reinterpret_cast<uint8_t *>(a.planes), &a.p, c.qquant, c.qcorr, cs.planes, cs.one_bit, cs.sim);
   LatPreArgs pre{};
-  pre.idx = ix->main.view;
+  pre.idx = launch_view(ix, ix->main);
   pre.rows = (int32_t)P;
   pre.per_wave = per_wave;
   pre.pre_keys = ctx->d_pre_keys;
@@ -1136,7 +1170,7 @@ int search_latency_chain(const BatchCtx &c, const BatchCtx &cs, int32_t *out_idx
     s.ctrl_clean = true;
   }
   LatScanArgs a{};
-  a.idx = ix->main.view;
+  a.idx = launch_view(ix, ix->main);
   a.row_id_base = ix->main.row_id_base;
   a.theta = s.d_theta;
   a.flags = s.d_flags;
@@ -1244,6 +1278,9 @@ void destroy_unlocked(bbq_index *ix) {
   if (ix->pilot.d_exact) (void)hipFree(ix->pilot.d_exact);
   if (ix->main.d_exact) (void)hipFree(ix->main.d_exact);
   if (ix->d_dense_all) (void)hipFree(ix->d_dense_all);
+  if (ix->ctx)
+    for (size_t i = 0; i < ix->ctx->cache_users.size(); ++i)
+      if (ix->ctx->cache_users[i].index == ix) { ix->ctx->cache_users.erase(ix->ctx->cache_users.begin() + (long)i); break; }
   if (ix->ctx) (void)settle_shard_slots(ix->ctx, ix);  // sub-batches of an asynchronous scan that was never waited for
   for (bbq_index::ShardSet &set : ix->shard_set) {
     if (set.done) { (void)hipEventSynchronize(set.done); (void)hipEventDestroy(set.done); }
@@ -1554,7 +1591,7 @@ int bbq_score_rows(bbq_index *ix, const uint8_t *qquant, const double *qcorr, in
   for (int64_t cb = c_first; cb < c_last && rc == BBQ_OK; cb += piece_chunks) {
     const int64_t nc = std::min(piece_chunks, c_last - cb);
     ScanArgs a{};
-    a.idx = ix->main.view;
+    a.idx = launch_view(ix, ix->main);
     a.qplanes = reinterpret_cast<const uint4 *>(ix->ctx->d_aux_qbuf);
     a.qparams = reinterpret_cast<const QueryParams *>(ix->ctx->d_aux_qbuf + qb);
     a.chunk_begin = cb;
@@ -1752,6 +1789,7 @@ int bbq_set_option(bbq_index *ix, const char *name, int64_t v) {
   else if (n == "pipeline_slots" && v >= 1 && v <= kMaxSlots) ix->opt_slots = (int)v;
   else if (n == "segment_growth" && v >= 2 && v <= 1024) { ix->opt_growth = (int)v; ix->plan.k = -1; }
   else if (n == "first_segment_rows" && v >= 1024 && v <= 8192 && v % kChunkRows == 0) { ix->opt_s0 = v; ix->plan.k = -1; }
+  else if (n == "resident_mb" && v >= -1 && v <= 1 << 20) ix->opt_resident_mb = (int)v;
   else if (n == "replay_threads" && v >= 1 && v <= 256) ix->opt_replay_threads = (int)v;
   else if (n == "force_dense" && (v == 0 || v == 1)) ix->opt_force_dense = (int)v;
   else if (n == "device_select" && (v == 0 || v == 1)) ix->opt_device_select = (int)v;

@@ -58,6 +58,10 @@ struct IndexView {
   int32_t dim;
   int32_t layout;
   int32_t store_bits;   // 1: packed 1-bit rows; 2 / 4 / 8: multi-bit fields (indexBits 2 / 3-4 / 5-8)
+  int64_t resident_tiles;  // tiles [0, resident_tiles) are loaded with the default cache policy (they stay in the 256 MiB Infinity Cache
+                           // from one query's sweep to the next), the rest with non-temporal loads (streamed, read once per sweep)
+  int64_t nt_delta;        // always 0.  The streamed loads add it to their address so that the compiler sees two different addresses
+                           // in the two branches: it merges loads that differ only in the cache policy into ONE plain load
 };
 
 // Per-query uniforms of the score formula (src/batchDotProduct.ts:478-617)

@@ -127,6 +127,9 @@ struct DeviceCtx {
   uint64_t *h_lat = nullptr, *d_lat = nullptr;
   uint64_t lat_seq = 0;
   uint32_t *d_pre_keys = nullptr;     // [kLatPreKeys] per-wave top keys of the pre-sampled threshold
+  // the indexes that launched sweeps on this device lately share its Infinity Cache (launch_view, bbq_core.cpp); under `mu`
+  struct CacheUser { const void *index; int64_t bytes; uint64_t tick; };
+  std::vector<CacheUser> cache_users;
 
 };
 constexpr int kLatAnswerOffset = 8;   // words in front of the answer block inside DeviceCtx::h_lat
@@ -181,6 +184,8 @@ struct bbq_index {
   // walk the index in fewer, faster-growing segments (more candidates per query - the device selects the answer itself anyway)
   int opt_latency_queries = 4, opt_latency_growth = 64;
   int opt_latency_append = 1;  // 0: calls with few queries keep the chunk slots (and the finalize launches their compaction)
+  int opt_resident_mb = -1;  // MiB of the index (from row 0) loaded with the default cache policy so that they stay in the Infinity Cache between
+                             // sweeps (IndexView::resident_tiles); -1: the whole index when it fits (kResidentAutoBytes), else none
   int opt_latency_presample = 1;  // ... and on large indexes get their threshold from per-wave top keys of a prefix (two small launches) instead of two scan / finalize pairs
   int opt_latency_fused = 1;  // single-query calls take the three-launch latency path (bbq_latency_kernels.hip) when the index shape has one
   int opt_append_last = 1;  // append mode also for the last (largest) segment: its finalize launch gets cheaper, its sweep slower (one

@@ -17,7 +17,52 @@ namespace bbq {
 #endif
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// a tile's bytes: default cache policy for the resident part of the index (IndexView::resident_tiles), streamed otherwise.
+// `resident` must be wave-uniform (chunk_is_resident: decided per workgroup from blockIdx): a scalar branch, never both loads
+template <class T> __device__ __forceinline__ const T *stream_ptr(const T *p, int64_t nt_delta) {
+  return reinterpret_cast<const T *>(reinterpret_cast<const char *>(p) + nt_delta);
+}
+// the compiler merges the loads of two branches that differ only in the cache policy into ONE plain load (also through a phi of
+// the two addresses): the streamed branch is fenced with compiler barriers, which its loads cannot be hoisted or sunk across
+#define BBQ_BRANCH_FENCE() asm volatile("" ::: "memory")
+__device__ __forceinline__ bool chunk_is_resident(int64_t chunk, int64_t resident_tiles) {
+  return chunk * kTilesPerChunk < resident_tiles;  // resident_tiles is a multiple of kTilesPerChunk; chunk comes from blockIdx: scalar
+}
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+// ALL loads of a wave's tile in ONE two-way branch (W > 0): the W code chunks of the lane's row and its corrections - CORR 0: none,
+// 1: the compact word, 2: the inline f64 corrections (lower, upper | additional | component sum if stored).  Loads that are
+// already in flight when the branch is reached make the compiler wait for them inside it (it assumes either arm may follow them).
+template <int W, int CORR>
+__device__ __forceinline__ void load_tile(const uint8_t *__restrict__ tp, int lane, bool has_x1, bool resident, int64_t nt_delta,
+                                          u32x4 (&c)[W], uint32_t &cw, f64x2 &lu, double &xadd, double &x1) {
+  const u32x4 *__restrict__ cp = reinterpret_cast<const u32x4 *>(tp) + lane;
+  const uint8_t *__restrict__ cr = tp + (size_t)W * (kTileRows * 16);
+  if (resident) {  // scalar branch
+#pragma unroll
+    for (int j = 0; j < W; ++j) c[j] = cp[j * kTileRows];
+    if constexpr (CORR == 1) cw = *(reinterpret_cast<const uint32_t *>(cr) + lane);
+    if constexpr (CORR == 2) {
+      lu = *(reinterpret_cast<const f64x2 *>(cr) + lane);
+      xadd = *(reinterpret_cast<const double *>(cr + 1024) + lane);
+      if (has_x1) x1 = *(reinterpret_cast<const double *>(cr + 1536) + lane);
+    }
+  } else {
+    BBQ_BRANCH_FENCE();
+    const u32x4 *__restrict__ cs = stream_ptr(cp, nt_delta);
+    const uint8_t *__restrict__ crs = stream_ptr(cr, nt_delta);
+#pragma unroll
+    for (int j = 0; j < W; ++j) c[j] = BBQ_STREAM_LOAD(cs + j * kTileRows);
+    if constexpr (CORR == 1) cw = BBQ_STREAM_LOAD(reinterpret_cast<const uint32_t *>(crs) + lane);
+    if constexpr (CORR == 2) {
+      lu = BBQ_STREAM_LOAD(reinterpret_cast<const f64x2 *>(crs) + lane);
+      xadd = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(crs + 1024) + lane);
+      if (has_x1) x1 = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(crs + 1536) + lane);
+    }
+    BBQ_BRANCH_FENCE();
+  }
+}
 
 __device__ __forceinline__ uint32_t popc4(u32x4 v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
 
@@ -46,31 +91,32 @@ __device__ __forceinline__ double score_f64(double qc, double ax, double ux, dou
   return t < 0.0 ? 1.0 / (1.0 - t / FBS) : t / FBS + 1.0;
 }
 
-// One tile = 64 rows, one row per lane.  W = compile-time number of 16-byte chunks per row (0: runtime).
+// One tile = 64 rows, one row per lane.  W = compile-time number of 16-byte chunks per row: the chunks come in registers (load_tile)
 template <int QB, int W>
-__device__ __forceinline__ void tile_popcounts(const uint8_t *__restrict__ tp, int lane, int w16,
-                                               const u32x4 *__restrict__ s_planes, uint32_t (&acc)[QB], uint32_t &ones) {
+__device__ __forceinline__ void tile_popcounts(const u32x4 (&c)[W], const u32x4 *__restrict__ s_planes, uint32_t (&acc)[QB], uint32_t &ones) {
+#pragma unroll
+  for (int p = 0; p < QB; ++p) acc[p] = 0;
+  ones = 0;
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+#pragma unroll
+    for (int p = 0; p < QB; ++p) acc[p] += popc4(c[j] & s_planes[j * QB + p]);
+    ones += popc4(c[j]);
+  }
+}
+// any width (w16 chunks, known at run time): streamed chunk by chunk
+template <int QB>
+__device__ __forceinline__ void tile_popcounts_any(const uint8_t *__restrict__ tp, int lane, int w16, const u32x4 *__restrict__ s_planes,
+                                                   uint32_t (&acc)[QB], uint32_t &ones) {
   const u32x4 *__restrict__ cp = reinterpret_cast<const u32x4 *>(tp) + lane;
 #pragma unroll
   for (int p = 0; p < QB; ++p) acc[p] = 0;
   ones = 0;
-  if constexpr (W > 0) {
-    u32x4 c[W];
+  for (int j = 0; j < w16; ++j) {
+    const u32x4 c = BBQ_STREAM_LOAD(cp + j * kTileRows);
 #pragma unroll
-    for (int j = 0; j < W; ++j) c[j] = BBQ_STREAM_LOAD(cp + j * kTileRows);
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-#pragma unroll
-      for (int p = 0; p < QB; ++p) acc[p] += popc4(c[j] & s_planes[j * QB + p]);
-      ones += popc4(c[j]);
-    }
-  } else {
-    for (int j = 0; j < w16; ++j) {
-      const u32x4 c = BBQ_STREAM_LOAD(cp + j * kTileRows);
-#pragma unroll
-      for (int p = 0; p < QB; ++p) acc[p] += popc4(c & s_planes[j * QB + p]);
-      ones += popc4(c);
-    }
+    for (int p = 0; p < QB; ++p) acc[p] += popc4(c & s_planes[j * QB + p]);
+    ones += popc4(c);
   }
 }
 

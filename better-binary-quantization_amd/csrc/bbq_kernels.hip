@@ -62,24 +62,26 @@ __device__ __forceinline__ void dot_chunk_multibit(const u32x4 c, const uint32_t
 }
 
 template <int QB, int W, int SB>
-__device__ __forceinline__ void tile_dot_multibit(const uint8_t *__restrict__ tp, int lane, int w16, const u32x4 *__restrict__ s_planes,
-                                                  uint32_t &qc, uint32_t &sum) {
+__device__ __forceinline__ void tile_dot_multibit(const u32x4 (&c)[W], const u32x4 *__restrict__ s_planes, uint32_t &qc, uint32_t &sum) {
+  const uint32_t *__restrict__ sq = reinterpret_cast<const uint32_t *>(s_planes);
+  constexpr int QN = query_units_per_chunk(QB, SB);
+  uint32_t lo = 0, hi = 0;
+  sum = 0;
+#pragma unroll
+  for (int j = 0; j < W; ++j) dot_chunk_multibit<QB, SB>(c[j], sq + j * 4 * QN, lo, hi, sum);
+  qc = lo + (hi << 4);
+}
+template <int QB, int SB>
+__device__ __forceinline__ void tile_dot_multibit_any(const uint8_t *__restrict__ tp, int lane, int w16, const u32x4 *__restrict__ s_planes,
+                                                      uint32_t &qc, uint32_t &sum) {
   const u32x4 *__restrict__ cp = reinterpret_cast<const u32x4 *>(tp) + lane;
   const uint32_t *__restrict__ sq = reinterpret_cast<const uint32_t *>(s_planes);
   constexpr int QN = query_units_per_chunk(QB, SB);
   uint32_t lo = 0, hi = 0;
   sum = 0;
-  if constexpr (W > 0) {
-    u32x4 c[W];
-#pragma unroll
-    for (int j = 0; j < W; ++j) c[j] = BBQ_STREAM_LOAD(cp + j * kTileRows);
-#pragma unroll
-    for (int j = 0; j < W; ++j) dot_chunk_multibit<QB, SB>(c[j], sq + j * 4 * QN, lo, hi, sum);
-  } else {
-    for (int j = 0; j < w16; ++j) {
-      const u32x4 c = BBQ_STREAM_LOAD(cp + j * kTileRows);
-      dot_chunk_multibit<QB, SB>(c, sq + j * 4 * QN, lo, hi, sum);
-    }
+  for (int j = 0; j < w16; ++j) {
+    const u32x4 c = BBQ_STREAM_LOAD(cp + j * kTileRows);
+    dot_chunk_multibit<QB, SB>(c, sq + j * 4 * QN, lo, hi, sum);
   }
   qc = lo + (hi << 4);
 }
@@ -126,33 +128,53 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) 
     const uint8_t *__restrict__ cr = tp + (size_t)w16 * (kTileRows * 16);
     const int64_t row = tile * kTileRows + lane;
     const bool valid = row < a.idx.n_rows;
+    const bool resident = chunk_is_resident(chunk, a.idx.resident_tiles);
 
-    // corrections: issue their loads before the popcount loop so they are in flight with the code loads
+    // every load of the tile is issued up front: the row's code chunks and its corrections
     f64x2 lu = {0.0, 0.0};
     double xadd = 0.0, x1 = 0.0;
     uint32_t cpk0 = 0, cpk1 = 0;
-    if constexpr (!COMPACT) {
-      lu = BBQ_STREAM_LOAD(reinterpret_cast<const f64x2 *>(cr) + lane);
-      xadd = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(cr + 1024) + lane);
-      if (a.idx.has_x1) x1 = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(cr + 1536) + lane);
-    } else if constexpr (DENSE) {
-      const f64x2 *__restrict__ ex = reinterpret_cast<const f64x2 *>(a.idx.exact + row * 4);
-      lu = BBQ_STREAM_LOAD(ex);
-      xadd = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(ex + 1));
-    } else {
-      cpk0 = BBQ_STREAM_LOAD(reinterpret_cast<const uint32_t *>(cr) + lane);
-      // the tile's additive-correction range: EUCLIDEAN scores fall with it (take the minimum), the others rise (maximum)
-      cpk1 = __float_as_uint(a.idx.add_range[tile * 2 + (p.sim == 0 ? 0 : 1)]);
-    }
-
     uint32_t qc = 0, ones;
-    if constexpr (SB == 1) {
-      uint32_t acc[QB];
-      tile_popcounts<QB, W>(tp, lane, w16, s_planes, acc, ones);
+    constexpr int CORR = !COMPACT ? 2 : (DENSE ? 0 : 1);
+    if constexpr (W > 0) {
+      u32x4 c[W];
+      load_tile<W, CORR>(tp, lane, a.idx.has_x1 != 0, resident, a.idx.nt_delta, c, cpk0, lu, xadd, x1);
+      if constexpr (COMPACT && DENSE) {
+        const f64x2 *__restrict__ ex = reinterpret_cast<const f64x2 *>(a.idx.exact + row * 4);
+        lu = BBQ_STREAM_LOAD(ex);
+        xadd = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(ex + 1));
+      }
+      // the tile's additive-correction range: EUCLIDEAN scores fall with it (take the minimum), the others rise (maximum)
+      if constexpr (COMPACT && !DENSE) cpk1 = __float_as_uint(a.idx.add_range[tile * 2 + (p.sim == 0 ? 0 : 1)]);
+      if constexpr (SB == 1) {
+        uint32_t acc[QB];
+        tile_popcounts<QB, W>(c, s_planes, acc, ones);
 #pragma unroll
-      for (int pl = 0; pl < QB; ++pl) qc += acc[pl] << pl;
-    } else {
-      tile_dot_multibit<QB, W, SB>(tp, lane, w16, s_planes, qc, ones);
+        for (int pl = 0; pl < QB; ++pl) qc += acc[pl] << pl;
+      } else {
+        tile_dot_multibit<QB, W, SB>(c, s_planes, qc, ones);
+      }
+    } else {  // a row width without a compiled kernel: streamed chunk by chunk
+      if constexpr (!COMPACT) {
+        lu = BBQ_STREAM_LOAD(reinterpret_cast<const f64x2 *>(cr) + lane);
+        xadd = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(cr + 1024) + lane);
+        if (a.idx.has_x1) x1 = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(cr + 1536) + lane);
+      } else if constexpr (DENSE) {
+        const f64x2 *__restrict__ ex = reinterpret_cast<const f64x2 *>(a.idx.exact + row * 4);
+        lu = BBQ_STREAM_LOAD(ex);
+        xadd = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(ex + 1));
+      } else {
+        cpk0 = BBQ_STREAM_LOAD(reinterpret_cast<const uint32_t *>(cr) + lane);
+        cpk1 = __float_as_uint(a.idx.add_range[tile * 2 + (p.sim == 0 ? 0 : 1)]);
+      }
+      if constexpr (SB == 1) {
+        uint32_t acc[QB];
+        tile_popcounts_any<QB>(tp, lane, w16, s_planes, acc, ones);
+#pragma unroll
+        for (int pl = 0; pl < QB; ++pl) qc += acc[pl] << pl;
+      } else {
+        tile_dot_multibit_any<QB, SB>(tp, lane, w16, s_planes, qc, ones);
+      }
     }
     if (!a.idx.has_x1) x1 = (double)ones;  // quantizedComponentSum of a freshly quantized row is its popcount / component sum
 
@@ -284,23 +306,15 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_shared_kernel(const ScanA
 
   if (tile < n_tiles) {  // wave-uniform
     const uint8_t *__restrict__ tp = a.idx.tiles + tile * (int64_t)a.idx.tile_stride;
-    const uint8_t *__restrict__ cr = tp + (size_t)W * (kTileRows * 16);
     const int64_t row = tile * kTileRows + lane;
     const bool valid = row < a.idx.n_rows;
-    const u32x4 *__restrict__ cp = reinterpret_cast<const u32x4 *>(tp) + lane;
     u32x4 c[W];
-#pragma unroll
-    for (int j = 0; j < W; ++j) c[j] = BBQ_STREAM_LOAD(cp + j * kTileRows);
     f64x2 lu = {0.0, 0.0};
     double xadd = 0.0, x1 = 0.0, al = 0.0, au = 0.0, aadd = 0.0;
-    bool have_exact = false;
-    if constexpr (!COMPACT) {
-      lu = BBQ_STREAM_LOAD(reinterpret_cast<const f64x2 *>(cr) + lane);
-      xadd = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(cr + 1024) + lane);
-      if (a.idx.has_x1) x1 = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(cr + 1536) + lane);
-      have_exact = true;
-    } else {
-      const uint32_t cw = BBQ_STREAM_LOAD(reinterpret_cast<const uint32_t *>(cr) + lane);
+    uint32_t cw = 0;
+    load_tile<W, COMPACT ? 1 : 2>(tp, lane, a.idx.has_x1 != 0, chunk_is_resident(chunk, a.idx.resident_tiles), a.idx.nt_delta, c, cw, lu, xadd, x1);
+    bool have_exact = !COMPACT;
+    if constexpr (COMPACT) {
       al = (double)__uint_as_float(cw << 16);
       au = (double)__uint_as_float(cw & 0xffff0000u);
       // tile range of the additive correction; the queries of one call share the similarity function

@@ -50,22 +50,16 @@ __global__ __launch_bounds__(kLatThreads) void bbq_lat_scan_kernel(const LatScan
   bool nan_seen = false;
   if (tile < n_tiles) {  // wave-uniform
     const uint8_t *__restrict__ tp = a.idx.tiles + tile * (int64_t)a.idx.tile_stride;
-    const uint8_t *__restrict__ cr = tp + (size_t)W * (kTileRows * 16);
     const int64_t row = tile * kTileRows + lane;
     const bool valid = row < a.idx.n_rows;
     f64x2 lu = {0.0, 0.0};
     double xadd = 0.0, x1 = 0.0;
     uint32_t cpk0 = 0, cpk1 = 0;
-    if constexpr (!COMPACT) {
-      lu = BBQ_STREAM_LOAD(reinterpret_cast<const f64x2 *>(cr) + lane);
-      xadd = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(cr + 1024) + lane);
-      if (a.idx.has_x1) x1 = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(cr + 1536) + lane);
-    } else {
-      cpk0 = BBQ_STREAM_LOAD(reinterpret_cast<const uint32_t *>(cr) + lane);
-      cpk1 = __float_as_uint(a.idx.add_range[tile * 2 + (p.sim == 0 ? 0 : 1)]);
-    }
+    u32x4 c[W];
+    load_tile<W, COMPACT ? 1 : 2>(tp, lane, a.idx.has_x1 != 0, chunk_is_resident(chunk, a.idx.resident_tiles), a.idx.nt_delta, c, cpk0, lu, xadd, x1);
+    if constexpr (COMPACT) cpk1 = __float_as_uint(a.idx.add_range[tile * 2 + (p.sim == 0 ? 0 : 1)]);
     uint32_t acc[QB], ones, qc = 0;
-    tile_popcounts<QB, W>(tp, lane, W, s_planes, acc, ones);
+    tile_popcounts<QB, W>(c, s_planes, acc, ones);
 #pragma unroll
     for (int pl = 0; pl < QB; ++pl) qc += acc[pl] << pl;
     if (!a.idx.has_x1) x1 = (double)ones;
@@ -127,22 +121,21 @@ __global__ __launch_bounds__(kLatThreads) void bbq_lat_pre_kernel(const LatPreAr
   const int64_t row = tile * kTileRows + lane;
   const bool valid = row < (int64_t)a.rows && row < a.idx.n_rows;
   const uint8_t *__restrict__ tp = a.idx.tiles + tile * (int64_t)a.idx.tile_stride;
-  const uint8_t *__restrict__ cr = tp + (size_t)W * (kTileRows * 16);
   uint32_t key = 0;
   if (tile * kTileRows < (int64_t)a.rows) {  // wave-uniform
-    f64x2 lu;
-    double xadd, x1 = 0.0;
-    if constexpr (!COMPACT) {
-      lu = BBQ_STREAM_LOAD(reinterpret_cast<const f64x2 *>(cr) + lane);
-      xadd = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(cr + 1024) + lane);
-      if (a.idx.has_x1) x1 = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(cr + 1536) + lane);
-    } else {
+    f64x2 lu = {0.0, 0.0};
+    double xadd = 0.0, x1 = 0.0;
+    uint32_t unused = 0;
+    u32x4 c[W];
+    // the prefix the threshold is sampled from is also the part of the index that stays cache-resident
+    load_tile<W, COMPACT ? 0 : 2>(tp, lane, a.idx.has_x1 != 0, chunk_is_resident((int64_t)blockIdx.x, a.idx.resident_tiles), a.idx.nt_delta, c, unused, lu, xadd, x1);
+    if constexpr (COMPACT) {
       const f64x2 *__restrict__ ex = reinterpret_cast<const f64x2 *>(a.idx.exact + (valid ? row : 0) * 4);
       lu = BBQ_STREAM_LOAD(ex);
       xadd = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(ex + 1));
     }
     uint32_t acc[QB], ones, qc = 0;
-    tile_popcounts<QB, W>(tp, lane, W, s_planes, acc, ones);
+    tile_popcounts<QB, W>(c, s_planes, acc, ones);
 #pragma unroll
     for (int pl = 0; pl < QB; ++pl) qc += acc[pl] << pl;
     if (!a.idx.has_x1) x1 = (double)ones;

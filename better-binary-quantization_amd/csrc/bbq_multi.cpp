@@ -509,6 +509,7 @@ int multi_get_stats(bbq_index *ix, bbq_stats *out) {
     agg.total_scan_ms = std::max(agg.total_scan_ms, s.total_scan_ms);
     agg.total_scan_bytes += s.total_scan_bytes;
     agg.total_scan_launches = std::max(agg.total_scan_launches, s.total_scan_launches);
+    agg.resident_bytes += s.resident_bytes;
   }
   *out = agg;
   return BBQ_OK;

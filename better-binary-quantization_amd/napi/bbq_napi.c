@@ -362,6 +362,7 @@ static napi_value Stats(napi_env env, napi_callback_info info) {
   napi_create_double(env, (double)st.candidates, &v); set_prop(env, o, "candidates", v);
   napi_create_double(env, (double)st.dense_fallbacks, &v); set_prop(env, o, "denseFallbacks", v);
   napi_create_double(env, (double)st.host_replays, &v); set_prop(env, o, "hostReplays", v);
+  napi_create_double(env, (double)st.resident_bytes, &v); set_prop(env, o, "residentBytes", v);
   napi_create_double(env, (double)bbq_index_shards(ix), &v); set_prop(env, o, "shards", v);
   napi_create_double(env, (double)bbq_index_bytes_per_row(ix), &v); set_prop(env, o, "bytesPerRow", v);
   return o;

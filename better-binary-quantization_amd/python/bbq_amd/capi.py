@@ -54,7 +54,7 @@ def _opts(corrections):
 class Stats(C.Structure):
     _fields_ = [("last_scan_ms", C.c_double), ("last_scan_rows", C.c_int64), ("last_scan_bytes", C.c_int64),
                 ("candidates", C.c_int64), ("dense_fallbacks", C.c_int64), ("total_scan_ms", C.c_double),
-                ("total_scan_bytes", C.c_int64), ("total_scan_launches", C.c_int64), ("host_replays", C.c_int64)]
+                ("total_scan_bytes", C.c_int64), ("total_scan_launches", C.c_int64), ("host_replays", C.c_int64), ("resident_bytes", C.c_int64)]
 
 
 _lib = None

@@ -1398,3 +1398,76 @@ def test_search_raw_batch_equals_quantize_then_search(sim, qb, nq):
         np.testing.assert_array_equal(sc.view(np.uint32), want[1].view(np.uint32))
     finally:
         mx.close()
+
+
+@pytest.mark.parametrize("dim,qb,sim,compact,ib", [(768, 4, 1, True, 1), (1024, 1, 2, False, 1), (1536, 4, 0, True, 1), (200, 4, 1, True, 1),
+                                                   (1024, 8, 1, True, 2), (256, 4, 1, True, 4)])
+def test_cache_resident_prefix_changes_no_answer(dim, qb, sim, compact, ib):
+    """the sweeps load a prefix of the index with the default cache policy (it stays in the Infinity Cache from one query's sweep to the
+    next) and stream the rest (option resident_mb, IndexView::resident_tiles): every split - nothing, one chunk, a part, everything,
+    the automatic share - gives the oracle's answer for batches, single queries and the shared sweep; bbq_stats.resident_bytes
+    reports the split"""
+    rng = np.random.default_rng(dim + qb + sim)
+    n, k, nq = 70_000, 50, 9
+    if ib == 1:
+        pb = (dim + 7) // 8
+        codes = rng.integers(0, 256, size=(n, pb), dtype=np.uint8)
+        if dim % 8:
+            codes[:, -1] &= (0xFF << (8 - dim % 8)) & 0xFF
+        x1 = np.unpackbits(codes, axis=1).sum(axis=1)
+    else:
+        codes = rng.integers(0, 1 << ib, size=(n, dim), dtype=np.uint8)
+        x1 = codes.sum(axis=1)
+    corr = np.empty((n, 4))
+    corr[:, 0] = -0.04 * (0.9 + 0.2 * rng.random(n))
+    corr[:, 1] = 0.04 * (0.9 + 0.2 * rng.random(n))
+    corr[:, 2] = 1e-4 * (2 * rng.random(n) - 1)
+    corr[:, 3] = x1
+    cdp = 0.0009
+    qq = rng.integers(0, 1 << qb, size=(nq, dim), dtype=np.uint8)
+    qc = np.empty((nq, 4))
+    qc[:, 0] = -0.15 * (0.9 + 0.2 * rng.random(nq))
+    qc[:, 1] = 0.148 * (0.9 + 0.2 * rng.random(nq))
+    qc[:, 2] = -0.0028 * rng.random(nq)
+    qc[:, 3] = qq.sum(axis=1)
+    want = []
+    for q in range(nq):
+        if ib == 1:
+            _, _, s32 = O.score_all(codes, corr, dim, qq[q], qc[q], qb, sim, cdp)
+        elif qb in (1, 4):
+            _, _, s32 = O.score_all(codes, corr, dim, qq[q], qc[q], qb, sim, cdp, ib=ib)
+        else:   # the reference throws for this queryBits on a multi-bit index: libbbq's documented extension
+            _, _, s32 = O.score_all_multibit_ext(codes, corr, dim, qq[q], qc[q], qb, sim, cdp)
+        want.append(O.heap_topk(s32, k))
+    ix = _make_index(codes, corr, dim, cdp, compact, index_bits=ib)
+    try:
+        row_bytes = ix.bytes_per_row
+        index_bytes = (n + 63) // 64 * 64 * row_bytes
+        seen = set()
+        for mb in (0, 1, 3, 1 << 20, -1):
+            ix.set_option("resident_mb", mb)
+            idx, sc, cnt = ix.search_batch(qq, qc, qb, sim, k)
+            for q in range(nq):
+                np.testing.assert_array_equal(idx[q], want[q][0])
+                np.testing.assert_array_equal(sc[q].view(np.uint32), want[q][1].view(np.uint32))
+            rb = ix.stats()["resident_bytes"]
+            seen.add(rb)
+            assert 0 <= rb <= index_bytes and rb % (512 * row_bytes) == 0     # whole chunks of 512 rows
+            if mb == 0:
+                assert rb == 0
+            if mb in (1, 3):
+                assert 0 < rb <= mb << 20
+            si, ss = ix.search(qq[0], qc[0], qb, sim, k)        # the single-query paths
+            np.testing.assert_array_equal(si, want[0][0])
+            np.testing.assert_array_equal(ss.view(np.uint32), want[0][1].view(np.uint32))
+        assert len(seen) >= 3
+        assert ix.stats()["resident_bytes"] > 0                  # the automatic share of a small index: all of its whole chunks
+        if ib == 1 and qb == 4 and dim % 128 == 0:
+            ix.set_option("resident_mb", 2)
+            ix.set_option("sweep_share", 32)
+            idx, sc, cnt = ix.search_batch(qq, qc, qb, sim, k)
+            for q in range(nq):
+                np.testing.assert_array_equal(idx[q], want[q][0])
+            ix.set_option("sweep_share", 1)
+    finally:
+        ix.close()
