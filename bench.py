@@ -223,8 +223,9 @@ def time_steps(ix, batches, QB, SIM, k):
 # the sweeps keep a prefix of the index in the 256 MiB Infinity Cache (library option resident_mb, bbq_stats.resident_bytes)
 RESIDENT_NOTE = ("achieved = ALGORITHMIC bytes per second against the HBM peak; cache_resident_bytes of the index are loaded with the default "
                  "cache policy and stay in the 256 MiB Infinity Cache between the sweeps of successive queries, the rest is streamed with "
-                 "non-temporal loads: the resident part's re-reads do not reach HBM (PMC traffic < algorithmic bytes), and an index "
-                 "that fits entirely is bounded by the cache's delivery rate, not by HBM")
+                 "non-temporal loads: the resident part's re-reads do not reach HBM, and an index that fits entirely is bounded by "
+                 "the cache's delivery rate, not by HBM.  `traffic` (FETCH_SIZE x2 + WRITE_SIZE) counts the bytes that left the L2s; the "
+                 "Infinity Cache sits behind that counter, so traffic stays ~= the algorithmic bytes and is an upper bound of the HBM bytes")
 
 
 def config_leg(B, torch, name, N, dim, k, QB, IB, sim_name, device, steps, warmup, Q, slots, replay_threads, parity=True):
