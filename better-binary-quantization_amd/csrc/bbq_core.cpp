@@ -214,10 +214,10 @@ namespace {
 // 57 K with 96-128; at 10 M rows 32 is as good as 64 and needs half the workspace).  A call should also be cut into at least four
 // sub-batches where it can: the first sub-batch's small segments run alone on the device and only the later ones hide theirs behind
 // another sub-batch's large sweep (1 M rows x 256 queries per call: 0.849 of the roofline end to end with 2 x 128, 0.855 with 4 x 64)
-// The view a launch gets: the stored view + how much of the index is loaded cache-resident.  The indexes that have launched sweeps
-// on the device lately (kCacheWindow) share its 256 MiB Infinity Cache: each keeps a prefix in proportion to its size
-// (resident_mb >= 0: that many MiB, whatever else is there).  Called with the device context locked.
-constexpr int64_t kResidentAutoBytes = 224ll << 20;  // measured: 10 M x 768 gains up to 256 MiB, a 260 MB index kept whole gains nothing (248 MiB resident: all of the gain lost)
+// The view a launch gets: the stored view + which chunks it loads cache-resident.  The indexes that have launched sweeps on the device
+// lately (kCacheWindow) share its 256 MiB Infinity Cache in proportion to their sizes (resident_mb >= 0: that many MiB per launch,
+// whatever else is there).  Called with the device context locked.
+constexpr int64_t kResidentAutoBytes = 224ll << 20;  // per launch; measured: 192 / 224 / 240 MiB within noise of each other at 10 M x 768, a resident set of 248 MiB gains nothing
 constexpr uint64_t kCacheWindow = 100'000'000;  // ns: an index that has launched nothing for 0.1 s is not competing for the cache
 static int64_t cache_sharers_bytes(bbq_index *ix, int64_t own) {
   DeviceCtx *c = ix->ctx;
@@ -235,15 +235,36 @@ static int64_t cache_sharers_bytes(bbq_index *ix, int64_t own) {
   if (!found) { c->cache_users.push_back({ix, own, now}); all += own; }
   return all;
 }
-static IndexView launch_view(bbq_index *ix, const Storage &sto) {
+// One launch sweeps chunks [chunk_begin, chunk_begin + n_chunks) of `sto` once per query of its sub-batch, back to back: what it can
+// keep in the cache is a part of ITS range (the launches of a sub-batch run one after the other, each over its own rows).
+static IndexView launch_view(bbq_index *ix, const Storage &sto, int64_t chunk_begin = 0, int64_t n_chunks = -1) {
   IndexView v = sto.view;
-  const int64_t tiles = (v.n_rows + kTileRows - 1) / kTileRows;
-  const int64_t own = ((ix->main.view.n_rows + kTileRows - 1) / kTileRows) * (int64_t)ix->main.view.tile_stride;
+  const int64_t all_chunks = sto.n_chunks();
+  if (n_chunks < 0) n_chunks = all_chunks - chunk_begin;
+  const int64_t chunk_bytes = (int64_t)kTilesPerChunk * v.tile_stride;
+  const int64_t own = ix->main.n_chunks() * (int64_t)kTilesPerChunk * ix->main.view.tile_stride;
   const int64_t all = std::max<int64_t>(1, cache_sharers_bytes(ix, own));
   const int64_t budget = ix->opt_resident_mb >= 0 ? ((int64_t)ix->opt_resident_mb << 20)
-                                                  : (int64_t)((double)kResidentAutoBytes * ((double)own / (double)all));
-  v.resident_tiles = std::min(tiles, budget / std::max(1, v.tile_stride)) / kTilesPerChunk * kTilesPerChunk;  // decided per chunk (workgroup)
-  if (&sto == &ix->main) ix->stats.resident_bytes = v.resident_tiles * (int64_t)v.tile_stride;
+                                            : (int64_t)((double)kResidentAutoBytes * ((double)own / (double)all));
+  const int64_t fit = std::min(n_chunks, budget / std::max<int64_t>(1, chunk_bytes));  // chunks of this launch's range that stay resident
+  int64_t resident_chunks;
+  if (fit >= n_chunks) {  // everything this launch reads
+    v.resident_share = -1;
+    v.resident_tiles = (chunk_begin + n_chunks) * kTilesPerChunk;
+    resident_chunks = n_chunks;
+  } else if (ix->opt_resident_interleave && n_chunks >= 64) {  // of every 64 chunks the first `share`: cache and HBM deliver side by side
+    v.resident_share = fit * 64 / n_chunks;  // rounded down: never more than the budget
+    v.resident_tiles = 0;
+    resident_chunks = n_chunks * v.resident_share / 64;
+  } else {  // the first chunks of the range
+    v.resident_share = -1;
+    v.resident_tiles = (chunk_begin + fit) * kTilesPerChunk;
+    resident_chunks = fit;
+  }
+  if (&sto == &ix->main && n_chunks >= ix->stat_range_chunks) {  // reported for the largest launch of the call
+    ix->stat_range_chunks = n_chunks;
+    ix->stats.resident_bytes = resident_chunks * chunk_bytes;
+  }
   return v;
 }
 
@@ -689,7 +710,7 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const 
   for (const Segment &g : p.segs) {
     const Storage &sto = g.storage == 0 ? ix->pilot : ix->main;
     ScanArgs a{};
-    a.idx = launch_view(ix, sto);
+    a.idx = launch_view(ix, sto, g.chunk_begin, g.n_chunks);
     a.qplanes = reinterpret_cast<const uint4 *>(s.d_qbuf);
     a.qparams = reinterpret_cast<const QueryParams *>(s.d_qbuf + (size_t)nq * qb);
     a.chunk_begin = g.chunk_begin;
@@ -1417,6 +1438,7 @@ static int search_batch_impl(bbq_index *ix, int32_t n_queries, const uint8_t *qq
     ix->stats.candidates = 0;
     ix->stats.dense_fallbacks = 0;
     ix->stats.host_replays = 0;
+    ix->stat_range_chunks = 0;
     if (ix->n_rows == 0) return BBQ_OK;
     return multi_search_batch(ix, n_queries, qquant, qcorr, query_bits, sim, k, out_idx, out_score, out_n);
   }
@@ -1429,6 +1451,7 @@ static int search_batch_impl(bbq_index *ix, int32_t n_queries, const uint8_t *qq
   ix->stats.candidates = 0;
   ix->stats.dense_fallbacks = 0;
   ix->stats.host_replays = 0;
+  ix->stat_range_chunks = 0;
   if (ix->n_rows == 0) return BBQ_OK;
 
   BatchCtx c{ix, qquant, qcorr, 0, query_bits == 1 ? 1 : 0, sim, k};
@@ -1778,6 +1801,7 @@ int bbq_reset_stats(bbq_index *ix) {
   if (!ix) return fail(BBQ_ERR_INVALID_ARG, "bbq_reset_stats: null");
   if (ix->multi) return multi_reset_stats(ix);
   ix->stats = bbq_stats{};
+  ix->stat_range_chunks = 0;
   return BBQ_OK;
 }
 
@@ -1789,6 +1813,7 @@ int bbq_set_option(bbq_index *ix, const char *name, int64_t v) {
   else if (n == "pipeline_slots" && v >= 1 && v <= kMaxSlots) ix->opt_slots = (int)v;
   else if (n == "segment_growth" && v >= 2 && v <= 1024) { ix->opt_growth = (int)v; ix->plan.k = -1; }
   else if (n == "first_segment_rows" && v >= 1024 && v <= 8192 && v % kChunkRows == 0) { ix->opt_s0 = v; ix->plan.k = -1; }
+  else if (n == "resident_interleave" && (v == 0 || v == 1)) ix->opt_resident_interleave = (int)v;
   else if (n == "resident_mb" && v >= -1 && v <= 1 << 20) ix->opt_resident_mb = (int)v;
   else if (n == "replay_threads" && v >= 1 && v <= 256) ix->opt_replay_threads = (int)v;
   else if (n == "force_dense" && (v == 0 || v == 1)) ix->opt_force_dense = (int)v;

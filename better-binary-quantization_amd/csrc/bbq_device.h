@@ -58,8 +58,10 @@ struct IndexView {
   int32_t dim;
   int32_t layout;
   int32_t store_bits;   // 1: packed 1-bit rows; 2 / 4 / 8: multi-bit fields (indexBits 2 / 3-4 / 5-8)
-  int64_t resident_tiles;  // tiles [0, resident_tiles) are loaded with the default cache policy (they stay in the 256 MiB Infinity Cache
-                           // from one query's sweep to the next), the rest with non-temporal loads (streamed, read once per sweep)
+  // cache residency of a launch (launch_view(), bbq_core.cpp): the chunks read with the default cache policy - they stay in the 256 MiB
+  // Infinity Cache from one query's sweep to the next - the others are streamed with non-temporal loads
+  int64_t resident_tiles;  // resident_share < 0: chunks whose first tile is below this
+  int64_t resident_share;  // >= 0: chunk c is resident iff (c & 63) < resident_share (the resident chunks spread over the whole sweep)
   int64_t nt_delta;        // always 0.  The streamed loads add it to their address so that the compiler sees two different addresses
                            // in the two branches: it merges loads that differ only in the cache policy into ONE plain load
 };

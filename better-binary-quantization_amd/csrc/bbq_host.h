@@ -184,8 +184,10 @@ struct bbq_index {
   // walk the index in fewer, faster-growing segments (more candidates per query - the device selects the answer itself anyway)
   int opt_latency_queries = 4, opt_latency_growth = 64;
   int opt_latency_append = 1;  // 0: calls with few queries keep the chunk slots (and the finalize launches their compaction)
-  int opt_resident_mb = -1;  // MiB of the index (from row 0) loaded with the default cache policy so that they stay in the Infinity Cache between
-                             // sweeps (IndexView::resident_tiles); -1: the whole index when it fits (kResidentAutoBytes), else none
+  int64_t stat_range_chunks = 0;  // chunks of the largest launch of the current call (bbq_stats.resident_bytes is that launch's)
+  int opt_resident_interleave = 1;  // the resident chunks of a launch are spread over its range (of every 64 chunks the first n) instead of being its head
+  int opt_resident_mb = -1;  // MiB of its row range that ONE sweep launch loads with the default cache policy, so that they stay in the Infinity
+                             // Cache from one query's sweep to the next (launch_view(), bbq_core.cpp); -1: this index's share of kResidentAutoBytes
   int opt_latency_presample = 1;  // ... and on large indexes get their threshold from per-wave top keys of a prefix (two small launches) instead of two scan / finalize pairs
   int opt_latency_fused = 1;  // single-query calls take the three-launch latency path (bbq_latency_kernels.hip) when the index shape has one
   int opt_append_last = 1;  // append mode also for the last (largest) segment: its finalize launch gets cheaper, its sweep slower (one

@@ -26,8 +26,8 @@ template <class T> __device__ __forceinline__ const T *stream_ptr(const T *p, in
 // the compiler merges the loads of two branches that differ only in the cache policy into ONE plain load (also through a phi of
 // the two addresses): the streamed branch is fenced with compiler barriers, which its loads cannot be hoisted or sunk across
 #define BBQ_BRANCH_FENCE() asm volatile("" ::: "memory")
-__device__ __forceinline__ bool chunk_is_resident(int64_t chunk, int64_t resident_tiles) {
-  return chunk * kTilesPerChunk < resident_tiles;  // resident_tiles is a multiple of kTilesPerChunk; chunk comes from blockIdx: scalar
+__device__ __forceinline__ bool chunk_is_resident(int64_t chunk, const IndexView &v) {  // chunk comes from blockIdx: scalar
+  return v.resident_share >= 0 ? (chunk & 63) < v.resident_share : chunk * kTilesPerChunk < v.resident_tiles;
 }
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) 
     const uint8_t *__restrict__ cr = tp + (size_t)w16 * (kTileRows * 16);
     const int64_t row = tile * kTileRows + lane;
     const bool valid = row < a.idx.n_rows;
-    const bool resident = chunk_is_resident(chunk, a.idx.resident_tiles);
+    const bool resident = chunk_is_resident(chunk, a.idx);
 
     // every load of the tile is issued up front: the row's code chunks and its corrections
     f64x2 lu = {0.0, 0.0};
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_shared_kernel(const ScanA
     f64x2 lu = {0.0, 0.0};
     double xadd = 0.0, x1 = 0.0, al = 0.0, au = 0.0, aadd = 0.0;
     uint32_t cw = 0;
-    load_tile<W, COMPACT ? 1 : 2>(tp, lane, a.idx.has_x1 != 0, chunk_is_resident(chunk, a.idx.resident_tiles), a.idx.nt_delta, c, cw, lu, xadd, x1);
+    load_tile<W, COMPACT ? 1 : 2>(tp, lane, a.idx.has_x1 != 0, chunk_is_resident(chunk, a.idx), a.idx.nt_delta, c, cw, lu, xadd, x1);
     bool have_exact = !COMPACT;
     if constexpr (COMPACT) {
       al = (double)__uint_as_float(cw << 16);

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kLatThreads) void bbq_lat_scan_kernel(const LatScan
     double xadd = 0.0, x1 = 0.0;
     uint32_t cpk0 = 0, cpk1 = 0;
     u32x4 c[W];
-    load_tile<W, COMPACT ? 1 : 2>(tp, lane, a.idx.has_x1 != 0, chunk_is_resident(chunk, a.idx.resident_tiles), a.idx.nt_delta, c, cpk0, lu, xadd, x1);
+    load_tile<W, COMPACT ? 1 : 2>(tp, lane, a.idx.has_x1 != 0, chunk_is_resident(chunk, a.idx), a.idx.nt_delta, c, cpk0, lu, xadd, x1);
     if constexpr (COMPACT) cpk1 = __float_as_uint(a.idx.add_range[tile * 2 + (p.sim == 0 ? 0 : 1)]);
     uint32_t acc[QB], ones, qc = 0;
     tile_popcounts<QB, W>(c, s_planes, acc, ones);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kLatThreads) void bbq_lat_pre_kernel(const LatPreAr
     uint32_t unused = 0;
     u32x4 c[W];
     // the prefix the threshold is sampled from is also the part of the index that stays cache-resident
-    load_tile<W, COMPACT ? 0 : 2>(tp, lane, a.idx.has_x1 != 0, chunk_is_resident((int64_t)blockIdx.x, a.idx.resident_tiles), a.idx.nt_delta, c, unused, lu, xadd, x1);
+    load_tile<W, COMPACT ? 0 : 2>(tp, lane, a.idx.has_x1 != 0, chunk_is_resident((int64_t)blockIdx.x, a.idx), a.idx.nt_delta, c, unused, lu, xadd, x1);
     if constexpr (COMPACT) {
       const f64x2 *__restrict__ ex = reinterpret_cast<const f64x2 *>(a.idx.exact + (valid ? row : 0) * 4);
       lu = BBQ_STREAM_LOAD(ex);

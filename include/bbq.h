@@ -386,15 +386,16 @@ typedef struct {
   int64_t total_scan_launches;
   int64_t host_replays;       /* queries of the last call whose heap was replayed on the host (equal scores in or at the edge of the
                                  answer, k > 1024, device_select 0); the others were selected and sorted by the last finalize launch */
-  int64_t resident_bytes;     /* bytes of the index (from row 0) that the sweeps load with the default cache policy, so that they stay
-                                 in the device's 256 MiB Infinity Cache from one query's sweep to the next (option resident_mb); the
-                                 rest is streamed with non-temporal loads.  Their re-reads do not reach HBM */
+  int64_t resident_bytes;     /* bytes of its row range that the LARGEST sweep launch of the last call loaded with the default cache policy,
+                                 so that they stay in the device's 256 MiB Infinity Cache from one query's sweep to the next (option
+                                 resident_mb); the rest is streamed with non-temporal loads.  Their re-reads do not reach HBM */
 } bbq_stats;
 int bbq_get_stats(bbq_index *idx, bbq_stats *out);
 int bbq_reset_stats(bbq_index *idx);
 /* tuning knobs; returns BBQ_ERR_INVALID_ARG for unknown names or values out of range (DESIGN.md "Knobs"):
  *   batch_queries 0..1024 (0 = by index size: 32 from 6 M rows, 64 from 2.5 M, 128 below)   pipeline_slots 1..4 (3)   segment_growth 2..1024 (8)   first_segment_rows 1024..8192 (4096)
- *   resident_mb -1..2^20 (-1: this index's share of 256 MiB, by size among the searched indexes of its device; 0: stream everything)
+ *   resident_mb -1..2^20 (MiB of its row range a sweep launch keeps cache-resident; -1: this index's share of 224 MiB, by size among the
+ *     indexes active on its device; 0: stream everything)   resident_interleave 0|1 (1: the resident chunks are spread over the range)
  *   replay_threads 1..256 (half the host cores, at most 16)   flood_rows 0..2^24 (262144)   force_dense 0|1 (0)
  *   sweep_share 1|4|8|32 (1: every query sweeps the index itself; 32: shared sweep on the matrix cores)
  *   device_select 0|1 (1: for k <= 1024 the device selects and sorts the answer itself whenever no two scores in or at the edge of it
