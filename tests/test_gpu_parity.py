@@ -1402,10 +1402,10 @@ def test_search_raw_batch_equals_quantize_then_search(sim, qb, nq):
 
 @pytest.mark.parametrize("dim,qb,sim,compact,ib", [(768, 4, 1, True, 1), (1024, 1, 2, False, 1), (1536, 4, 0, True, 1), (200, 4, 1, True, 1),
                                                    (1024, 8, 1, True, 2), (256, 4, 1, True, 4)])
-def test_cache_resident_prefix_changes_no_answer(dim, qb, sim, compact, ib):
+def test_cache_resident_chunks_change_no_answer(dim, qb, sim, compact, ib):
     """the sweeps load a prefix of the index with the default cache policy (it stays in the Infinity Cache from one query's sweep to the
-    next) and stream the rest (option resident_mb, IndexView::resident_tiles): every split - nothing, one chunk, a part, everything,
-    the automatic share - gives the oracle's answer for batches, single queries and the shared sweep; bbq_stats.resident_bytes
+    next) and stream the rest (option resident_mb per sweep launch, IndexView::resident_share / resident_tiles): every split - nothing,
+    a few chunks, a part, everything, the automatic share; spread over the launch's range or at its head - gives the oracle's answer for batches, single queries and the shared sweep; bbq_stats.resident_bytes
     reports the split"""
     rng = np.random.default_rng(dim + qb + sim)
     n, k, nq = 70_000, 50, 9
@@ -1444,8 +1444,9 @@ def test_cache_resident_prefix_changes_no_answer(dim, qb, sim, compact, ib):
         row_bytes = ix.bytes_per_row
         index_bytes = (n + 63) // 64 * 64 * row_bytes
         seen = set()
-        for mb in (0, 1, 3, 1 << 20, -1):
+        for mb, spread in ((0, 1), (1, 1), (1, 0), (3, 1), (3, 0), (1 << 20, 1), (-1, 0), (-1, 1)):
             ix.set_option("resident_mb", mb)
+            ix.set_option("resident_interleave", spread)    # the resident chunks spread over a launch's range / at its head
             idx, sc, cnt = ix.search_batch(qq, qc, qb, sim, k)
             for q in range(nq):
                 np.testing.assert_array_equal(idx[q], want[q][0])
