@@ -472,6 +472,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the sharded code path (process group, collectives) even with one rank")
     ap.add_argument("--no-configs", action="store_true", help="skip the short legs of BASELINE configs 2, 4 and 5 (default run on one GPU only)")
     ap.add_argument("--no-napi", action="store_true", help="skip the Node/N-API leg (the drop-in boundary driven from node at the timed size)")
+    ap.add_argument("--no-hbm-only", action="store_true", help="skip the leg that repeats the timed step with nothing kept in the Infinity Cache")
     ap.add_argument("--no-raw", action="store_true", help="skip the raw-query leg (query quantization inside the timed region)")
     ap.add_argument("--quantize-threads", type=int, default=16, help="host threads of bbq_quantize_queries in the raw-query leg")
     ap.add_argument("--inprocess-shards", type=int, default=4,
@@ -686,6 +687,27 @@ def main():
                "what": "the same step from raw fp32 queries through bbq_search_raw_batch: normalise + quantizeQueryVector on host threads, chunk by chunk, "
                        "while the sub-batches in front are already on the device, + sweep + top-k"}
 
+    hbm_only = None
+    if dist is None and not args.no_hbm_only and not any(o.startswith("resident_mb=") for o in args.opt):
+        # the same timed step with NOTHING kept in the Infinity Cache (resident_mb 0: every byte of every sweep streamed from HBM with
+        # non-temporal loads): the figure the HBM roofline in its strict sense applies to, next to the default above
+        ix.set_option("resident_mb", 0)
+        time_steps(ix, batches[:1], QB, SIM, k)
+        ix.reset_stats()
+        dth, res_h = time_steps(ix, batches[args.warmup:], QB, SIM, k)
+        sth = ix.stats()
+        lb = sth["total_scan_bytes"] / max(sth["total_scan_launches"], 1)
+        lm = sth["total_scan_ms"] / max(sth["total_scan_launches"], 1)
+        hbm_only = {"value": args.steps * Q / dth, "unit": "queries/s", "ms_per_step": dth / args.steps * 1e3,
+                    "end_to_end_hbm_frac": (args.steps * Q / dth) * N * bytes_per_row / 1e9 / HBM_PEAK_GBS,
+                    "roofline_frac_dominant_launch": (lb / (lm * 1e-3) / 1e9 / HBM_PEAK_GBS) if lm > 0 else None,
+                    "cache_resident_bytes": sth["resident_bytes"],
+                    "identical_to_default": bool((res_h[0][0] == results[args.warmup][0]).all() and
+                                                 (res_h[0][1].view(np.uint32) == results[args.warmup][1].view(np.uint32)).all()),
+                    "what": "library option resident_mb=0: no part of the index is kept in the Infinity Cache between sweeps"}
+        ix.set_option("resident_mb", -1)
+        time_steps(ix, batches[:1], QB, SIM, k)    # warm the cache again for the legs below
+
     inproc = None
     if dist is None and args.inprocess_shards > 1:
         # the in-process multi-device index (what the TS host uses, bbq_index_create_multi) with every shard on THIS GPU: the same
@@ -785,6 +807,8 @@ def main():
             out["batched"] = batched
         if raw is not None:
             out["raw_queries"] = raw
+        if hbm_only is not None:
+            out["hbm_only"] = hbm_only
         if inproc is not None:
             out["inprocess_multi"] = inproc
         if world == 1 and dist is None and not args.no_napi and IB == 1:

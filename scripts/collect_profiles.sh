@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/rp_kt /tmp/rp_f /tmp/rp_w
-COMMON="--no-recall --no-cpu-baseline --no-parity --latency-calls 0 --shared-sweep 0 --no-configs --no-napi --no-raw --inprocess-shards 0"
+COMMON="--no-recall --no-cpu-baseline --no-parity --latency-calls 0 --shared-sweep 0 --no-configs --no-napi --no-raw --no-hbm-only --inprocess-shards 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_kt -- python3 $R/bench.py "$@" --steps 3 --warmup 1 $COMMON > $OUT/bench_under_trace.json 2> $OUT/trace.err || exit 1
 cp $(ls /tmp/rp_kt/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 cp $(ls /tmp/rp_kt/*/*kernel_trace.csv | head -1) $OUT/kernel_trace_full.csv

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/${1:-gpurun_out/ea_latency}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-COMMON="--no-recall --no-cpu-baseline --no-parity --latency-calls 0 --shared-sweep 0 --no-configs --no-napi --no-raw --inprocess-shards 0"
+COMMON="--no-recall --no-cpu-baseline --no-parity --latency-calls 0 --shared-sweep 0 --no-configs --no-napi --no-raw --no-hbm-only --inprocess-shards 0"
 for spec in ${2:-0:0 0:224 0:448 0:640 1:224 1:448}; do
   il=${spec%%:*}; mb=${spec##*:}
   rm -rf /tmp/rp_ea

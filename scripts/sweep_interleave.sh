@@ -2,7 +2,7 @@
 # residency settings over index sizes: scripts/sweep_interleave.sh <outdir> "<rows list>" "<il:mb:smallpct list>"
 OUT=${1:-gpurun_out/interleave}
 mkdir -p "$OUT"
-COMMON="--no-cpu-baseline --no-recall --no-napi --no-raw --no-configs --no-parity --inprocess-shards 0 --latency-calls 100 --shared-sweep 0"
+COMMON="--no-cpu-baseline --no-recall --no-napi --no-raw --no-hbm-only --no-configs --no-parity --inprocess-shards 0 --latency-calls 100 --shared-sweep 0"
 for rows in ${2:-10000000 4000000 20000000}; do
   case $rows in c*) sel="--config $rows"; steps=32;; *) sel="--rows $rows"; steps=$(( 80000000 / rows )); [ $steps -lt 4 ] && steps=4;; esac
   for spec in ${3:-1:224:100 1:224:50 1:224:25 1:240:100 1:192:100 0:224:100 1:224:0}; do

@@ -3,7 +3,7 @@
 #   scripts/sweep_resident.sh <outdir> ["headline values"] ["c2 values"] ["c5 values"] ["c4 values"]
 OUT=${1:-gpurun_out/resident}
 mkdir -p "$OUT"
-COMMON="--no-cpu-baseline --no-recall --no-napi --no-raw --no-configs --no-parity --inprocess-shards 0 --latency-calls 100 --shared-sweep 0"
+COMMON="--no-cpu-baseline --no-recall --no-napi --no-raw --no-hbm-only --no-configs --no-parity --inprocess-shards 0 --latency-calls 100 --shared-sweep 0"
 for mb in ${2:-0 192 224 256 288 0 224}; do
   timeout -k 10 200 python bench.py $COMMON --steps 8 --warmup 2 --opt resident_mb=$mb > "$OUT/headline_$mb.json" 2> "$OUT/headline_$mb.err" || exit 1
   python -c "import json,sys; d=json.loads(open('$OUT/headline_$mb.json').read().strip().splitlines()[-1]); print('headline', $mb, round(d['value']), round(d['roofline']['frac'],4), d['latency']['p50_ms'])"
