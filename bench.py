@@ -304,7 +304,7 @@ def napi_leg(B, ix, centroid, dim, k, sim_name, SIM, QB, nq=512):
         jc = blob[nq * k * 8:].view(np.int32)
         same = bool((jc == gc).all() and (ji == gi).all() and (jsx == gs.view(np.uint32)).all())
         return {"value": js["batch_queries_per_s"], "unit": "queries/s", "call": "format.searchNearestNeighborsBatch(raw fp32 queries, values, k) through bbq_napi.node, %d queries per call" % nq,
-                "batch_ms_per_call": js["batch_ms_per_call"], "p50_ms": js["single_p50_ms"], "p99_ms": js["single_p99_ms"], "min_ms": js["single_min_ms"],
+                "batch_ms_per_call": js["batch_ms_per_call"], "batch_ms_per_call_inside_addon": js.get("batch_ms_per_call_inside_addon"), "p50_ms": js["single_p50_ms"], "p99_ms": js["single_p99_ms"], "min_ms": js["single_min_ms"],
                 "single_call": "format.searchNearestNeighbors(raw fp32 query, values, k): normalise + quantize + sweep + top-k per call (src/binaryQuantizationFormat.ts:308-412)",
                 "single_queries_per_s": js["single_queries_per_s"], "single_equals_batch": js["single_equals_batch"], "identical_to_ctypes": same,
                 "index": "loaded by the node process from the .veb/.vemb pair this process saved (%d rows)" % js["rows"], "load_ms": js["load_ms"], "node": js["node"]}

@@ -135,6 +135,9 @@ function shardDevices(rows) {
   return one;
 }
 
+/** time the batch call has spent inside the addon since the process started (tests/js/bench_scale.js prices the host's own share with it) */
+const hostClock = { insideAddonNs: 0n };
+
 function flatten(vectors, dim) {
   const flat = new Float32Array(vectors.length * dim);
   for (let i = 0; i < vectors.length; i++) flat.set(vectors[i], i * dim);
@@ -458,8 +461,10 @@ class BinaryQuantizationFormat {
     // searchNearestNeighbors normalises for COSINE and quantizeQueryVector normalises again (:337-347, :279-281); both happen behind
     // bbq_search_raw_batch, on host threads, chunk by chunk while the sub-batches in front are already on the device (one 768-d query
     // costs ~15 us on one core, more than its sweep of 1 M rows on the device)
+    const tNative = process.hrtime.bigint();
     const r = native.searchRawBatch(targetVectors._deviceIndex(), nq, flat, targetVectors.getCentroid(), sim, this.config.queryBits, q.lambda, q.iters,
       Number(process.env.BBQ_THREADS || 0), k);
+    hostClock.insideAddonNs += process.hrtime.bigint() - tNative;
     const out = new Array(nq), indices = r.indices, scores = r.scores, stride = r.stride;
     for (let i = 0; i < nq; i++) {
       const n = r.counts[i], base = i * stride, res = new Array(n);
@@ -833,5 +838,5 @@ module.exports = Object.assign({}, require('./helpers'), {
   normalizeVector, computeCentroid, computeDotProduct, computeEuclideanDistance, computeEuclideanSimilarity, computeMaximumInnerProduct,
   computeSimilarity, computeQuantizedDotProduct, computeInt4BitDotProduct: computeQuantizedDotProduct, computeInt1BitDotProduct: computeQuantizedDotProduct,
   deviceCount: native.deviceCount,
-  _native: native,
+  _native: native, _hostClock: hostClock,
 });

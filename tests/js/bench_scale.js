@@ -32,9 +32,13 @@ const loadMs = Number(process.hrtime.bigint() - t0) / 1e6;
 // ---- batch call shape (extension): every query still sweeps the index on its own
 let res = format.searchNearestNeighborsBatch(queries, values, k);   // warm-up: workspace allocation,
 res = format.searchNearestNeighborsBatch(queries, values, k);       // and the host's own loops compiled (the first calls run them interpreted)
+// how much of a call is spent inside the addon (bbq_search_raw_batch: quantize + sweeps + top-k), the rest being this host's own
+// work (flattening the queries, 51 K result objects per call, their garbage collection)
+const insideBefore = bbq._hostClock.insideAddonNs;
 t0 = process.hrtime.bigint();
 for (let r = 0; r < batchReps; r++) res = format.searchNearestNeighborsBatch(queries, values, k);
 const batchS = Number(process.hrtime.bigint() - t0) / 1e9;
+const nativeNs = bbq._hostClock.insideAddonNs - insideBefore;
 
 const idx = new Int32Array(nq * k), sc = new Float32Array(nq * k), cnt = new Int32Array(nq);
 for (let i = 0; i < nq; i++) {
@@ -59,7 +63,7 @@ ms.sort(function (a, b) { return a - b; });
 const stats = values.deviceStats();
 console.log(JSON.stringify({
   rows: values.size(), dim: values.dimension(), k: k, queries: nq, node: process.version, load_ms: loadMs,
-  batch_queries_per_s: nq * batchReps / batchS, batch_ms_per_call: batchS / batchReps * 1e3,
+  batch_queries_per_s: nq * batchReps / batchS, batch_ms_per_call: batchS / batchReps * 1e3, batch_ms_per_call_inside_addon: Number(nativeNs) / 1e6 / batchReps,
   single_p50_ms: ms[ms.length >> 1], single_p99_ms: ms[Math.min(ms.length - 1, Math.floor(ms.length * 0.99))], single_min_ms: ms[0],
   single_queries_per_s: 1e3 / (ms.reduce(function (a, b) { return a + b; }, 0) / ms.length),
   single_equals_batch: sameAsBatch, host_replays_last_call: stats.hostReplays,
