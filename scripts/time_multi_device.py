@@ -28,6 +28,15 @@ for name, make in (("single", lambda: B.Index(codes, corr, dim, 0.01)),
     for i in range(1, 4):
         res = ix.search_batch(qq[i * Q:(i + 1) * Q], qc[i * Q:(i + 1) * Q], 4, 1, k)
     dt = (time.perf_counter() - t0) / 3
+    by_round = {}
+    if name != "single":    # rounds of a call are pipelined: round r + 1 is swept while round r is merged
+        for rq in (128, 256, 512):
+            ix.set_option("round_queries", rq)
+            ix.search_batch(qq[:Q], qc[:Q], 4, 1, k)
+            tr = time.perf_counter()
+            for i in range(1, 4):
+                ix.search_batch(qq[i * Q:(i + 1) * Q], qc[i * Q:(i + 1) * Q], 4, 1, k)
+            by_round[rq] = round(Q / ((time.perf_counter() - tr) / 3))
     # the same three steps as ONE call: the multi-device handle pipelines its rounds (round r + 1 is swept while round r is merged)
     if name != "single":
         ix.set_option("round_queries", Q)
@@ -39,6 +48,6 @@ for name, make in (("single", lambda: B.Index(codes, corr, dim, 0.01)),
         ix.search(qq[i], qc[i], 4, 1, k)
     lat = (time.perf_counter() - t1) / 20
     out[name] = {"queries_per_s": round(Q / dt), "queries_per_s_three_steps_in_one_call": round(Q / dtp), "single_query_ms": round(lat * 1e3, 3),
-                 "host_replays": ix.stats()["host_replays"]}
+                 "host_replays": ix.stats()["host_replays"], "queries_per_s_by_round_queries": by_round}
     ix.close()
 print(out)
