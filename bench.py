@@ -221,8 +221,9 @@ def time_steps(ix, batches, QB, SIM, k):
 
 
 # the sweeps keep a prefix of the index in the 256 MiB Infinity Cache (library option resident_mb, bbq_stats.resident_bytes)
-RESIDENT_NOTE = ("achieved = ALGORITHMIC bytes per second against the HBM peak; cache_resident_bytes of the index are loaded with the default "
-                 "cache policy and stay in the 256 MiB Infinity Cache between the sweeps of successive queries, the rest is streamed with "
+RESIDENT_NOTE = ("achieved = ALGORITHMIC bytes per second against the HBM peak; cache_resident_bytes_per_sweep of the bytes one query sweeps "
+                 "(every scan launch of a sub-batch keeps up to 224 MiB of ITS row range) are loaded with the default cache policy and stay "
+                 "in the 256 MiB Infinity Cache between the sweeps of successive queries, the rest is streamed with "
                  "non-temporal loads: the resident part's re-reads do not reach HBM, and an index that fits entirely is bounded by "
                  "the cache's delivery rate, not by HBM.  `traffic` (FETCH_SIZE x2 + WRITE_SIZE) counts the bytes that left the L2s; the "
                  "Infinity Cache sits behind that counter, so traffic stays ~= the algorithmic bytes and is an upper bound of the HBM bytes")
@@ -259,7 +260,7 @@ def config_leg(B, torch, name, N, dim, k, QB, IB, sim_name, device, steps, warmu
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "bytes_per_launch": launch_bytes, "avg_launch_ms": launch_ms, "launches_timed": st["total_scan_launches"],
                         "how": "HIP events around the largest-segment launch on its own stream",
-                        "cache_resident_bytes": st["resident_bytes"], "cache_resident_frac_of_index": st["resident_bytes"] / float(N * bpr),
+                        "cache_resident_bytes_per_sweep": st["resident_bytes"], "cache_resident_frac_of_sweep": st["resident_bytes"] / float(N * bpr),
                         "note": RESIDENT_NOTE},
            "end_to_end_hbm_frac": qps * N * bpr / 1e9 / HBM_PEAK_GBS, "host_replays": st["host_replays"], "dense_fallbacks": st["dense_fallbacks"],
            "build_s": round(build_s, 1)}
@@ -791,8 +792,8 @@ def main():
                          "frac_hipevent": achieved / HBM_PEAK_GBS, "frac_rocprof_avg": frac_rocprof, "rocprof_source": rocprof_src,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "bbq_scan_kernel (largest segment launch)",
                          "bytes_per_launch": launch_bytes, "avg_launch_ms": launch_ms, "launches_timed": st["total_scan_launches"],
-                         "cache_resident_bytes": st["resident_bytes"],
-                         "cache_resident_frac_of_index": st["resident_bytes"] / float(max(1, (N // world) * bytes_per_row)), "note": RESIDENT_NOTE},
+                         "cache_resident_bytes_per_sweep": st["resident_bytes"],
+                         "cache_resident_frac_of_sweep": st["resident_bytes"] / float(max(1, (N // world) * bytes_per_row)), "note": RESIDENT_NOTE},
             "ranks": dist.get_world_size() if dist is not None else 1, "backend": (dist.get_backend() if dist is not None else None),
             "end_to_end_hbm_frac": (qps * (N / world) * bytes_per_row / 1e9) / HBM_PEAK_GBS,
             "candidates_per_query": st["candidates"] / float(Q) if dist is None else None,

@@ -261,10 +261,7 @@ static IndexView launch_view(bbq_index *ix, const Storage &sto, int64_t chunk_be
     v.resident_tiles = (chunk_begin + fit) * kTilesPerChunk;
     resident_chunks = fit;
   }
-  if (&sto == &ix->main && n_chunks >= ix->stat_range_chunks) {  // reported for the largest launch of the call
-    ix->stat_range_chunks = n_chunks;
-    ix->stats.resident_bytes = resident_chunks * chunk_bytes;
-  }
+  ix->sweep_resident_acc += resident_chunks * chunk_bytes;  // the caller books it per sweep of the index (bbq_stats.resident_bytes)
   return v;
 }
 
@@ -707,10 +704,12 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const 
   const bool append = use_final && p.latency && ix->opt_latency_append && !ix->has_pilot && ix->opt_share == 1;
   s.appended = append || (use_mfma && !d_lists_ext);
   s.timed = false;
+  ix->sweep_resident_acc = 0;
   for (const Segment &g : p.segs) {
     const Storage &sto = g.storage == 0 ? ix->pilot : ix->main;
     ScanArgs a{};
     a.idx = launch_view(ix, sto, g.chunk_begin, g.n_chunks);
+    ix->stats.resident_bytes = ix->sweep_resident_acc;  // of one query's sweep over all segments (complete after the last one)
     a.qplanes = reinterpret_cast<const uint4 *>(s.d_qbuf);
     a.qparams = reinterpret_cast<const QueryParams *>(s.d_qbuf + (size_t)nq * qb);
     a.chunk_begin = g.chunk_begin;
@@ -1108,7 +1107,9 @@ int search_latency_presampled(const BatchCtx &c, const BatchCtx &cs, int32_t *ou
     s.ctrl_clean = true;
   }
   LatScanArgs a{};
+  ix->sweep_resident_acc = 0;
   a.idx = launch_view(ix, ix->main);
+  ix->stats.resident_bytes = ix->sweep_resident_acc;  // the one sweep over all rows
   a.row_id_base = ix->main.row_id_base;
   a.theta = s.d_theta;
   a.flags = s.d_flags;
@@ -1438,7 +1439,6 @@ static int search_batch_impl(bbq_index *ix, int32_t n_queries, const uint8_t *qq
     ix->stats.candidates = 0;
     ix->stats.dense_fallbacks = 0;
     ix->stats.host_replays = 0;
-    ix->stat_range_chunks = 0;
     if (ix->n_rows == 0) return BBQ_OK;
     return multi_search_batch(ix, n_queries, qquant, qcorr, query_bits, sim, k, out_idx, out_score, out_n);
   }
@@ -1451,7 +1451,6 @@ static int search_batch_impl(bbq_index *ix, int32_t n_queries, const uint8_t *qq
   ix->stats.candidates = 0;
   ix->stats.dense_fallbacks = 0;
   ix->stats.host_replays = 0;
-  ix->stat_range_chunks = 0;
   if (ix->n_rows == 0) return BBQ_OK;
 
   BatchCtx c{ix, qquant, qcorr, 0, query_bits == 1 ? 1 : 0, sim, k};
@@ -1801,7 +1800,6 @@ int bbq_reset_stats(bbq_index *ix) {
   if (!ix) return fail(BBQ_ERR_INVALID_ARG, "bbq_reset_stats: null");
   if (ix->multi) return multi_reset_stats(ix);
   ix->stats = bbq_stats{};
-  ix->stat_range_chunks = 0;
   return BBQ_OK;
 }
 

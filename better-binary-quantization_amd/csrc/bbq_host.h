@@ -184,7 +184,7 @@ struct bbq_index {
   // walk the index in fewer, faster-growing segments (more candidates per query - the device selects the answer itself anyway)
   int opt_latency_queries = 4, opt_latency_growth = 64;
   int opt_latency_append = 1;  // 0: calls with few queries keep the chunk slots (and the finalize launches their compaction)
-  int64_t stat_range_chunks = 0;  // chunks of the largest launch of the current call (bbq_stats.resident_bytes is that launch's)
+  int64_t sweep_resident_acc = 0;  // cache-resident bytes of the launches of one sweep of the index, summed by launch_view()
   int opt_resident_interleave = 1;  // the resident chunks of a launch are spread over its range (of every 64 chunks the first n) instead of being its head
   int opt_resident_mb = -1;  // MiB of its row range that ONE sweep launch loads with the default cache policy, so that they stay in the Infinity
                              // Cache from one query's sweep to the next (launch_view(), bbq_core.cpp); -1: this index's share of kResidentAutoBytes

@@ -386,9 +386,10 @@ typedef struct {
   int64_t total_scan_launches;
   int64_t host_replays;       /* queries of the last call whose heap was replayed on the host (equal scores in or at the edge of the
                                  answer, k > 1024, device_select 0); the others were selected and sorted by the last finalize launch */
-  int64_t resident_bytes;     /* bytes of its row range that the LARGEST sweep launch of the last call loaded with the default cache policy,
-                                 so that they stay in the device's 256 MiB Infinity Cache from one query's sweep to the next (option
-                                 resident_mb); the rest is streamed with non-temporal loads.  Their re-reads do not reach HBM */
+  int64_t resident_bytes;     /* bytes of ONE query's sweep of the index (all launches of its sub-batch; pilot replica included) that are
+                                 loaded with the default cache policy, so that they stay in the device's 256 MiB Infinity Cache from one
+                                 query's sweep to the next (option resident_mb, per launch); the rest is streamed with non-temporal loads.
+                                 Their re-reads do not reach HBM */
 } bbq_stats;
 int bbq_get_stats(bbq_index *idx, bbq_stats *out);
 int bbq_reset_stats(bbq_index *idx);
