@@ -246,7 +246,10 @@ static IndexView launch_view(bbq_index *ix, const Storage &sto, int64_t chunk_be
   const int64_t all = std::max<int64_t>(1, cache_sharers_bytes(ix, own));
   const int64_t budget = ix->opt_resident_mb >= 0 ? ((int64_t)ix->opt_resident_mb << 20)
                                             : (int64_t)((double)kResidentAutoBytes * ((double)own / (double)all));
-  const int64_t fit = std::min(n_chunks, budget / std::max<int64_t>(1, chunk_bytes));  // chunks of this launch's range that stay resident
+  int64_t fit = std::min(n_chunks, budget / std::max<int64_t>(1, chunk_bytes));  // chunks of this launch's range that stay resident
+  // an index only a little larger than the budget: its launches are short and overlap (the small ones of the next sub-batch run beside
+  // the large one), so their resident sets must fit TOGETHER - the same share of every launch's range
+  if (own > budget && own <= budget + budget / 4 && ix->opt_resident_mb < 0) fit = std::min(n_chunks, (int64_t)((double)n_chunks * (double)budget / (double)own));
   int64_t resident_chunks;
   if (fit >= n_chunks) {  // everything this launch reads
     v.resident_share = -1;
