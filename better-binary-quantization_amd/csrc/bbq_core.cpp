@@ -209,11 +209,6 @@ int storage_from_device_rows(bbq_index *ix, Storage &st, const uint8_t *d_codes,
 
 namespace {
 
-// queries per launch sequence (sub-batch).  The largest sweep of a sub-batch should run for about a millisecond: shorter ones pay the
-// device's dependent-launch gaps and their own ramp (1.25 M rows x 2048 queries: 52.5 K q/s with 32 per sub-batch, 56.5 K with 64,
-// 57 K with 96-128; at 10 M rows 32 is as good as 64 and needs half the workspace).  A call should also be cut into at least four
-// sub-batches where it can: the first sub-batch's small segments run alone on the device and only the later ones hide theirs behind
-// another sub-batch's large sweep (1 M rows x 256 queries per call: 0.849 of the roofline end to end with 2 x 128, 0.855 with 4 x 64)
 // The view a launch gets: the stored view + which chunks it loads cache-resident.  The indexes that have launched sweeps on the device
 // lately (kCacheWindow) share its 256 MiB Infinity Cache in proportion to their sizes (resident_mb >= 0: that many MiB per launch,
 // whatever else is there).  Called with the device context locked.
@@ -268,6 +263,11 @@ static IndexView launch_view(bbq_index *ix, const Storage &sto, int64_t chunk_be
   return v;
 }
 
+// queries per launch sequence (sub-batch).  The largest sweep of a sub-batch should run for about a millisecond: shorter ones pay the
+// device's dependent-launch gaps and their own ramp (1.25 M rows x 2048 queries: 52.5 K q/s with 32 per sub-batch, 56.5 K with 64,
+// 57 K with 96-128; at 10 M rows 32 is as good as 64 and needs half the workspace).  A call should also be cut into at least four
+// sub-batches where it can: the first sub-batch's small segments run alone on the device and only the later ones hide theirs behind
+// another sub-batch's large sweep (1 M rows x 256 queries per call: 0.849 of the roofline end to end with 2 x 128, 0.855 with 4 x 64)
 int effective_batch(const bbq_index *ix, int64_t n_queries = 0) {
   if (ix->opt_batch > 0) return ix->opt_batch;
   const int64_t rows = ix->main.view.n_rows;
