@@ -1052,6 +1052,8 @@ def test_fuzz_shapes_options_vs_oracle(seed):
         ix.set_option("pipeline_slots", int(rng.choice([1, 2, 3])))
         ix.set_option("replay_threads", int(rng.choice([1, 4])))
         ix.set_option("sweep_share", int(rng.choice([1, 1, 4, 8, 32])))
+        ix.set_option("resident_mb", int(rng.choice([-1, -1, 0, 1, 2])))      # how much of a launch's range is read cache-resident
+        ix.set_option("resident_interleave", int(rng.integers(0, 2)))
         qs = [B.quantize_query(q, cen, sim, qb) for q in queries]
         qq, qc = np.stack([a for a, _ in qs]), np.stack([b for _, b in qs])
         for i in range(nq):
