@@ -2,6 +2,7 @@
 // query planes staged through LDS) with its work added step by step:
 //   0 popcounts only   1 + f64 score bound per row (35 f64 operations)   2 + threshold test, ballot, LDS append of the survivors
 //   3 + workgroup barrier at the end and one count word written per workgroup   4 + per-query parameters loaded from global memory
+//   5 + the tile's side value (plain load)   6 + 0.3 survivors per chunk that gather 32 B of exact corrections and are written out
 //   hipcc --offload-arch=gfx950 -O3 -o scan_steps scan_steps.hip && ./scan_steps
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -14,7 +15,8 @@ struct QP { double ay, ly, y1, qadd, cdp, dimd; int sim, one_bit, mip, pad; };
 
 template <int STEP>
 __global__ __launch_bounds__(512) void k(const u32x4 *__restrict__ p, unsigned n_chunks, const u32x4 *__restrict__ planes, const QP *__restrict__ qps,
-                                         const uint32_t *__restrict__ thetas, uint32_t *__restrict__ counts, uint64_t *__restrict__ entries, uint32_t *out) {
+                                         const uint32_t *__restrict__ thetas, uint32_t *__restrict__ counts, uint64_t *__restrict__ entries, uint32_t *out,
+                                         const float *__restrict__ add_range, const double *__restrict__ exact) {
   __shared__ u32x4 s_planes[24];
   __shared__ uint64_t s_ent[512];
   __shared__ uint32_t s_cnt;
@@ -34,6 +36,8 @@ __global__ __launch_bounds__(512) void k(const u32x4 *__restrict__ p, unsigned n
 #pragma unroll
   for (int j = 0; j < 6; ++j) v[j] = __builtin_nontemporal_load(tp + j * 64);
   const uint32_t cc = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(tp - lane + 6 * 64) + lane);
+  float addr_ = 0.f;
+  if (STEP >= 5) addr_ = add_range[((size_t)c * 8 + wave) * 2 + 1];   // per-tile side value, plain load, one address per wave
   uint32_t acc[4] = {0, 0, 0, 0}, ones = 0;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -58,6 +62,14 @@ __global__ __launch_bounds__(512) void k(const u32x4 *__restrict__ p, unsigned n
     ub32 = (float)(sc * (1.0 + 1e-9));
     r ^= __float_as_uint(ub32);
     pass = __float_as_uint(ub32) > theta;   // practically never
+    if (STEP >= 5) r ^= __float_as_uint(addr_);
+    // the library's survivors: about 0.3 rows per chunk pass the bound, gather their exact corrections (32 B, plain) and are emitted
+    if (STEP >= 6) pass = ((c * 2654435761u + (unsigned)q * 40503u + tid * 2246822519u) >> 7) % 1700u == 0u;
+    if (STEP >= 6 && pass) {
+      const double *ex = exact + ((size_t)c * 512 + tid) * 4;
+      const double e0 = ex[0], e1 = ex[1], e2 = ex[2];
+      ub32 = (float)(e0 + e1 + e2);
+    }
   }
   if (STEP >= 2) {
     const uint64_t m = __ballot(pass);
@@ -79,7 +91,7 @@ __global__ __launch_bounds__(512) void k(const u32x4 *__restrict__ p, unsigned n
 
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-struct Bufs { u32x4 *d, *planes; QP *qps; uint32_t *thetas, *counts, *out; uint64_t *entries; };
+struct Bufs { u32x4 *d, *planes; QP *qps; uint32_t *thetas, *counts, *out; uint64_t *entries; float *add_range; double *exact; };
 
 template <int STEP>
 static int run(const Bufs &b, size_t bytes, int reps, unsigned drop, const char *name) {
@@ -89,7 +101,7 @@ static int run(const Bufs &b, size_t bytes, int reps, unsigned drop, const char 
   float best = 1e9f, sum = 0;
   for (int it = 0; it < 7; ++it) {
     CHK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k<STEP>), dim3(n_chunks, reps), dim3(512), 0, 0, b.d, n_chunks, b.planes, b.qps, b.thetas, b.counts, b.entries, b.out);
+    hipLaunchKernelGGL((k<STEP>), dim3(n_chunks, reps), dim3(512), 0, 0, b.d, n_chunks, b.planes, b.qps, b.thetas, b.counts, b.entries, b.out, b.add_range, b.exact);
     CHK(hipEventRecord(e1));
     CHK(hipEventSynchronize(e1));
     float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
@@ -115,6 +127,8 @@ int main() {
   CHK(hipMalloc((void **)&b.counts, (size_t)64 * 22000 * 4));
   CHK(hipMalloc((void **)&b.entries, (size_t)64 * 22000 * 16 * 8));
   CHK(hipMalloc((void **)&b.out, 4)); CHK(hipMemset(b.out, 0, 4));
+  CHK(hipMalloc((void **)&b.add_range, (size_t)22000 * 8 * 2 * 4)); CHK(hipMemset(b.add_range, 0, (size_t)22000 * 8 * 2 * 4));
+  CHK(hipMalloc((void **)&b.exact, (size_t)22000 * 512 * 32)); CHK(hipMemset(b.exact, 0, (size_t)22000 * 512 * 32));
   for (size_t mb : {1000, 100}) {
     const size_t bytes = mb << 20;
     const int reps = mb == 1000 ? 8 : 40;
@@ -124,6 +138,8 @@ int main() {
       if (run<2>(b, bytes, reps, drop, "+ threshold, ballot, LDS append")) return 1;
       if (run<3>(b, bytes, reps, drop, "+ end barrier, count word per workgroup")) return 1;
       if (run<4>(b, bytes, reps, drop, "+ query parameters from global memory")) return 1;
+      if (run<5>(b, bytes, reps, drop, "+ per-tile side value (plain load)")) return 1;
+      if (run<6>(b, bytes, reps, drop, "+ 0.3 survivors per chunk: gather 32 B, emit")) return 1;
     }
   }
   return 0;
