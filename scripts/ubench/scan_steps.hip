@@ -64,10 +64,12 @@ __global__ __launch_bounds__(512) void k(const u32x4 *__restrict__ p, unsigned n
     pass = __float_as_uint(ub32) > theta;   // practically never
     if (STEP >= 5) r ^= __float_as_uint(addr_);
     // the library's survivors: about 0.3 rows per chunk pass the bound, gather their exact corrections (32 B, plain) and are emitted
-    if (STEP >= 6) pass = ((c * 2654435761u + (unsigned)q * 40503u + tid * 2246822519u) >> 7) % 1700u == 0u;
+    if (STEP >= 6) pass = ((c * 2654435761u + (unsigned)q * 40503u + tid * 2246822519u) >> 7) % (STEP >= 7 ? 155u : 1700u) == 0u;   // step 7, 8: 3.3 per chunk (the 1 M-row index)
     if (STEP >= 6 && pass) {
       const double *ex = exact + ((size_t)c * 512 + tid) * 4;
-      const double e0 = ex[0], e1 = ex[1], e2 = ex[2];
+      double e0, e1, e2;
+      if (STEP >= 8) { e0 = __builtin_nontemporal_load(ex); e1 = __builtin_nontemporal_load(ex + 1); e2 = __builtin_nontemporal_load(ex + 2); }
+      else { e0 = ex[0]; e1 = ex[1]; e2 = ex[2]; }
       ub32 = (float)(e0 + e1 + e2);
     }
   }
@@ -83,8 +85,13 @@ __global__ __launch_bounds__(512) void k(const u32x4 *__restrict__ p, unsigned n
   if (STEP >= 3) {
     __syncthreads();
     const uint32_t n = s_cnt;
-    for (uint32_t i = tid; i < n; i += 512) entries[((size_t)q * n_chunks + c) * 16 + (i & 15)] = s_ent[i];
-    if (tid == 0) counts[(size_t)q * n_chunks + c] = n;
+    if (STEP >= 8) {
+      for (uint32_t i = tid; i < n; i += 512) __builtin_nontemporal_store(s_ent[i], &entries[((size_t)q * n_chunks + c) * 16 + (i & 15)]);
+      if (tid == 0) __builtin_nontemporal_store(n, &counts[(size_t)q * n_chunks + c]);
+    } else {
+      for (uint32_t i = tid; i < n; i += 512) entries[((size_t)q * n_chunks + c) * 16 + (i & 15)] = s_ent[i];
+      if (tid == 0) counts[(size_t)q * n_chunks + c] = n;
+    }
   }
   if (r == 0x12345678u) atomicAdd(out, 1u);
 }
@@ -118,17 +125,28 @@ int main() {
   Bufs b;
   CHK(hipMalloc((void **)&b.d, cap));
   CHK(hipMemset(b.d, 0x5a, cap));
-  CHK(hipMalloc((void **)&b.planes, 64 * 24 * 16)); CHK(hipMemset(b.planes, 0x33, 64 * 24 * 16));
-  QP h[64];
-  for (int i = 0; i < 64; ++i) { h[i].ay = -0.15; h[i].ly = 0.02; h[i].y1 = 5760.0; h[i].qadd = -0.001; h[i].cdp = 0.0009; h[i].dimd = 768.0; h[i].sim = 1; h[i].one_bit = 0; h[i].mip = 0; h[i].pad = 0; }
+  CHK(hipMalloc((void **)&b.planes, 128 * 24 * 16)); CHK(hipMemset(b.planes, 0x33, 128 * 24 * 16));
+  QP h[128];
+  for (int i = 0; i < 128; ++i) { h[i].ay = -0.15; h[i].ly = 0.02; h[i].y1 = 5760.0; h[i].qadd = -0.001; h[i].cdp = 0.0009; h[i].dimd = 768.0; h[i].sim = 1; h[i].one_bit = 0; h[i].mip = 0; h[i].pad = 0; }
   CHK(hipMalloc((void **)&b.qps, sizeof h)); CHK(hipMemcpy(b.qps, h, sizeof h, hipMemcpyHostToDevice));
-  uint32_t th[64]; for (int i = 0; i < 64; ++i) th[i] = 0x7fffffffu;
+  uint32_t th[128]; for (int i = 0; i < 128; ++i) th[i] = 0x7fffffffu;
   CHK(hipMalloc((void **)&b.thetas, sizeof th)); CHK(hipMemcpy(b.thetas, th, sizeof th, hipMemcpyHostToDevice));
-  CHK(hipMalloc((void **)&b.counts, (size_t)64 * 22000 * 4));
-  CHK(hipMalloc((void **)&b.entries, (size_t)64 * 22000 * 16 * 8));
+  CHK(hipMalloc((void **)&b.counts, (size_t)128 * 22000 * 4));
+  CHK(hipMalloc((void **)&b.entries, (size_t)128 * 22000 * 16 * 8));
   CHK(hipMalloc((void **)&b.out, 4)); CHK(hipMemset(b.out, 0, 4));
   CHK(hipMalloc((void **)&b.add_range, (size_t)22000 * 8 * 2 * 4)); CHK(hipMemset(b.add_range, 0, (size_t)22000 * 8 * 2 * 4));
   CHK(hipMalloc((void **)&b.exact, (size_t)22000 * 512 * 32)); CHK(hipMemset(b.exact, 0, (size_t)22000 * 512 * 32));
+  {  // the library's large launch on the 1 M-row index: 1378 chunks starting at chunk 576, 128 queries; x extent as is / padded to 1384
+    Bufs o = b;
+    o.d = b.d + (size_t)576 * 51200 / 16;
+    if (run<6>(o, (size_t)1378 * 51200, 128, 0, "library geometry, 1378 chunks from chunk 576")) return 1;
+    if (run<6>(o, (size_t)1384 * 51200, 128, 0, "library geometry, padded to 1384 chunks")) return 1;
+    if (run<4>(o, (size_t)1384 * 51200, 128, 0, "library geometry, padded to 1384 chunks")) return 1;
+    if (run<7>(o, (size_t)1384 * 51200, 128, 0, "1384 chunks, 3.3 survivors per chunk, plain")) return 1;
+    if (run<8>(o, (size_t)1384 * 51200, 128, 0, "1384 chunks, 3.3 survivors per chunk, nt")) return 1;
+    if (run<7>(o, (size_t)1378 * 51200, 128, 0, "1378 chunks, 3.3 survivors per chunk, plain")) return 1;
+    if (run<8>(o, (size_t)1378 * 51200, 128, 0, "1378 chunks, 3.3 survivors per chunk, nt")) return 1;
+  }
   for (size_t mb : {1000, 100}) {
     const size_t bytes = mb << 20;
     const int reps = mb == 1000 ? 8 : 40;
