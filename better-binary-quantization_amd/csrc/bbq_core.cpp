@@ -861,7 +861,6 @@ int dense_scores_one(const BatchCtx &c, int64_t qi, float *out) {
   a.dense_score32 = ix->d_dense_all;
   a.dense_stride = n;
   // gridDim.x is limited to 2^31-1: fine for any index that fits in HBM
-  a.n_chunks = (int32_t)chunks;
   HIPCHK(launch_scan(a, c.planes, true, 1, (int)chunks, st));
   HIPCHK(hipMemcpyAsync(out, ix->d_dense_all, (size_t)n * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -1627,7 +1626,6 @@ int bbq_score_rows(bbq_index *ix, const uint8_t *qquant, const double *qcorr, in
     a.dense_qcdist = dqc;
     a.dense_score64 = d64;
     a.dense_stride = piece_rows;
-    a.n_chunks = (int32_t)nc;
     hipError_t e = launch_scan(a, c.planes, true, 1, (int)nc, st);
     const int64_t r0 = cb * kChunkRows, r1 = std::min((cb + nc) * kChunkRows, ix->main.view.n_rows);
     if (e == hipSuccess) e = hipMemcpyAsync(h32.data(), d32, (size_t)(r1 - r0) * 4, hipMemcpyDeviceToHost, st);

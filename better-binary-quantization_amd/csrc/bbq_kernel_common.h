@@ -3,7 +3,6 @@
 // order-statistic selection.  Everything here is __forceinline__: each kernel file gets its own copy.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <float.h>
 #include "bbq_device.h"
 
 #pragma clang fp contract(off)
@@ -175,73 +174,6 @@ __device__ __forceinline__ double score_upper_bound(double qc, double al, double
     u = t_up < 0.0 ? 1.0 / (1.0 - t_up / FBS) : t_up / FBS + 1.0;
   }
   return u + kRoundRel * (fabs(u) + 1.0);
-}
-
-// ---- the same bound as a TEST in "z-space" (the monotone argument of the similarity transform), for the sweeps -------------------
-// score_upper_bound() spends ~80 vector instructions per row (the transform with its division, the terms in the reference's order,
-// their magnitudes one by one), and the sweep is bound by vector issue whenever its bytes come out of a cache.  The test
-// "can this row's f32 score exceed the threshold score th" does not need the score:
-//   COSINE / MIP: z = s + xadd,  score = f(z + qadd - cdp), f non-decreasing;   EUCLIDEAN: z = 2 s - xadd, score = 1 / (1 + qadd - z)
-//   z_threshold(): zmin with  f32 score > th  =>  z > zmin   (inverse transform, once per workgroup)
-//   row_may_pass(): z_up >= z of the exact corrections, from s = al A + au B, B = ay x1 + ly qc, A = C0 - B, C0 = ay D + ly y1
-//     (the same s as ((t1 + t2) + t3) + t4 in exact arithmetic), the error terms of score_upper_bound() and a rounding allowance
-//     kRoundRel x mag with mag >= |t1| + |t2| + |t3| + |t4| + |qadd| + |aadd| + |cdp| + 1 as there.   z_up <= zmin: the row is skipped.
-// tests/test_bound_math_cpu.py restates both in numpy: no row whose f32 score exceeds th is ever skipped.
-struct BoundConsts {
-  double c0, c0abs, aya, lya, kmag, zmin, cs, ca;
-};
-
-__device__ __forceinline__ double z_threshold(uint32_t theta_key, const QueryParams &p) {
-  if (theta_key == 0u) return -DBL_MAX;
-  const uint32_t bits = (theta_key & 0x80000000u) ? (theta_key & 0x7fffffffu) : ~theta_key;
-  const double th = (double)__uint_as_float(bits);  // the threshold score (a float the reference produced)
-  if (!(th == th)) return -DBL_MAX;
-  double z;
-  if (p.sim == 1) {                 // max((1+t)/2, 0) > th  =>  t > 2 th - 1        (th >= 0 always for scores)
-    if (th < 0.0) return -DBL_MAX;
-    z = (2.0 * th - 1.0) - (p.qadd - p.cdp);
-  } else if (p.sim == 2) {
-    double t;
-    if (p.one_bit || p.mip_plain) t = th >= 1.0 ? th - 1.0 : (th > 0.0 ? 1.0 - 1.0 / th : -DBL_MAX);
-    else {
-      const double FBS = 1.0 / 15.0;
-      t = th >= 1.0 ? (th - 1.0) * FBS : (th > 0.0 ? (1.0 - 1.0 / th) * FBS : -DBL_MAX);
-    }
-    if (t == -DBL_MAX) return -DBL_MAX;
-    z = t - (p.qadd - p.cdp);
-  } else {                          // 1/(1+e) > th, e = qadd + xadd - 2s = qadd - z   =>  z > qadd + 1 - 1/th
-    if (!(th > 0.0)) return -DBL_MAX;
-    z = p.qadd + 1.0 - 1.0 / th;
-  }
-  if (!(fabs(z) <= DBL_MAX)) return -DBL_MAX;
-  return z - 1e-9 * (fabs(z) + fabs(p.qadd) + fabs(p.cdp) + 1.0);  // rounding allowance of this inversion
-}
-
-__device__ __forceinline__ void make_bound_consts(const QueryParams &p, uint32_t theta_key, BoundConsts &k) {
-  k.c0 = p.ay * p.dimd + p.ly * p.y1;
-  k.aya = fabs(p.ay);
-  k.lya = fabs(p.ly);
-  k.c0abs = k.aya * p.dimd + k.lya * fabs(p.y1);
-  k.kmag = fabs(p.qadd) + fabs(p.cdp) + 1.0;
-  k.zmin = z_threshold(theta_key, p);
-  k.cs = p.sim == 0 ? 2.0 : 1.0;
-  k.ca = p.sim == 0 ? -1.0 : 1.0;
-}
-
-// true: the row's exact score has to be computed (it may exceed the threshold, or nothing can be said: NaN, overflow)
-__device__ __forceinline__ bool row_may_pass(double qc, double al, double au, double aadd, double x1, const QueryParams &p, const BoundConsts &k) {
-  const double B = fma(p.ly, qc, p.ay * x1);
-  const double A = k.c0 - B;
-  const double s = fma(au, B, al * A);
-  const double ea = fma(fabs(al), kBf16Rel, kAbsSlack);
-  const double eu = fma(fabs(au), kBf16Rel, kAbsSlack);
-  const double es = fma(fabs(A), ea, fabs(B) * eu);
-  const double Babs = fma(k.lya, fabs(qc), k.aya * fabs(x1));
-  const double mag = fma(fabs(al) + fabs(au), Babs, fabs(al) * k.c0abs) + (k.kmag + fabs(aadd));
-  const double slop = kRoundRel * ((mag + fabs(A)) + fabs(B));
-  const double eadd = fma(fabs(aadd), kF32Rel, kAbsSlack);
-  const double z_up = fma(k.cs, s, k.ca * aadd) + (fma(k.cs, es, eadd) + slop);
-  return !(mag < 1e290) || !(z_up <= k.zmin);
 }
 
 __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t *s_wave, uint32_t &total) {

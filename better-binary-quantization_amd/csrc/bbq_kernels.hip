@@ -103,11 +103,7 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) 
   // with a flood tier every passing row of the chunk is staged (it may have to move to the overflow area as a whole)
   const uint32_t stage_cap = DENSE ? 0u : ((a.ovf || a.append_lists) ? (uint32_t)kChunkRows : (uint32_t)a.cap);
   uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_ent + stage_cap);
-  BoundConsts *s_bk = reinterpret_cast<BoundConsts *>(s_cnt + 2);  // 8-byte aligned: everything in front is a multiple of 8 bytes
 
-  // the grid's x extent is padded to a multiple of 8: workgroups go to the 8 XCDs round robin by linear id, so chunk c of EVERY query
-  // of the launch runs on XCD c % 8, and what that XCD's L2 keeps of the chunk's (streamed) lines serves the next query
-  if ((int)blockIdx.x >= a.n_chunks) return;
   const int q = blockIdx.y;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -120,9 +116,6 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) 
   }
   const QueryParams p = a.qparams[q];
   const uint32_t theta = DENSE ? 0u : a.theta[q];
-  if constexpr (COMPACT && !DENSE) {
-    if (tid == 64) make_bound_consts(p, theta, *s_bk);  // the per-query side of the row test, once per workgroup
-  }
   __syncthreads();
 
   const int64_t chunk = a.chunk_begin + blockIdx.x;
@@ -190,13 +183,14 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) 
       const double al = (double)__uint_as_float(cpk0 << 16);
       const double au = (double)__uint_as_float(cpk0 & 0xffff0000u);
       const double aadd = (double)__uint_as_float(cpk1);
-      // NaN / overflow (no bound) passes; otherwise the row can only matter if even the upper end of its z beats the threshold's
-      need_exact = valid && row_may_pass((double)qc, al, au, aadd, x1, p, *s_bk);
+      // NaN (no bound) passes; otherwise the row can only matter if even its upper bound beats the threshold
+      const double ub = score_upper_bound((double)qc, al, au, aadd, x1, p);
+      const float ub32 = (float)ub;
+      need_exact = valid && ((ub32 != ub32) || key_of_bits(__float_as_uint(ub32)) > theta);
       if (need_exact) {
-        // (streamed like everything a sweep touches once: what the XCD's L2 keeps between the queries of a launch are tile lines)
         const f64x2 *__restrict__ ex = reinterpret_cast<const f64x2 *>(a.idx.exact + row * 4);
-        lu = BBQ_STREAM_LOAD(ex);
-        xadd = BBQ_STREAM_LOAD(reinterpret_cast<const double *>(ex + 1));
+        lu = ex[0];
+        xadd = reinterpret_cast<const double *>(ex + 1)[0];
       }
     }
     if (need_exact) {
@@ -235,7 +229,7 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) 
         return;
       }
       uint64_t *__restrict__ dst = a.append_lists + (size_t)q * a.append_cap + at;
-      for (uint32_t i = tid; i < cnt; i += NT) __builtin_nontemporal_store(s_ent[i], dst + i);
+      for (uint32_t i = tid; i < cnt; i += NT) dst[i] = s_ent[i];
       return;
     }
     uint32_t cnt = *s_cnt;
@@ -268,9 +262,9 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) 
       const uint64_t e = s_ent[i];
       uint32_t rank = 0;
       for (uint32_t j = 0; j < cnt; ++j) rank += (s_ent[j] < e) ? 1u : 0u;
-      __builtin_nontemporal_store(e, out + rank);
+      out[rank] = e;
     }
-    if (tid == 0) __builtin_nontemporal_store(count_word, a.counts + (size_t)q * a.n_chunks + blockIdx.x);
+    if (tid == 0) a.counts[(size_t)q * a.n_chunks + blockIdx.x] = count_word;
   }
 }
 
@@ -868,9 +862,8 @@ __global__ __launch_bounds__(256) void bbq_pack_copy_kernel(const uint64_t *__re
 template <int QB, int W, int MODE, int SB = 1>
 static hipError_t launch_scan_t(const ScanArgs &a, int n_queries, int n_chunks, hipStream_t s) {
   const int w16 = W > 0 ? W : a.idx.w16;
-  const size_t smem = (size_t)w16 * query_units_per_chunk(QB, SB) * 16 + ((MODE & 1) ? 0 : (size_t)((a.ovf || a.append_lists) ? kChunkRows : a.cap) * 8) + 16 + sizeof(BoundConsts);
-  if (a.n_chunks != n_chunks) return hipErrorInvalidValue;  // the kernel drops the workgroups of the padding by ScanArgs::n_chunks
-  dim3 grid((unsigned)((n_chunks + 7) / 8 * 8), (unsigned)n_queries, 1), block(kChunkRows, 1, 1);
+  const size_t smem = (size_t)w16 * query_units_per_chunk(QB, SB) * 16 + ((MODE & 1) ? 0 : (size_t)((a.ovf || a.append_lists) ? kChunkRows : a.cap) * 8) + 16;
+  dim3 grid((unsigned)n_chunks, (unsigned)n_queries, 1), block(kChunkRows, 1, 1);
   hipLaunchKernelGGL((bbq_scan_kernel<QB, W, MODE, SB>), grid, block, smem, s, a);
   return hipGetLastError();
 }

@@ -30,7 +30,6 @@ __global__ __launch_bounds__(kLatThreads) void bbq_lat_scan_kernel(const LatScan
   __shared__ __attribute__((aligned(16))) u32x4 s_planes[W * QB];
   __shared__ uint64_t s_ent[kChunkRows];
   __shared__ uint32_t s_misc[16];
-  __shared__ BoundConsts s_bk;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   {
     for (int i = tid; i < W * QB; i += kLatThreads) {  // the query: kernel arguments -> LDS
@@ -43,9 +42,6 @@ __global__ __launch_bounds__(kLatThreads) void bbq_lat_scan_kernel(const LatScan
   const QueryParams p = a.p;
   // the dense prefix runs with threshold 0: below the key of every number, so each of its rows is scored exactly and listed
   const uint32_t theta = a.first ? 0u : *a.theta;
-  if constexpr (COMPACT) {
-    if (tid == 64) make_bound_consts(p, theta, s_bk);
-  }
   __syncthreads();
 
   const int64_t chunk = a.chunk_begin + blockIdx.x;
@@ -72,7 +68,9 @@ __global__ __launch_bounds__(kLatThreads) void bbq_lat_scan_kernel(const LatScan
       const double al = (double)__uint_as_float(cpk0 << 16);
       const double au = (double)__uint_as_float(cpk0 & 0xffff0000u);
       const double aadd = (double)__uint_as_float(cpk1);
-      need_exact = valid && row_may_pass((double)qc, al, au, aadd, x1, p, s_bk);
+      const double ub = score_upper_bound((double)qc, al, au, aadd, x1, p);
+      const float ub32 = (float)ub;
+      need_exact = valid && ((ub32 != ub32) || key_of_bits(__float_as_uint(ub32)) > theta);
       if (need_exact) {
         const f64x2 *__restrict__ ex = reinterpret_cast<const f64x2 *>(a.idx.exact + row * 4);
         lu = ex[0];

@@ -85,108 +85,3 @@ def test_upper_bound_dominates_exact_score(sim, qb):
         if ordinary.sum() > 100 and sim == 1:
             assert np.median(u32[ordinary] - s32[ordinary]) < 0.05
 
-
-# ---- the sweeps' row test in z-space (bbq_kernel_common.h: z_threshold, make_bound_consts, row_may_pass) -------------------------------
-
-DBL_MAX = np.finfo(np.float64).max
-
-
-def z_threshold(th, ay, ly, y1, qadd, cdp, sim, one_bit_or_plain):
-    """zmin with: exact f32 score > th  =>  z > zmin (same operations as the device function)"""
-    th = float(th)
-    if th != th:
-        return -DBL_MAX
-    if sim == 1:
-        if th < 0.0:
-            return -DBL_MAX
-        z = (2.0 * th - 1.0) - (qadd - cdp)
-    elif sim == 2:
-        if one_bit_or_plain:
-            t = th - 1.0 if th >= 1.0 else (1.0 - 1.0 / th if th > 0.0 else -DBL_MAX)
-        else:
-            t = (th - 1.0) * FBS if th >= 1.0 else ((1.0 - 1.0 / th) * FBS if th > 0.0 else -DBL_MAX)
-        if t == -DBL_MAX:
-            return -DBL_MAX
-        z = t - (qadd - cdp)
-    else:
-        if not th > 0.0:
-            return -DBL_MAX
-        z = qadd + 1.0 - 1.0 / th
-    if not abs(z) <= DBL_MAX:
-        return -DBL_MAX
-    return z - 1e-9 * (abs(z) + abs(qadd) + abs(cdp) + 1.0)
-
-
-def row_may_pass(qc, al, au, aadd, x1, ay, ly, y1, qadd, cdp, dim, sim, zmin):
-    """fma(a, b, c) is a * b + c with one rounding on the device; numpy rounds twice - the difference is far inside the allowance"""
-    with np.errstate(all="ignore"):
-        c0 = ay * dim + ly * y1
-        aya, lya = abs(ay), abs(ly)
-        c0abs = aya * dim + lya * abs(y1)
-        kmag = abs(qadd) + abs(cdp) + 1.0
-        cs, ca = (2.0, -1.0) if sim == 0 else (1.0, 1.0)
-        B = ly * qc + ay * x1
-        A = c0 - B
-        s = au * B + al * A
-        ea = np.abs(al) * BF16_REL + ABS_SLACK
-        eu = np.abs(au) * BF16_REL + ABS_SLACK
-        es = np.abs(A) * ea + np.abs(B) * eu
-        Babs = lya * np.abs(qc) + aya * np.abs(x1)
-        mag = (np.abs(al) + np.abs(au)) * Babs + np.abs(al) * c0abs + (kmag + np.abs(aadd))
-        slop = ROUND_REL * ((mag + np.abs(A)) + np.abs(B))
-        eadd = np.abs(aadd) * F32_REL + ABS_SLACK
-        z_up = (cs * s + ca * aadd) + ((cs * es + eadd) + slop)
-        return ~(mag < 1e290) | ~(z_up <= zmin)
-
-
-@pytest.mark.parametrize("sim", [0, 1, 2])
-@pytest.mark.parametrize("qb", [1, 4, 8])
-def test_row_test_never_skips_a_row_above_the_threshold(sim, qb):
-    """for thresholds taken from the scores themselves (and around them): every row whose exact f32 score exceeds the threshold passes
-    the z-space test; and on ordinary magnitudes it is as selective as score_upper_bound()"""
-    rng = np.random.default_rng(70 * sim + qb)
-    n, dim = 120000, 128
-    codes = rng.integers(0, 256, size=(n, dim // 8), dtype=np.uint8)
-    pop = np.unpackbits(codes, axis=1).sum(axis=1).astype(np.float64)
-    for flavour in range(3):
-        corr = np.zeros((n, 4))
-        if flavour == 0:       # ordinary: what the quantizer produces
-            corr[:, 0] = -0.04 * (0.9 + 0.2 * rng.random(n))
-            corr[:, 1] = 0.04 * (0.9 + 0.2 * rng.random(n))
-            corr[:, 2] = 1e-4 * (2 * rng.random(n) - 1)
-        else:                  # hostile magnitudes, zeros
-            scale = 10.0 ** rng.uniform(-12, 6 if flavour == 1 else 2, n)
-            corr[:, 0] = rng.standard_normal(n) * scale
-            corr[:, 1] = rng.standard_normal(n) * scale * 10.0 ** rng.uniform(-2, 2, n)
-            corr[:, 2] = rng.standard_normal(n) * 10.0 ** rng.uniform(-10, 6, n)
-            corr[::101, 0] = 0
-            corr[::103, 1] = 0
-            corr[::107, 2] = 0
-        corr[:, 3] = pop
-        qq = rng.integers(0, 1 << qb, dim).astype(np.uint8)
-        for qc in (np.array([-0.15, 0.148, -0.0028, float(qq.sum())]), np.array([-30.0, 55.0, 4.0, float(qq.sum())])):
-            cdp = 0.0009
-            d, s64, s32 = O.score_all(codes, corr, dim, qq, qc, qb, sim, cdp)
-            one_bit = qb == 1
-            ly = (qc[1] - qc[0]) if one_bit else (qc[1] - qc[0]) * FBS
-            al, au = bf16_trunc(corr[:, 0]), bf16_trunc(corr[:, 1])
-            add32 = corr[:, 2].astype(np.float32).astype(np.float64)
-            # the kernel passes the tile's bound of the additive correction: the end that makes the score larger; per row here, the
-            # extremes over windows of 64 rows there - both are covered by testing with each row's own value and with the extremes
-            finite = ~np.isnan(s32)
-            order = np.sort(s32[finite])
-            ths = np.unique(np.concatenate([order[[0, len(order) // 2, -1000, -100, -10, -1]], np.nextafter(order[[-100, -1]], np.float32(np.inf)),
-                                            np.array([0.0, 1.0, 0.5], np.float32)]))
-            for th in ths:
-                zmin = z_threshold(th, qc[0], ly, qc[3], qc[2], cdp, sim, one_bit)
-                for aadd in (add32, np.full(n, add32.min() if sim == 0 else add32.max())):
-                    may = row_may_pass(d.astype(np.float64), al, au, aadd, pop, qc[0], ly, qc[3], qc[2], cdp, float(dim), sim, zmin)
-                    above = finite & (s32 > th)
-                    assert may[above].all(), "a row above the threshold would be skipped (sim %d qb %d flavour %d th %r)" % (sim, qb, flavour, th)
-            if flavour == 0 and qc[0] == -0.15:
-                th = order[-100]
-                zmin = z_threshold(th, qc[0], ly, qc[3], qc[2], cdp, sim, one_bit)
-                may = row_may_pass(d.astype(np.float64), al, au, add32, pop, qc[0], ly, qc[3], qc[2], cdp, float(dim), sim, zmin)
-                u = upper_bound(d.astype(np.float64), al, au, add32, pop, qc[0], ly, qc[3], qc[2], cdp, float(dim), sim, one_bit)
-                old = (u.astype(np.float32) > th) | np.isnan(u)
-                assert may.sum() <= old.sum() * 1.05 + 10, "the z-space test lets %d rows through, score_upper_bound %d" % (may.sum(), old.sum())
