@@ -14,8 +14,11 @@ export interface BinarizedByteVectorValues {
   clearUnpackedVectorCache?(): void;
   /** releases the device-resident copy (extension) */
   dispose(): void;
-  /** libbbq tuning knob on the device index, e.g. ('sweep_share', 32) (extension) */
+  /** libbbq tuning knob on the device index, e.g. ('sweep_share', 32), ('resident_mb', 0) (extension; include/bbq.h lists them) */
   setDeviceOption(name: string, value: number): void;
+  /** libbbq counters of the last call on the device index (extension; bbq_stats in include/bbq.h) */
+  deviceStats(): { lastScanMs: number; lastScanBytes: number; candidates: number; denseFallbacks: number; hostReplays: number;
+                   residentBytes: number; shards: number; bytesPerRow: number };
 }
 export interface QuantizedScoreResult { score: number; bitDotProduct: number; corrections: { query: QuantizationResult; index: QuantizationResult }; }
 export declare class OptimizedScalarQuantizer {
