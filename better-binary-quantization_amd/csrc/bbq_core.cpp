@@ -701,6 +701,10 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const 
   const int64_t list_cap = d_lists_ext ? list_cap_ext : s.list_cap;
   int32_t *d_list_counts = d_counts_ext ? d_counts_ext : s.d_list_counts;
   if (d_counts_ext) HIPCHK(hipMemsetAsync(d_counts_ext, 0, (size_t)nq * 8, st));
+  // a shard without rows (and without a pilot replica) launches nothing that would write its answer blocks: all-zero blocks say
+  // "nothing listed, no cut, no flags", which is what bbq_merge_answers expects of such a shard
+  if (ext && ext->answers && p.segs.empty())
+    HIPCHK(hipMemsetAsync(ext->answers, 0, ((size_t)(nq - 1) * (size_t)ext->answers_stride + (size_t)c.k + 2) * 8, st));
 
   const bool use_final = !d_lists_ext && p.final_k > 0 && !p.segs.empty();
   // few queries: the sparse launches append their candidates to the list themselves (ScanArgs::append_lists)
@@ -1160,7 +1164,10 @@ int search_latency_presampled(const BatchCtx &c, const BatchCtx &cs, int32_t *ou
   const uint64_t *hdr = ctx->h_lat + kLatAnswerOffset;
   const uint32_t listed = (uint32_t)hdr[0], flags = (uint32_t)(hdr[0] >> 32), m = (uint32_t)hdr[1], replay = (uint32_t)(hdr[1] >> 32);
   s.timed = false;
-  if (flags != 0 || replay != 0) return BBQ_OK;  // the segmented chain answers it
+  // The list holds the rows ABOVE the sampled threshold only, so the selection's "take every listed row" case (total <= k2) proves
+  // nothing here: equal keys at ranks k2+1 / k2+2 of the sample can leave fewer than k2 rows above it (N >= 262144 > k2, so a
+  // complete answer has exactly k2 entries).  Anything else goes to the segmented chain.
+  if (flags != 0 || replay != 0 || m != (uint32_t)k2) return BBQ_OK;
   for (uint32_t j = 0; j < m; ++j) {
     const uint64_t e = hdr[2 + j];
     const uint32_t bits = (uint32_t)e;
@@ -1707,7 +1714,8 @@ int bbq_shard_scan_begin(bbq_index *ix, int32_t n_queries, const uint8_t *qquant
   for (int64_t i = 0; i < nsub; ++i) {
     Slot &s = ix->slots[i % nslots];
     if (s.busy) {
-      HIPCHK(hipEventSynchronize(s.ev_done));
+      const hipError_t e = hipEventSynchronize(s.ev_done);
+      if (e != hipSuccess) return bail(fail(BBQ_ERR_HIP, "bbq_shard_scan_begin: %s", hipGetErrorString(e)));
       s.busy = false;
       account_timing(s.shard_owner ? s.shard_owner : ix, s);
       s.shard_owner = nullptr;
@@ -1790,8 +1798,11 @@ int bbq_get_stats(bbq_index *ix, bbq_stats *out) {
   if (ix->multi) return multi_get_stats(ix, out);
   if (ix->ctx) {
     std::lock_guard<std::mutex> lk(ix->ctx->mu);
+    int prev = -1;  // a getter must not change the calling thread's current device
+    (void)hipGetDevice(&prev);
     HIPCHK(hipSetDevice(ix->device));
     int rc = settle_shard_slots(ix->ctx, ix);  // timings of an asynchronous scan are booked when its slots are retired
+    if (prev >= 0 && prev != ix->device) (void)hipSetDevice(prev);
     if (rc != BBQ_OK) return rc;
     *out = ix->stats;
     return BBQ_OK;

@@ -423,11 +423,13 @@ int multi_set_option(bbq_index *ix, const char *name, int64_t v) {
     ms->round_queries = (int)v;
     return BBQ_OK;
   }
+  const std::string n(name);
+  if (n == "device_select" && v != 0 && v != 1)  // the shards refuse it too; checked here so that no shard is changed first
+    return fail(BBQ_ERR_INVALID_ARG, "bbq_set_option: unknown option or value out of range: %s=%lld", name, (long long)v);
   for (MultiShard &sh : ms->shards) {
     int rc = bbq_set_option(sh.ix, name, v);
     if (rc != BBQ_OK) return rc;
   }
-  const std::string n(name);
   if (n == "replay_threads") ix->opt_replay_threads = (int)v;
   if (n == "force_dense") ix->opt_force_dense = (int)v;
   if (n == "device_select") ix->opt_device_select = (int)v;  // 0: no shard-local answers, every query replays its lists (the ABI-2 path)

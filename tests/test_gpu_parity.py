@@ -1359,6 +1359,49 @@ def test_latency_fused_path_equals_general_path(dim, qb, sim, compact, n):
         ix.close()
 
 
+@pytest.mark.parametrize("k,copies", [(1, 3), (1, 9), (10, 12), (10, 40), (100, 130)])
+def test_latency_presampled_threshold_ties_in_the_prefix(k, copies):
+    """the pre-sampled single-query call when the sampled keys at ranks k+1 and k+2 are EQUAL: the best-matching row is stored `copies`
+    >= k + 2 times inside the sampled prefix, so the threshold is that row's own key, no row lies strictly above it and the sweep
+    lists fewer than k rows.  The reference always returns min(k, size) entries (src/binaryQuantizationFormat.ts:385): the call has to
+    notice that its short list proves nothing and hand the query to the segmented chain."""
+    rng = np.random.default_rng(1000 * k + copies)
+    n, dim, qb, sim = 300_000, 768, 4, 1
+    pb = dim // 8
+    codes = rng.integers(0, 256, size=(n, pb), dtype=np.uint8)
+    corr = np.empty((n, 4))
+    corr[:, 0] = -0.04 * (0.9 + 0.2 * rng.random(n))
+    corr[:, 1] = 0.04 * (0.9 + 0.2 * rng.random(n))
+    corr[:, 2] = 1e-4 * (2 * rng.random(n) - 1)
+    cdp = 0.0009
+    qq = rng.integers(0, 1 << qb, size=dim, dtype=np.uint8)
+    qc = np.array([-0.15, 0.148, -0.0014, float(qq.sum())])
+    # the row that matches the query best: its own bit pattern (every set query bit counted), large corrections
+    best = np.packbits((qq >= 8).astype(np.uint8)).astype(np.uint8)
+    at = np.sort(rng.choice(4000, size=copies, replace=False))       # all inside the first 8192 rows = inside every prefix
+    codes[at] = best
+    corr[at, 0] = -0.06
+    corr[at, 1] = 0.06
+    corr[at, 2] = 1e-4
+    corr[:, 3] = np.unpackbits(codes, axis=1).sum(axis=1)
+    _, _, s32 = O.score_all(codes, corr, dim, qq, qc, qb, sim, cdp)
+    assert (s32 == s32[at[0]]).sum() == copies and s32.max() == s32[at[0]], "the planted rows are the strict maximum, all equal"
+    oi, osc = O.heap_topk(s32, k)
+    assert len(oi) == k
+    for compact in (True, False):
+        ix = _make_index(codes, corr, dim, cdp, compact)
+        try:
+            for fused, presample in ((1, 1), (1, 0), (0, 0)):
+                ix.set_option("latency_fused", fused)
+                ix.set_option("latency_presample", presample)
+                fi, fs = ix.search(qq, qc, qb, sim, k)
+                assert len(fi) == k, "fused %d presample %d compact %s: %d results for k = %d" % (fused, presample, compact, len(fi), k)
+                np.testing.assert_array_equal(fi, oi, err_msg="fused %d presample %d compact %s" % (fused, presample, compact))
+                np.testing.assert_array_equal(fs.view(np.uint32), osc.view(np.uint32))
+        finally:
+            ix.close()
+
+
 @pytest.mark.parametrize("sim,qb,nq", [(1, 4, 200), (0, 4, 70), (2, 1, 130), (1, 8, 65), (1, 4, 5)])
 def test_search_raw_batch_equals_quantize_then_search(sim, qb, nq):
     """bbq_search_raw_batch (quantization on host threads pipelined with the sweeps) == bbq_quantize_queries + bbq_search_batch, bit for
