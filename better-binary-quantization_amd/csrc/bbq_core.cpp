@@ -548,10 +548,11 @@ void fill_query(const bbq_index *ix, uint8_t *planes_dst, QueryParams *pp, const
 }
 
 // MFMA shared sweep: the int8 query values in the order the code bits fall out of the packed words.  For 32-dim word
-// g, half h, dword c, byte i the kernel extracts bit p = 4h + c + 8i of the little-endian word ((w >> (4h + c)) &
-// 0x01010101), which is row byte 4g + (p >> 3), bit (p & 7), i.e. dimension 32g + 8*(p >> 3) + 7 - (p & 7)
-// (MSB-first packing, src/optimizedScalarQuantizer.ts:420-446).  Layout: [group][g][h][n][16 B], n = query in its group of 32.
-void fill_query_mfma(const bbq_index *ix, uint8_t *dst, int q_in_batch, const uint8_t *q) {
+// g, half h, dword c, byte i the kernel extracts bit p = 4h + c + 8i of the little-endian word, which is row byte 4g + (p >> 3),
+// bit (p & 7), i.e. dimension 32g + 8*(p >> 3) + 7 - (p & 7) (MSB-first packing, src/optimizedScalarQuantizer.ts:420-446).
+// `scaled` (query values <= 15): the kernel leaves that bit where it stands inside its nibble - an int8 value of 2^c - so the
+// query byte carries the factor 8 >> c and every product is 8 * q * bit.  Layout: [group][g][h][n][16 B], n = query in its group of 32.
+void fill_query_mfma(const bbq_index *ix, uint8_t *dst, int q_in_batch, const uint8_t *q, bool scaled) {
   const int words = ix->w16 * 4, group = q_in_batch / 32, n = q_in_batch % 32;
   uint8_t *gb = dst + (size_t)group * words * 2 * 32 * 16;
   for (int g = 0; g < words; ++g)
@@ -561,9 +562,17 @@ void fill_query_mfma(const bbq_index *ix, uint8_t *dst, int q_in_batch, const ui
         for (int i = 0; i < 4; ++i) {
           const int p = 4 * h + cc + 8 * i;
           const int d = 32 * g + 8 * (p >> 3) + 7 - (p & 7);
-          o[4 * cc + i] = d < ix->dim ? q[d] : 0;
+          const int v = d < ix->dim ? q[d] : 0;
+          o[4 * cc + i] = (uint8_t)(scaled ? v * (8 >> cc) : v);
         }
     }
+}
+
+// The matrix-core sweep tests "score > threshold" as an inequality on the integer dot product (bbq_mfma_kernels.hip), which divides by
+// the query's interval width: it takes queries with a positive, finite width and finite corrections; any other sub-batch sweeps on
+// the vector ALUs.
+bool mfma_query_ok(const QueryParams &p) {
+  return p.ly > 0.0 && p.ly < 1e30 && 1.0 / p.ly < 1e30 && fabs(p.ay) < 1e30 && fabs(p.y1) < 1e30 && fabs(p.qadd) < 1e30 && fabs(p.cdp) < 1e30;
 }
 
 int validate_query_args(const bbq_index *ix, int32_t nq, const uint8_t *qquant, const double *qcorr, int32_t query_bits,
@@ -669,9 +678,11 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const 
     fill_query(ix, hp + (size_t)i * qb, hq + i, c.qquant + (size_t)(q_first + i) * ix->dim, c.qcorr + (size_t)(q_first + i) * 4,
                c.planes, c.one_bit, c.sim);
   size_t bytes = (size_t)nq * qb + (size_t)nq * sizeof(QueryParams);
-  const bool use_mfma = ix->opt_share == 32 && c.maxq <= 127 && ix->store_bits == 1;
+  bool use_mfma = ix->opt_share == 32 && c.maxq <= 127 && ix->store_bits == 1;
+  for (int i = 0; i < nq && use_mfma; ++i) use_mfma = mfma_query_ok(hq[i]);
+  const bool mfma_scaled = c.maxq <= 15;  // queryBits <= 4: the bit -> int8 expansion without shifts
   size_t off_qbytes = 0, off_qmax = 0;
-  if (use_mfma) {  // second copy of the queries as int8 values in MFMA fragment order + per-group maxima for the pre-filter slack
+  if (use_mfma) {  // second copy of the queries as int8 values in MFMA fragment order + per-group maxima for the rows' magnitude budget
     const int groups = (nq + 31) / 32;
     off_qbytes = (bytes + 15) / 16 * 16;
     const size_t qbytes_len = (size_t)groups * 32 * ix->w16 * 128;
@@ -681,17 +692,17 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const 
     float *qm = reinterpret_cast<float *>(s.h_qbuf + off_qmax);
     for (int gidx = 0; gidx < groups; ++gidx) qm[4 * gidx] = qm[4 * gidx + 1] = qm[4 * gidx + 2] = qm[4 * gidx + 3] = 0.f;
     for (int i = 0; i < nq; ++i) {
-      fill_query_mfma(ix, s.h_qbuf + off_qbytes, i, c.qquant + (size_t)(q_first + i) * ix->dim);
+      fill_query_mfma(ix, s.h_qbuf + off_qbytes, i, c.qquant + (size_t)(q_first + i) * ix->dim, mfma_scaled);
       float *m = qm + 4 * (i / 32);
-      // upper bounds (rounded up) of the group's |ay|, |ly|, y1, |qadd - cdp|
-      m[0] = std::max(m[0], (float)(fabs(hq[i].ay) * 1.000001));
-      m[1] = std::max(m[1], (float)(fabs(hq[i].ly) * 1.000001));
-      // the slack bounds |qcDist| and |y1 - qcDist| by this: qcDist <= the sum of the query's values whatever y1 the caller passed
+      // upper bounds (rounded up) of the group's |ay / ly|, |y1|, 1 / (cs * ly) and of the sum of a query's values (the largest
+      // qcDist there can be, whatever y1 the caller passed)
       double qsum = 0;
       const uint8_t *qv = c.qquant + (size_t)(q_first + i) * ix->dim;
       for (int d = 0; d < ix->dim; ++d) qsum += qv[d];
-      m[2] = std::max(m[2], (float)((fabs(hq[i].y1) + qsum) * 1.000001));
-      m[3] = std::max(m[3], (float)(fabs(hq[i].qadd - hq[i].cdp) * 1.000001));
+      m[0] = std::max(m[0], (float)(fabs(hq[i].ay / hq[i].ly) * 1.000001));
+      m[1] = std::max(m[1], (float)(fabs(hq[i].y1) * 1.000001));
+      m[2] = std::max(m[2], (float)(1.0 / ((c.sim == 0 ? 2.0 : 1.0) * hq[i].ly) * 1.000001));
+      m[3] = std::max(m[3], (float)(qsum * 1.000001));
     }
   }
   hipStream_t st = s.stream;
@@ -748,7 +759,7 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const 
     if (g.dominant) HIPCHK(hipEventRecord(s.ev0, st));
     const bool mfma_here = use_mfma && !g.dense && mfma_sweep_supported(a);
     if (mfma_here)
-      HIPCHK(launch_scan_mfma(a, s.d_qbuf + off_qbytes, reinterpret_cast<const float *>(s.d_qbuf + off_qmax), nq, (int)g.n_chunks, st));
+      HIPCHK(launch_scan_mfma(a, s.d_qbuf + off_qbytes, reinterpret_cast<const float *>(s.d_qbuf + off_qmax), mfma_scaled, nq, (int)g.n_chunks, st));
     else if (!g.dense && ix->opt_share > 1 && shared_sweep_supported(a, ix->opt_share))
       HIPCHK(launch_scan_shared(a, c.planes, ix->opt_share, nq, (int)g.n_chunks, st));
     else

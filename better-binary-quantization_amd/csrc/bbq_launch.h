@@ -10,9 +10,10 @@ hipError_t launch_scan(const ScanArgs &a, int planes, bool dense, int n_queries,
 // shared sweep: `share` (4 or 8) queries per workgroup reuse every loaded row (sparse segments, fixed-width dims only)
 bool shared_sweep_supported(const ScanArgs &a, int share);
 hipError_t launch_scan_shared(const ScanArgs &a, int planes, int share, int n_queries, int n_chunks, hipStream_t s);
-// shared sweep on the matrix cores: 32 queries per workgroup (bbq_mfma_kernels.hip); query values must be <= 127
+// shared sweep on the matrix cores: 32 queries per workgroup (bbq_mfma_kernels.hip); query values must be <= 127 (`scaled`: <= 15 and
+// the query bytes carry the factor 8 >> dword), every query's interval width positive and finite
 bool mfma_sweep_supported(const ScanArgs &a);
-hipError_t launch_scan_mfma(const ScanArgs &a, const uint8_t *qbytes, const float *qmax, int n_queries, int n_chunks, hipStream_t s);
+hipError_t launch_scan_mfma(const ScanArgs &a, const uint8_t *qbytes, const float *qmax, bool scaled, int n_queries, int n_chunks, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, int n_queries, hipStream_t s);
 // lists are [nq][list_stride]; a query may hold more than advertised_cap entries (a flood): such queries are only dropped
 // (flagged) when the packed buffer cannot take the sum

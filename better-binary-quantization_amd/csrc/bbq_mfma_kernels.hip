@@ -3,23 +3,40 @@
 // With 32 queries sharing a sweep the integer dot products ARE a dense contraction,
 //     qcDist[row][query] = sum_d bit_d(row) * q[query][d],
 // and the VALU popcount formulation is bound by v_bcnt (bbq_kernels.hip: shared kernel, ~1.4x).  Here every wave expands
-// the 1-bit codes of its 64-row tile to int8 {0,1} fragments on the fly and multiplies them with the 32 queries' int8
+// the 1-bit codes of its 64-row tile to int8 fragments on the fly and multiplies them with the 32 queries' int8
 // values on v_mfma_i32_32x32x32_i8 (fragment layout verified on gfx950 by scripts/ubench/mfma_probe.hip:
 //   A[m = lane%32][k = 16*(lane/32)+i],  B[k][n = lane%32],  C[r] -> row (r&3) + 8*(r>>2) + 4*(lane/32), col lane%32).
 // The k -> dimension assignment is free as long as A and B agree, so the host lays the query bytes out in the order the
-// code bits fall out of the packed words (fill_query_mfma in bbq_core.cpp).
+// code bits fall out of the packed words (fill_query_mfma in bbq_core.cpp).  The QUERIES are the A operand (M = 32 queries) and
+// the index ROWS the B operand (N = 32 rows), so a lane's 16 accumulators of a row group are 16 queries against ONE row.
 //
-// Operand roles (round 3): the QUERIES are the A operand (M = 32 queries) and the index ROWS the B operand (N = 32 rows), so a
-// lane's 16 accumulators are 16 queries against ONE row (column lane%32) - its own row, or its half-wave partner's.  The row's
-// pre-filter constants therefore sit in the lane's registers, and only the per-query constants (one float4, the same for the whole
-// half-wave) come from LDS: 48 + 32 = 80 ds_read_b128 per tile and wave where the rows-as-A layout needed 48 + 128.
-// What binds the kernel (profiles/r03_mfma_pmc.json, DESIGN.md "Shared sweeps"): VALU issue - 1 349 vector instructions per tile
-// and wave next to 48 MFMAs, SQ_ACTIVE_INST_VALU = 88 % of the launch's SIMD time, the matrix cores 24 % busy.  The pre-filter
-// (~16 instructions per pair) and the bit -> int8 expansion (9 per MFMA) are that load.
+// Round 4: the kernel was bound by vector issue (profiles/r03_mfma_pmc.json: 1 349 vector instructions per tile and wave next to
+// 48 MFMAs, the matrix cores 24 % busy) - 16 instructions per (row, query) pair of pre-filter and 9 per MFMA of bit -> int8
+// expansion.  Both are gone:
+//  * THE PRE-FILTER LIVES IN THE ACCUMULATOR.  "score > theta" is, for a row with upper > lower and a query with upper > lower,
+//    an inequality on the integer itself:  qcDist > T(query, row), where T is a sum of four (per-query constant) x (per-row
+//    constant) products (derivation at row_constants()).  The MFMA's C operand is initialised with the float
+//        1.5 * 2^23 + slack(row) - S * T(query, row)          (4 v_fma_f32 per pair, nothing else)
+//    whose BITS are the integer 0x4B400000 + round(...); the matrix cores then add S * qcDist to those bits, and a pair can only
+//    be a candidate if its accumulator ends above 0x4B400000: one v_max3_i32 per two pairs finds out whether a tile has any.
+//    4.5 vector instructions per pair instead of 16, no conversion, no compare per pair.  Tiles with a survivor (about one in
+//    five) re-derive the initial value of the few accumulators that passed and take qcDist from the difference.
+//    The constants are f32 images of the EXACT f64 corrections (both layouts: the compact layout reads its side array exact[],
+//    32 B/row more per 32 queries - this kernel is nowhere near the HBM bound), so no per-pair error terms exist: every rounding
+//    is covered by a per-row slack of a few S-units (slack_of()), about 0.05 standard deviations of qcDist.
+//  * THE EXPANSION IS ONE AND PER DWORD.  With query values <= 15 (queryBits <= 4) the host scales the query bytes by 8 >> c for
+//    operand dword c and the kernel takes bit c of every nibble where it stands: (w & 0x01010101 << c) is a dword of int8 values
+//    {0, 2^c}, S = 8 and the accumulator holds 8 * qcDist.  One v_permlane32_swap of (w, w >> 4) hands BOTH row groups their
+//    operand words (own or half-wave partner's row, already aligned for the half's nibble), so a 32-dimension word costs
+//    1 shift + 1 swap + 8 ANDs for two MFMAs: 5 vector instructions per MFMA instead of 9.  Query values up to 127 keep the
+//    {0, 1} expansion with its three extra shifts (S = 1).
+//  * Both row groups' accumulators are live at once, so a query fragment is read from LDS once for two MFMAs and a query's
+//    constants once for two rows (40 ds_read_b128 per tile and wave instead of 80), and the next tile's loads are issued as soon as
+//    the contraction has consumed the codes - into the same registers.
+// Packed f32 instructions (v_pk_fma_f32) are NOT used: on gfx950 they issue at half rate (MI355X_MICROARCH.md, cycle constants).
 //
-// Per (row, query) pair a cheap, provably conservative f32 pre-filter in "z-space" (the monotone argument of the
-// similarity transform) rejects almost everything; the rare survivors go through the f64 bound and the exact f64 score of
-// the one-sweep kernel, so the emitted candidates - and therefore the results - are identical.
+// The rare survivors go through the exact f64 score of the one-sweep kernel, so the emitted candidates - and therefore the
+// results - are identical.
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include "bbq_device.h"
@@ -37,6 +54,9 @@ typedef double f64x2m __attribute__((ext_vector_type(2)));
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 
 constexpr int kMfmaQueries = 32;
+constexpr int kMfmaBias = 0x4B400000;          // bits of 1.5 * 2^23: floats in [2^23, 2^24) are 0x4B000000 + their integer distance from 2^23
+constexpr float kMfmaBiasF = 12582912.0f;      // 1.5 * 2^23
+constexpr float kMfmaMagLimit = 4000000.0f;    // S * (sum of the terms' magnitudes) must stay below 2^22: every partial sum then lies in (2^23, 2^24), ulp 1
 
 // ---- exact pieces shared with bbq_kernels.hip (kept textually identical: same operation order) ----------------------
 __device__ __forceinline__ double m_js_max0(double x) { return (x != x) ? x : (x > 0.0 ? x : 0.0); }
@@ -59,10 +79,10 @@ __device__ __forceinline__ double m_score_f64(double qc, double ax, double ux, d
   return t < 0.0 ? 1.0 / (1.0 - t / FBS) : t / FBS + 1.0;
 }
 
-// conservative lower edge, in z-space, of "score > theta" for one query (see the pre-filter below).
+// conservative lower edge, in z-space, of "score > theta" for one query.
 //   COSINE / MIP: z = s + xadd,  score = f(z + qadd - cdp) with f increasing
 //   EUCLIDEAN   : z = 2s - xadd, score = 1/(1 + qadd - z)  increasing in z while the denominator is positive
-// Returns zmin with:  exact f32 score > theta_score  =>  z > zmin.   -inf accepts everything.
+// Returns zmin with:  exact f32 score > theta_score  =>  z > zmin.   -DBL_MAX accepts everything.
 __device__ __forceinline__ double z_threshold(uint32_t theta_key, const QueryParams &p) {
   if (theta_key == 0u) return -DBL_MAX;
   const uint32_t bits = (theta_key & 0x80000000u) ? (theta_key & 0x7fffffffu) : ~theta_key;
@@ -89,31 +109,118 @@ __device__ __forceinline__ double z_threshold(uint32_t theta_key, const QueryPar
   return z - 1e-9 * (fabs(z) + fabs(p.qadd) + fabs(p.cdp) + 1.0);  // rounding allowance of this inversion
 }
 
+// ---- the threshold on the integer ------------------------------------------------------------------------------------------------
+// With ax = lower, lx = upper - lower of the row, x1 its component sum, D the dimension, and ay, ly, y1 of the query
+// (src/batchDotProduct.ts:478-617):
+//     s = ay * (ax * D + lx * x1) + ly * (ax * y1 + lx * qc),       z = cs * s + ca * add      (cs, ca) = (2, -1) EUCLIDEAN, (1, 1) otherwise
+// so for lx > 0 and ly > 0 (beta = cs * ly):
+//     z > zth   <=>   qc > T = (zth / beta) * (1 / lx)  -  (ay / ly) * (rho * D + x1)  -  y1 * rho  -  (1 / beta) * (ca * add / lx),    rho = ax / lx.
+// Per query (prologue, f64 -> f32):  qk = -S * {zth / beta, ay / ly, y1, 1 / beta}.   Per row (f32):  rk = {1 / lx, -(rho * D + x1), -rho, -ca * add / lx}.
+// The accumulator starts at  bits(K + qk . rk)  with K = 1.5 * 2^23 + slack, computed as four chained v_fma_f32 starting from K.
+//
+// Slack (in units of the accumulator, i.e. 1 / S of a qcDist unit).  Let mag = S * sum_j max_q |q_j| * |r_j| (the row's magnitude
+// budget, with |rho| * D + |x1| standing for |r_1|, plus S * the largest possible qcDist so that every term of s is covered).
+//  * four v_fma_f32 whose results lie in (2^23, 2^24) (guaranteed by mag < 2^22, else the row is "weird"): 4 * 0.5 ulp = 2;
+//  * the f32 images of the constants: q_j within 2^-24 (one rounding of an f64), 1 / lx within 2^-22 (v_rcp_f32 is good to 1 ulp, lx
+//    itself is rounded once), rho and add / lx within 2^-21.4, r_1 within 2^-21.3 of |rho| * D + |x1|: every product within 2^-21 of its
+//    magnitude, together below 2^-21 * mag;  the f64 evaluation of the reference score itself (~2^-50 of the same magnitudes) and
+//    the inversion of the similarity transform (z_threshold's own allowance) are far inside.
+// slack = 3 + 2^-20 * mag, rounded up to an integer: twice the bound.  A weird row (lx <= 0, non-finite, mag too large) gets
+// K = +inf and zero constants: every one of its pairs passes and is scored exactly.
+struct RowK {
+  float r0, r1, r2, r3, K;
+};
+__device__ __forceinline__ RowK row_constants(double al, double au, double add, double x1, float D, int sim, const float *__restrict__ gmax) {
+  const float lxf = (float)(au - al), alf = (float)al, addf = (float)add, x1f = (float)x1;
+  const float r0 = __builtin_amdgcn_rcpf(lxf);
+  const float rho = alf * r0;
+  RowK k;
+  k.r0 = r0;
+  k.r1 = -fmaf(rho, D, x1f);
+  k.r2 = -rho;
+  k.r3 = (sim == 0 ? addf : -addf) * r0;
+  // gmax: S * max over the group's queries of |zth / beta| (finite ones), |ay / ly|, |y1|, 1 / beta, and S * max sum of query values
+  const float mag = fmaf(gmax[0], fabsf(r0), fmaf(gmax[1], fmaf(fabsf(rho), D, fabsf(x1f)), fmaf(gmax[2], fabsf(rho), fmaf(gmax[3], fabsf(k.r3), gmax[4]))));
+  // NaN anywhere: not ok.  r0 >= 1e-6 (lx <= 1e6): a query that accepts everything carries the constant 3e38 and must still lift the
+  // sum far above the limit
+  const bool ok = lxf > 0.0f && r0 >= 1.0e-6f && mag < kMfmaMagLimit;
+  if (ok) {
+    k.K = kMfmaBiasF + ceilf(fmaf(mag, 9.5367431640625e-07f, 4.0f));  // 3 + 2^-20 * mag, and 1 for the roundings of this line
+  } else {
+    k.r0 = k.r1 = k.r2 = k.r3 = 0.0f;
+    k.K = __uint_as_float(0x7f800000u);
+  }
+  return k;
+}
+// v_fma_f32 spelled out: left to itself the compiler pairs the chains of neighbouring accumulators into v_pk_fma_f32 (half rate on
+// gfx950) and spends a v_mov per operand pair on top
+__device__ __forceinline__ float fma_f32(float a, float b, float c) {
+#ifdef BBQ_MFMA_PLAIN_FMA
+  return fmaf(a, b, c);
+#else
+  float d;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+#endif
+}
+__device__ __forceinline__ int acc_init(const f32x4m qk, float r0, float r1, float r2, float r3, float K) {
+  return (int)__float_as_uint(fma_f32(qk.x, r0, fma_f32(qk.y, r1, fma_f32(qk.z, r2, fma_f32(qk.w, r3, K)))));
+}
+
 struct MfmaArgs {
   ScanArgs s;
-  const uint8_t *qbytes;   // [groups][W*4 words][2 halves][32 queries][16 B]  int8 query values in fragment order
-  const float *qmax;       // [groups][4]: max |ay|, max |ly|, max y1, max |qadd - cdp| over the group's queries
+  const uint8_t *qbytes;   // [groups][W*4 words][2 halves][32 queries][16 B]  int8 query values in fragment order (scaled by 8 >> dword when SCALED)
+  const float *qmax;       // [groups][4]: S-free maxima over the group's queries: |ay / ly|, |y1|, 1 / (cs * ly), sum of the query's values
   int32_t nq_total;
 };
 
 // Pairs that pass the pre-filter are pushed to a per-wave LDS queue (packed qc | row-in-tile << 20 | query << 26) and
 // scored exactly afterwards by ONE copy of the exact code, 64 pairs at a time.
 constexpr int kMfmaQueueCap = 512;
-constexpr int kMfmaChunksPerBlock = 8;
+constexpr int kMfmaChunksPerBlock = 16;
+
 template <int W, bool COMPACT>
-__global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const MfmaArgs a) {  // 4 waves per SIMD = 2 workgroups per CU: caps the allocation at 128 VGPRs
+struct TileRegs {
+  u32x4m c[W];     // this lane's row: its code words
+  f64x2m lu;       // {lower, upper}
+  double add;      // additionalCorrection
+  double x1;       // explicit quantizedComponentSum (has_x1 only)
+};
+
+template <int W, bool COMPACT>
+__device__ __forceinline__ void load_tile_regs(TileRegs<W, COMPACT> &t, const IndexView &idx, int64_t tile, int lane) {
+  const uint8_t *__restrict__ tp = idx.tiles + tile * (int64_t)idx.tile_stride;
+#pragma unroll
+  for (int j = 0; j < W; ++j) t.c[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4m *>(tp) + lane + j * kTileRows);
+  const uint8_t *__restrict__ cr = tp + (size_t)W * (kTileRows * 16);
+  if constexpr (COMPACT) {
+    const double *__restrict__ ex = idx.exact + (tile * kTileRows + lane) * 4;
+    t.lu = __builtin_nontemporal_load(reinterpret_cast<const f64x2m *>(ex));
+    t.add = __builtin_nontemporal_load(ex + 2);
+    t.x1 = 0.0;
+  } else {
+    t.lu = __builtin_nontemporal_load(reinterpret_cast<const f64x2m *>(cr) + lane);
+    t.add = __builtin_nontemporal_load(reinterpret_cast<const double *>(cr + 1024) + lane);
+    t.x1 = idx.has_x1 ? __builtin_nontemporal_load(reinterpret_cast<const double *>(cr + 1536) + lane) : 0.0;
+  }
+}
+
+// 4 waves per SIMD = 2 workgroups per CU (128 VGPRs) up to 1024-d; 1536-d rows hold 48 code registers: one workgroup per CU
+template <int W, bool COMPACT, bool SCALED>
+__global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kernel(const MfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT = kChunkRows;
   constexpr int NW = kChunkRows / 64;
   constexpr int WORDS = W * 4;
+  constexpr int S = SCALED ? 8 : 1;
   u32x4m *s_B = reinterpret_cast<u32x4m *>(smem);                                    // [WORDS*2][32]
-  f32x4m *s_qk = reinterpret_cast<f32x4m *>(smem + (size_t)WORDS * 2 * 32 * 16);     // [32] per-query pre-filter constants {cs*ay, cs*ly, y1, zth - margin}
-  float *s_x1 = reinterpret_cast<float *>(s_qk + kMfmaQueries);                      // [NW][64] popcount of every tile row (exact in f32), for the survivors' exact scores
+  f32x4m *s_qk = reinterpret_cast<f32x4m *>(smem + (size_t)WORDS * 2 * 32 * 16);     // [32] per-query constants -S * {zth/beta, ay/ly, y1, 1/beta}
+  float *s_x1 = reinterpret_cast<float *>(s_qk + kMfmaQueries);                      // [NW][64] component sum of every tile row, for the survivors' exact scores
   uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_x1 + NW * 64);                  // [NW][kMfmaQueueCap]
   uint32_t *s_qcount = s_queue + NW * kMfmaQueueCap;                                 // [NW] (+ padding to 16 B)
   QueryParams *s_qp = reinterpret_cast<QueryParams *>(s_qcount + 8);                 // [32]
-  double *s_zth = reinterpret_cast<double *>(s_qp + kMfmaQueries);                   // [32]
-  uint32_t *s_theta = reinterpret_cast<uint32_t *>(s_zth + kMfmaQueries);            // [32]
+  float *s_gmax = reinterpret_cast<float *>(s_qp + kMfmaQueries);                    // [8]: the group's magnitude maxima (row_constants)
+  uint32_t *s_theta = reinterpret_cast<uint32_t *>(s_gmax + 8);                      // [32]
   uint32_t *s_cnt = s_theta + kMfmaQueries;                                          // [32]
   uint64_t *s_ent = reinterpret_cast<uint64_t *>(s_cnt + kMfmaQueries);              // [32][cap]
 
@@ -125,50 +232,60 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
   {
     const u32x4m *__restrict__ gb = reinterpret_cast<const u32x4m *>(a.qbytes) + (size_t)group * WORDS * 2 * 32;
     for (int i = tid; i < WORDS * 2 * 32; i += NT) s_B[i] = gb[i];
-    if (tid < kMfmaQueries) {
-      QueryParams p{};
-      uint32_t th = 0xFFFFFFFFu;  // lanes without a query accept nothing
-      if (tid < nb) { p = a.s.qparams[q0 + tid]; th = a.s.theta[q0 + tid]; }
-      s_qp[tid] = p;
-      s_theta[tid] = th;
-      const double zt = tid < nb ? z_threshold(th, p) : DBL_MAX;
-      s_zth[tid] = zt;
-      s_cnt[tid] = 0;
-      // what the pre-filter compares with, per query: cs = 2 for EUCLIDEAN (z = 2s - xadd), 1 otherwise.  Lanes without a query get a
-      // threshold nothing passes.  (float)zt rounds; the compare carries its own margin
-      const float csf = p.sim == 0 ? 2.0f : 1.0f;
-      const float zth = (float)zt;
-      f32x4m qk;
-      qk.x = csf * (float)p.ay; qk.y = csf * (float)p.ly; qk.z = (float)p.y1; qk.w = zth - 1e-6f * (fabsf(zth) + 1.0f);
-      s_qk[tid] = qk;
-    }
+    if (tid < 8) s_gmax[tid] = 0.0f;
     if (tid < NW) s_qcount[tid] = 0;
+  }
+  __syncthreads();
+  if (tid < kMfmaQueries) {
+    QueryParams p{};
+    uint32_t th = 0xFFFFFFFFu;
+    f32x4m qk;
+    // lanes without a query: the largest finite threshold - nothing of an ordinary row passes (a weird row's pairs are dropped later)
+    qk.x = -3.0e38f; qk.y = 0.0f; qk.z = 0.0f; qk.w = 0.0f;
+    if (tid < nb) {
+      p = a.s.qparams[q0 + tid];
+      th = a.s.theta[q0 + tid];
+      const double zt = z_threshold(th, p);
+      const double beta = (p.sim == 0 ? 2.0 : 1.0) * p.ly;   // > 0 and finite: the host sends no other query here (mfma_query_ok)
+      // -S * zth / beta, clamped to the finite floats: "accept everything" (zth = -DBL_MAX) becomes +3e38, which no ordinary row's sum
+      // brings back below the limit
+      double A = -(double)S * (zt / beta);
+      if (!(A <= 3.0e38)) A = 3.0e38;
+      if (!(A >= -3.0e38)) A = -3.0e38;
+      qk.x = (float)A;
+      qk.y = (float)(-(double)S * (p.ay / p.ly));
+      qk.z = (float)(-(double)S * p.y1);
+      qk.w = (float)(-(double)S / beta);
+      if (fabsf(qk.x) < 1.0e38f) atomicMax(reinterpret_cast<uint32_t *>(s_gmax), __float_as_uint(fabsf(qk.x) * 1.0000002f));  // non-negative floats order like their bits
+    }
+    s_qp[tid] = p;
+    s_theta[tid] = th;
+    s_cnt[tid] = 0;
+    s_qk[tid] = qk;
+    if (tid == 0) {  // the host's maxima are S-free and rounded up
+      const float *__restrict__ gm = a.qmax + (size_t)group * 4;
+      s_gmax[1] = (float)S * gm[0];
+      s_gmax[2] = (float)S * gm[1];
+      s_gmax[3] = (float)S * gm[2];
+      s_gmax[4] = (float)S * gm[3];
+    }
   }
   __syncthreads();
 
   const int64_t n_tiles = (a.s.idx.n_rows + kTileRows - 1) / kTileRows;
-  // A workgroup is persistent over kMfmaChunksPerBlock consecutive chunks of the same 32 queries: the query fragments are
-  // staged once, and the codes of the next chunk's tile are prefetched into registers while the current one is computed.
+  const int sim = s_qp[0].sim;                  // uniform over the call
+  const float Df = (float)a.s.idx.dim;
+  // A workgroup is persistent over kMfmaChunksPerBlock consecutive chunks of the same 32 queries: the query fragments and constants are
+  // staged once, and a wave's next tile is loaded while the current one is tested.
   const int lc0 = blockIdx.x * kMfmaChunksPerBlock;
-  u32x4m cnext[W];
-  u32x2m ccnext = {0u, 0u};  // .x: this lane's bf16 pair, .y: the tile's additive-correction bound (min for EUCLIDEAN, max otherwise)
+  TileRegs<W, COMPACT> t;
   {
     const int64_t t0 = (a.s.chunk_begin + lc0) * kTilesPerChunk + wave;
-    if (lc0 < a.s.n_chunks && t0 < n_tiles) {
-      const uint8_t *__restrict__ tp0 = a.s.idx.tiles + t0 * (int64_t)a.s.idx.tile_stride;
-#pragma unroll
-      for (int j = 0; j < W; ++j) cnext[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4m *>(tp0) + lane + j * kTileRows);
-      if constexpr (COMPACT) {
-        const uint8_t *cr0 = tp0 + (size_t)W * (kTileRows * 16);
-        ccnext.x = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(cr0) + lane);
-        ccnext.y = __float_as_uint(a.s.idx.add_range[t0 * 2 + (s_qp[0].sim == 0 ? 0 : 1)]);
-      }
-    }
+    if (lc0 < a.s.n_chunks && t0 < n_tiles) load_tile_regs<W, COMPACT>(t, a.s.idx, t0, lane);
   }
 #pragma unroll 1
   for (int ci = 0; ci < kMfmaChunksPerBlock; ++ci) {
-  // opaque zero, redefined every iteration: keeps the compiler from hoisting the 24 query-fragment LDS reads out of
-  // the chunk loop (96 VGPRs held across the loop -> 252 VGPRs, occupancy 2 and a slower kernel)
+  // opaque zero, redefined every iteration: keeps the compiler from hoisting the query-fragment LDS reads out of the chunk loop
   int lds_off;
   asm volatile("v_mov_b32 %0, 0" : "=v"(lds_off));
   const int lc = lc0 + ci;           // chunk index inside this launch
@@ -177,183 +294,144 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
   const int64_t tile = chunk * kTilesPerChunk + wave;
 
   if (tile < n_tiles) {  // wave-uniform
-    const int sim = s_qp[0].sim;            // uniform over the call (lanes without a query hold zeros)
-    const float *__restrict__ gm = a.qmax + (size_t)group * 4;
-    const float AYmax = gm[0], LYmax = gm[1], Y1max = gm[2];
-
     const uint8_t *__restrict__ tp = a.s.idx.tiles + tile * (int64_t)a.s.idx.tile_stride;
     const uint8_t *__restrict__ cr = tp + (size_t)W * (kTileRows * 16);
-    const int64_t row_l = tile * kTileRows + lane;  // the row whose codes this lane loads
-    const u32x4m *__restrict__ cp = reinterpret_cast<const u32x4m *>(tp) + lane;
-    u32x4m c[W];
-#pragma unroll
-    for (int j = 0; j < W; ++j) c[j] = cnext[j];
-    const u32x2m cc_cur = ccnext;
-    {  // prefetch the next chunk's tile (same wave slot) while this one is computed
-      const int64_t tn = tile + kTilesPerChunk;
-      if (ci + 1 < kMfmaChunksPerBlock && lc + 1 < a.s.n_chunks && tn < n_tiles) {
-        const uint8_t *__restrict__ tpn = a.s.idx.tiles + tn * (int64_t)a.s.idx.tile_stride;
-#pragma unroll
-        for (int j = 0; j < W; ++j) cnext[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4m *>(tpn) + lane + j * kTileRows);
-        if constexpr (COMPACT) {
-          const uint8_t *crn = tpn + (size_t)W * (kTileRows * 16);
-          ccnext.x = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(crn) + lane);
-          ccnext.y = __float_as_uint(a.s.idx.add_range[tn * 2 + (s_qp[0].sim == 0 ? 0 : 1)]);
-        }
-      }
-    }
-    (void)cp;
-    double al, au, aadd, ea, eu, eadd;
-    if constexpr (COMPACT) {
-      const u32x2m cc = cc_cur;
-      al = (double)__uint_as_float(cc.x << 16);
-      au = (double)__uint_as_float(cc.x & 0xffff0000u);
-      aadd = (double)__uint_as_float(cc.y);
-      const double rel = 0.0078125 * (1.0 + 1.0 / 65536.0);
-      ea = fabs(al) * rel + 1e-37;
-      eu = fabs(au) * rel + 1e-37;
-      eadd = fabs(aadd) * 1.1920928955078125e-07 + 1e-37;
-    } else {
-      const f64x2m lu = __builtin_nontemporal_load(reinterpret_cast<const f64x2m *>(cr) + lane);
-      al = lu.x; au = lu.y;
-      aadd = __builtin_nontemporal_load(reinterpret_cast<const double *>(cr + 1024) + lane);
-      // the f32 copies used by the pre-filter are rounded: 2^-24 relative
-      ea = fabs(al) * 6e-8 + 1e-37; eu = fabs(au) * 6e-8 + 1e-37; eadd = fabs(aadd) * 6e-8 + 1e-37;
-    }
+    // ---- my row's constants (tile row `lane`), then both row groups' through one swap each: [0] = row n, [1] = row 32 + n
     uint32_t ones = 0;
 #pragma unroll
-    for (int j = 0; j < W; ++j) ones += __popc(c[j].x) + __popc(c[j].y) + __popc(c[j].z) + __popc(c[j].w);
-    double x1row = (double)ones;  // quantizedComponentSum of a 1-bit row is its popcount ...
-    if (a.s.idx.has_x1) x1row = reinterpret_cast<const double *>(cr + 1536)[lane];  // ... unless the index says otherwise
-    // row constants of the pre-filter for MY row (tile row `lane`), in registers:
-    //   k0 = {R1, D - x1, x1, al}   k1 = {lx, ca*add + slack, ea, eu}
-    f32x4m k0, k1;
-    {
-      const double D = s_qp[0].dimd;   // same for every query of the batch
-      const double x1 = x1row, lx = au - al;
-      const double R1 = al * D + lx * x1;
-      const double cs_d = sim == 0 ? 2.0 : 1.0, ca_d = sim == 0 ? -1.0 : 1.0;
-      // f32 evaluation slack: 8 roundings of terms bounded with the group's largest query constants, doubled
-      const double F = (double)AYmax * fabs(R1) + (double)LYmax * (double)Y1max * (fabs(al) + fabs(lx)) + fabs(aadd) + 1.0;
-      const double slack = cs_d * (2e-6 * F + 1e-3 * (ea + eu) * ((double)AYmax * D + 2.0 * (double)LYmax * (double)Y1max)) + eadd * 1.001;
-      k0.x = (float)R1; k0.y = (float)(D - x1); k0.z = (float)x1; k0.w = (float)al;
-      // non-finite or huge rows: force a pass (an infinite slack makes every compare below fail to reject)
-      const bool weird = !(fabs(R1) + fabs(al) + fabs(lx) + fabs(aadd) < 1e30);
-      const float slack32 = weird ? __uint_as_float(0x7f800000u) : (float)slack * 1.001f + 1e-30f;
-      k1.x = (float)lx; k1.y = (float)(ca_d * aadd) + slack32; k1.z = (float)(ea * 1.001); k1.w = (float)(eu * 1.001);   // unscaled: the pair loop carries cs in A and B
-      // (float)(ca*aadd) + slack32 rounds once more: one extra ulp of |ca*aadd| is inside the 1.001 factors of slack (eadd part)
-      s_x1[wave * 64 + lane] = k0.z;   // for the survivors' exact scores (any lane may score any row of the tile)
-    }
-    // ---- the contraction, one row group at a time: C[m = query][n = row of the group] over WORDS k-steps of 32 dims, then the
-    //      pre-filter of its 32 x 32 pairs (a lane: 16 queries x its column's row); one accumulator tile live keeps the kernel under 128 VGPRs
-    uint32_t *__restrict__ queue = s_queue + (size_t)wave * kMfmaQueueCap;
-    const int rows_here = (int)min((int64_t)kTileRows, a.s.idx.n_rows - tile * kTileRows);
-#pragma unroll 1
+    for (int j = 0; j < W; ++j) ones += __popc(t.c[j].x) + __popc(t.c[j].y) + __popc(t.c[j].z) + __popc(t.c[j].w);
+    double x1row = (double)ones;                 // quantizedComponentSum of a 1-bit row is its popcount ...
+    if (a.s.idx.has_x1) x1row = t.x1;            // ... unless the index says otherwise
+    const RowK mine = row_constants(t.lu.x, t.lu.y, t.add, x1row, Df, sim, s_gmax);
+    s_x1[wave * 64 + lane] = (float)x1row;       // for the survivors' exact scores (any lane may score any row of the tile)
+    const auto k0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r0), __float_as_uint(mine.r0), false, false);
+    const auto k1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r1), __float_as_uint(mine.r1), false, false);
+    const auto k2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r2), __float_as_uint(mine.r2), false, false);
+    const auto k3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r3), __float_as_uint(mine.r3), false, false);
+    const auto kK = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.K), __float_as_uint(mine.K), false, false);
+    float ra[2][5];
+#pragma unroll
     for (int rg = 0; rg < 2; ++rg) {
-      i32x16m acc = {0};
-#pragma unroll
-      for (int g = 0; g < WORDS; ++g) {
-        const uint32_t w = (g & 3) == 0 ? c[g >> 2].x : (g & 3) == 1 ? c[g >> 2].y : (g & 3) == 2 ? c[g >> 2].z : c[g >> 2].w;
-        // v_permlane32_swap(w, w): [0] = {own | partner (lane-32)}, [1] = {partner (lane+32) | own}: exactly the word of
-        // tile row 32*rg + lane%32 (lanes of the other half borrow their partner's row)
-        const auto sw2 = __builtin_amdgcn_permlane32_swap(w, w, false, false);
-        const uint32_t aw = (rg == 0 ? sw2[0] : sw2[1]) >> (4 * h);
-        // this half supplies 16 of the word's 32 dims: bits 4h+c+8i -> byte i of dword c (one shift + one AND per dword;
-        // the host lays the query bytes out in the same order, fill_query_mfma)
-        i32x4m R;
-        R.x = (int)(aw & 0x01010101u); R.y = (int)((aw >> 1) & 0x01010101u);
-        R.z = (int)((aw >> 2) & 0x01010101u); R.w = (int)((aw >> 3) & 0x01010101u);
-        const u32x4m bq = s_B[(g * 2 + h) * 32 + n + lds_off];
-        i32x4m Q;
-        Q.x = (int)bq.x; Q.y = (int)bq.y; Q.z = (int)bq.z; Q.w = (int)bq.w;
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Q, R, acc, 0, 0, 0);   // A = queries (m), B = rows (n)
-      }
-      // per (query, row) pre-filter; this lane owns tile row rit and 16 queries of the group
-      const int rit = 32 * rg + n;
-      const bool row_ok = rit < rows_here;
-      // the constants of tile row rit: my own row when rg == h, otherwise my half-wave partner's (fetched here, per row group, so that
-      // only one set is live).  swap(v, v): [0] = {own | partner(lane - 32)}, [1] = {partner(lane + 32) | own}
-      f32x4m r0 = k0, r1 = k1;
-      {  // every lane takes part in the swaps (a swap under a half-wave branch would read inactive lanes); the select follows
-        const bool other = rg != h;
-        const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(k0.x), __float_as_uint(k0.x), false, false);
-        const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(k0.y), __float_as_uint(k0.y), false, false);
-        const auto sz = __builtin_amdgcn_permlane32_swap(__float_as_uint(k0.z), __float_as_uint(k0.z), false, false);
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(k0.w), __float_as_uint(k0.w), false, false);
-        const auto tx = __builtin_amdgcn_permlane32_swap(__float_as_uint(k1.x), __float_as_uint(k1.x), false, false);
-        const auto ty = __builtin_amdgcn_permlane32_swap(__float_as_uint(k1.y), __float_as_uint(k1.y), false, false);
-        const auto tz = __builtin_amdgcn_permlane32_swap(__float_as_uint(k1.z), __float_as_uint(k1.z), false, false);
-        const auto tw = __builtin_amdgcn_permlane32_swap(__float_as_uint(k1.w), __float_as_uint(k1.w), false, false);
-        if (other) {
-          r0.x = __uint_as_float(h ? sx[0] : sx[1]); r0.y = __uint_as_float(h ? sy[0] : sy[1]);
-          r0.z = __uint_as_float(h ? sz[0] : sz[1]); r0.w = __uint_as_float(h ? sw[0] : sw[1]);
-          r1.x = __uint_as_float(h ? tx[0] : tx[1]); r1.y = __uint_as_float(h ? ty[0] : ty[1]);
-          r1.z = __uint_as_float(h ? tz[0] : tz[1]); r1.w = __uint_as_float(h ? tw[0] : tw[1]);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * h;  // query of this accumulator
-        const int qc = acc[r];
-        const f32x4m qk = s_qk[m];                    // {cs*ay, cs*ly, y1, zth - margin}: the same address for the whole half-wave
-        const float ayz = qk.x, lyz = qk.y, y1q = qk.z;
-        const float qcf = (float)qc;
-        const float u = fmaf(r1.x, qcf, r0.w * y1q);                 // al*y1 + lx*qc
-        const float z = fmaf(lyz, u, fmaf(ayz, r0.x, r1.y));         // cs*(ay*R1 + ly*u) + ca*add + slack
-        // the error terms in the same scaling: cs*A, cs*B against ea, eu (cs is 1 or 2: scaling by it commutes with every rounding,
-        // so this is bit for bit |A|*(cs*ea) + |B|*(cs*eu) with A, B from the unscaled ay, ly - two multiplications per pair less)
-        const float Ae = fmaf(lyz, y1q - qcf, ayz * r0.y);           // cs*(ay*(D-x1) + ly*(y1-qc))
-        const float Be = fmaf(lyz, qcf, ayz * r0.z);                 // cs*(ay*x1 + ly*qc)
-        const float zu = fmaf(fabsf(Ae), r1.z, fmaf(fabsf(Be), r1.w, z));
-        // NaN anywhere => the compare fails => pass; an overflowed (infinite) zu proves nothing either: pass
-        const bool pass = m < nb && row_ok && (!(zu <= qk.w) || !(fabsf(zu) <= 3.0e38f));
-        if (pass) {
-          const uint32_t slot = atomicAdd(&s_qcount[wave], 1u);
-          if (slot < (uint32_t)kMfmaQueueCap) queue[slot] = (uint32_t)qc | ((uint32_t)rit << 20) | ((uint32_t)m << 26);
-          else atomicOr(a.s.flags + q0 + m, kFlagOverflow);  // more survivors than the queue holds: this query goes dense
-        }
-      }
+      ra[rg][0] = __uint_as_float(k0[rg]); ra[rg][1] = __uint_as_float(k1[rg]); ra[rg][2] = __uint_as_float(k2[rg]);
+      ra[rg][3] = __uint_as_float(k3[rg]); ra[rg][4] = __uint_as_float(kK[rg]);
     }
-    // ---- exact scores of the survivors (same-wave LDS traffic: program order is enough)
-    const uint32_t n_pass = min(s_qcount[wave], (uint32_t)kMfmaQueueCap);
-    for (uint32_t i = lane; i < n_pass; i += 64) {
-      const uint32_t e = queue[i];
-      const int qc = (int)(e & 0xFFFFFu), rit = (int)((e >> 20) & 63u), qn = (int)(e >> 26);
-      const QueryParams pq = s_qp[qn];
-      const int64_t row = tile * kTileRows + rit;
-      double lo, up, ad;
-      if constexpr (COMPACT) {
-        const double *__restrict__ ex = a.s.idx.exact + row * 4;
-        lo = ex[0]; up = ex[1]; ad = ex[2];
+    // ---- the accumulators start at the (negated, biased) thresholds of their pairs
+    i32x16m acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * h;  // query of this accumulator
+      const f32x4m qk = s_qk[m + lds_off];            // the same address for the whole half-wave
+      acc0[r] = acc_init(qk, ra[0][0], ra[0][1], ra[0][2], ra[0][3], ra[0][4]);
+      acc1[r] = acc_init(qk, ra[1][0], ra[1][1], ra[1][2], ra[1][3], ra[1][4]);
+    }
+    // ---- the contraction: C[m = query][n = row of the group] += sum over WORDS k-steps of 32 dims
+#pragma unroll
+    for (int g = 0; g < WORDS; ++g) {
+      const uint32_t w = (g & 3) == 0 ? t.c[g >> 2].x : (g & 3) == 1 ? t.c[g >> 2].y : (g & 3) == 2 ? t.c[g >> 2].z : t.c[g >> 2].w;
+      // swap(w, w >> 4): [0] = {row n's word | row n's word >> 4}, [1] = {row 32+n's word | row 32+n's word >> 4}: the lower half-wave
+      // supplies the low nibble of every byte, the upper one the high nibble, of the row group's row n
+      const auto sw = __builtin_amdgcn_permlane32_swap(w, w >> 4, false, false);
+      const u32x4m bq = s_B[(g * 2 + h) * 32 + n + lds_off];
+      i32x4m Q;
+      Q.x = (int)bq.x; Q.y = (int)bq.y; Q.z = (int)bq.z; Q.w = (int)bq.w;
+      i32x4m R0, R1;
+      if constexpr (SCALED) {  // bit c of every nibble where it stands: int8 values {0, 2^c} against query bytes scaled by 8 >> c
+        R0.x = (int)(sw[0] & 0x01010101u); R0.y = (int)(sw[0] & 0x02020202u); R0.z = (int)(sw[0] & 0x04040404u); R0.w = (int)(sw[0] & 0x08080808u);
+        R1.x = (int)(sw[1] & 0x01010101u); R1.y = (int)(sw[1] & 0x02020202u); R1.z = (int)(sw[1] & 0x04040404u); R1.w = (int)(sw[1] & 0x08080808u);
       } else {
-        lo = reinterpret_cast<const double *>(cr)[2 * rit];
-        up = reinterpret_cast<const double *>(cr)[2 * rit + 1];
-        ad = reinterpret_cast<const double *>(cr + 1024)[rit];
+        R0.x = (int)(sw[0] & 0x01010101u); R0.y = (int)((sw[0] >> 1) & 0x01010101u); R0.z = (int)((sw[0] >> 2) & 0x01010101u); R0.w = (int)((sw[0] >> 3) & 0x01010101u);
+        R1.x = (int)(sw[1] & 0x01010101u); R1.y = (int)((sw[1] >> 1) & 0x01010101u); R1.z = (int)((sw[1] >> 2) & 0x01010101u); R1.w = (int)((sw[1] >> 3) & 0x01010101u);
       }
-      double x1d = (double)s_x1[wave * 64 + rit];  // popcount of the row: exact in f32 (<= 2^24)
-      if (a.s.idx.has_x1) x1d = reinterpret_cast<const double *>(cr + 1536)[rit];  // explicit sums may not be f32-exact
-      const double s64 = m_score_f64((double)qc, lo, up, ad, x1d, pq);
-      const float s32 = (float)s64;
-      const uint32_t bits = __float_as_uint(s32);
-      if (s32 != s32) atomicOr(a.s.flags + q0 + qn, kFlagNaN);
-      else if (key_of_bits(bits) > s_theta[qn]) {
-        const uint64_t ent = ((uint64_t)(uint32_t)(a.s.row_id_base + row) << 32) | bits;
-        if (a.s.append_lists) {
-          // append mode: straight into the query's list (unordered inside the segment; the finalize launch takes its keys from there
-          // and the rare host replay sorts).  No per-chunk staging, so the waves of a workgroup never wait for each other (the slot
-          // mode has three barriers per tile): 49.6 -> 53.6 K q/s at 10 M x 768
-          const uint32_t slot = atomicAdd(a.s.append_counts + q0 + qn, 1u);
-          const int64_t at = (int64_t)a.s.append_base[2 * (q0 + qn)] + slot;
-          if (at < a.s.append_cap) a.s.append_lists[(size_t)(q0 + qn) * a.s.append_cap + at] = ent;
-          else atomicOr(a.s.flags + q0 + qn, kFlagOverflow);
-        } else {
-          const uint32_t slot = atomicAdd(&s_cnt[qn], 1u);
-          if (slot < (uint32_t)a.s.cap) s_ent[(size_t)qn * a.s.cap + slot] = ent;
+      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Q, R0, acc0, 0, 0, 0);   // A = queries (m), B = rows (n)
+      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Q, R1, acc1, 0, 0, 0);
+    }
+    // ---- the codes are consumed: the next tile of this wave slot goes into the same registers while this one is tested
+    {
+      const int64_t tn = tile + kTilesPerChunk;
+      if (ci + 1 < kMfmaChunksPerBlock && lc + 1 < a.s.n_chunks && tn < n_tiles) load_tile_regs<W, COMPACT>(t, a.s.idx, tn, lane);
+    }
+    // ---- any accumulator above the bias?
+    int mx = acc0[0];
+#pragma unroll
+    for (int r = 1; r < 16; r += 2) mx = max(mx, max(acc0[r], r + 1 < 16 ? acc0[r + 1] : acc0[r]));
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) mx = max(mx, max(acc1[r], acc1[r + 1]));
+    uint32_t *__restrict__ queue = s_queue + (size_t)wave * kMfmaQueueCap;
+    if (__any(mx > kMfmaBias)) {
+      const int rows_here = (int)min((int64_t)kTileRows, a.s.idx.n_rows - tile * kTileRows);
+      // survivors: take qcDist from the difference to the accumulator's initial value, which is derived again (the same four
+      // instructions on the same operands: the same bits).  The constants pass through an empty asm so that the compiler cannot keep
+      // all 32 initial values alive across the contraction instead.
+      float rb[2][5];
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          rb[rg][j] = ra[rg][j];
+          asm volatile("" : "+v"(rb[rg][j]));
+        }
+      // (the lane's coordinates as well: everything derived from them here - 32 queue words, 16 query-exists masks - would otherwise be
+      // hoisted out of the chunk loop and held in registers for the whole kernel)
+      int h2 = h, n2 = n;
+      asm volatile("" : "+v"(h2), "+v"(n2));
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg) {
+        const int rit = 32 * rg + n2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int av = rg == 0 ? acc0[r] : acc1[r];
+          if (__any(av > kMfmaBias)) {  // wave-uniform: most accumulators have no survivor in any lane
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * h2;
+            const f32x4m qk = s_qk[m];
+            const int init = acc_init(qk, rb[rg][0], rb[rg][1], rb[rg][2], rb[rg][3], rb[rg][4]);
+            if (av > kMfmaBias && m < nb && rit < rows_here) {
+              const uint32_t qc = (uint32_t)(av - init) / (uint32_t)S;
+              const uint32_t slot = atomicAdd(&s_qcount[wave], 1u);
+              if (slot < (uint32_t)kMfmaQueueCap) queue[slot] = qc | ((uint32_t)rit << 20) | ((uint32_t)m << 26);
+              else atomicOr(a.s.flags + q0 + m, kFlagOverflow);  // more survivors than the queue holds: this query goes dense
+            }
+          }
         }
       }
+      // ---- exact scores of the survivors (same-wave LDS traffic: program order is enough)
+      const uint32_t n_pass = min(s_qcount[wave], (uint32_t)kMfmaQueueCap);
+      for (uint32_t i = lane; i < n_pass; i += 64) {
+        const uint32_t e = queue[i];
+        const int qc = (int)(e & 0xFFFFFu), rit = (int)((e >> 20) & 63u), qn = (int)(e >> 26);
+        const QueryParams pq = s_qp[qn];
+        const int64_t row = tile * kTileRows + rit;
+        double lo, up, ad;
+        if constexpr (COMPACT) {
+          const double *__restrict__ ex = a.s.idx.exact + row * 4;
+          lo = ex[0]; up = ex[1]; ad = ex[2];
+        } else {
+          lo = reinterpret_cast<const double *>(cr)[2 * rit];
+          up = reinterpret_cast<const double *>(cr)[2 * rit + 1];
+          ad = reinterpret_cast<const double *>(cr + 1024)[rit];
+        }
+        double x1d = (double)s_x1[wave * 64 + rit];  // popcount of the row: exact in f32 (<= 2^24)
+        if (a.s.idx.has_x1) x1d = reinterpret_cast<const double *>(cr + 1536)[rit];  // explicit sums may not be f32-exact
+        const double s64 = m_score_f64((double)qc, lo, up, ad, x1d, pq);
+        const float s32 = (float)s64;
+        const uint32_t bits = __float_as_uint(s32);
+        if (s32 != s32) atomicOr(a.s.flags + q0 + qn, kFlagNaN);
+        else if (key_of_bits(bits) > s_theta[qn]) {
+          const uint64_t ent = ((uint64_t)(uint32_t)(a.s.row_id_base + row) << 32) | bits;
+          if (a.s.append_lists) {
+            // append mode: straight into the query's list (unordered inside the segment; the finalize launch takes its keys from there
+            // and the rare host replay sorts).  No per-chunk staging, so the waves of a workgroup never wait for each other
+            const uint32_t slot = atomicAdd(a.s.append_counts + q0 + qn, 1u);
+            const int64_t at = (int64_t)a.s.append_base[2 * (q0 + qn)] + slot;
+            if (at < a.s.append_cap) a.s.append_lists[(size_t)(q0 + qn) * a.s.append_cap + at] = ent;
+            else atomicOr(a.s.flags + q0 + qn, kFlagOverflow);
+          } else {
+            const uint32_t slot = atomicAdd(&s_cnt[qn], 1u);
+            if (slot < (uint32_t)a.s.cap) s_ent[(size_t)qn * a.s.cap + slot] = ent;
+          }
+        }
+      }
+      if (a.s.append_lists) s_qcount[wave] = 0;  // this wave's queue is its own: ready for its next tile
     }
-    (void)row_l;
-    if (a.s.append_lists) s_qcount[wave] = 0;  // this wave's queue is its own: ready for its next tile
   }
   if (a.s.append_lists) continue;  // workgroup-uniform: nothing to flush, nobody to wait for
   __syncthreads();
@@ -382,14 +460,18 @@ __global__ __launch_bounds__(kChunkRows, 4) void bbq_scan_mfma_kernel(const Mfma
 
 // ---------------------------------------------------------------------------------------------------------------------
 
-template <int W, bool COMPACT>
-static hipError_t launch_mfma_t(const MfmaArgs &a, int nq, int nc, hipStream_t s) {
+static size_t mfma_smem_bytes(int w16, int cap) {
   constexpr int NW = kChunkRows / 64;
-  const size_t smem = (size_t)W * 4 * 2 * 32 * 16 + (size_t)kMfmaQueries * 16 + (size_t)NW * 64 * 4 + (size_t)NW * kMfmaQueueCap * 4 + 32 +
-                      kMfmaQueries * (sizeof(QueryParams) + 8 + 4 + 4) + (size_t)kMfmaQueries * a.s.cap * 8 + 64;
+  return (size_t)w16 * 4 * 2 * 32 * 16 + (size_t)kMfmaQueries * 16 + (size_t)NW * 64 * 4 + (size_t)NW * kMfmaQueueCap * 4 + 32 +
+         kMfmaQueries * (sizeof(QueryParams) + 4 + 4) + 32 + (size_t)kMfmaQueries * (size_t)cap * 8 + 64;
+}
+
+template <int W, bool COMPACT, bool SCALED>
+static hipError_t launch_mfma_t(const MfmaArgs &a, int nq, int nc, hipStream_t s) {
+  const size_t smem = mfma_smem_bytes(W, a.s.cap);
   dim3 grid((unsigned)((nc + kMfmaChunksPerBlock - 1) / kMfmaChunksPerBlock), (unsigned)((nq + kMfmaQueries - 1) / kMfmaQueries), 1),
       block(kChunkRows, 1, 1);
-  auto kern = bbq_scan_mfma_kernel<W, COMPACT>;
+  auto kern = bbq_scan_mfma_kernel<W, COMPACT, SCALED>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
@@ -398,22 +480,27 @@ static hipError_t launch_mfma_t(const MfmaArgs &a, int nq, int nc, hipStream_t s
   return hipGetLastError();
 }
 
+template <int W>
+static hipError_t launch_mfma_w(const MfmaArgs &a, bool compact, bool scaled, int nq, int nc, hipStream_t s) {
+  if (compact) return scaled ? launch_mfma_t<W, true, true>(a, nq, nc, s) : launch_mfma_t<W, true, false>(a, nq, nc, s);
+  return scaled ? launch_mfma_t<W, false, true>(a, nq, nc, s) : launch_mfma_t<W, false, false>(a, nq, nc, s);
+}
+
 bool mfma_sweep_supported(const ScanArgs &a) {
   const int w = a.idx.w16;
   if (a.idx.store_bits != 1 || !(w == 1 || w == 6 || w == 8 || w == 12)) return false;
-  const size_t smem = (size_t)w * 4 * 2 * 32 * 16 + (size_t)(kChunkRows / 64) * (64 * 2 * 16 + kMfmaQueueCap * 4) + 4096 + (size_t)kMfmaQueries * a.cap * 8;
-  return smem <= 150 * 1024;
+  return mfma_smem_bytes(w, a.cap) <= 150 * 1024;
 }
 
-hipError_t launch_scan_mfma(const ScanArgs &sa, const uint8_t *qbytes, const float *qmax, int n_queries, int n_chunks, hipStream_t s) {
+hipError_t launch_scan_mfma(const ScanArgs &sa, const uint8_t *qbytes, const float *qmax, bool scaled, int n_queries, int n_chunks, hipStream_t s) {
   if (n_chunks <= 0 || n_queries <= 0) return hipSuccess;
   MfmaArgs a{sa, qbytes, qmax, n_queries};
   const bool compact = sa.idx.layout == kLayoutCompact;
   switch (sa.idx.w16) {
-    case 1: return compact ? launch_mfma_t<1, true>(a, n_queries, n_chunks, s) : launch_mfma_t<1, false>(a, n_queries, n_chunks, s);
-    case 6: return compact ? launch_mfma_t<6, true>(a, n_queries, n_chunks, s) : launch_mfma_t<6, false>(a, n_queries, n_chunks, s);
-    case 8: return compact ? launch_mfma_t<8, true>(a, n_queries, n_chunks, s) : launch_mfma_t<8, false>(a, n_queries, n_chunks, s);
-    case 12: return compact ? launch_mfma_t<12, true>(a, n_queries, n_chunks, s) : launch_mfma_t<12, false>(a, n_queries, n_chunks, s);
+    case 1: return launch_mfma_w<1>(a, compact, scaled, n_queries, n_chunks, s);
+    case 6: return launch_mfma_w<6>(a, compact, scaled, n_queries, n_chunks, s);
+    case 8: return launch_mfma_w<8>(a, compact, scaled, n_queries, n_chunks, s);
+    case 12: return launch_mfma_w<12>(a, compact, scaled, n_queries, n_chunks, s);
     default: return hipErrorInvalidValue;
   }
 }
