@@ -419,7 +419,7 @@ int ensure_slot(bbq_index *ix, Slot &s, int nq, bool own_lists) {
   s.hprefix = std::max<int64_t>(s.hprefix, hprefix);
   // theta | flags | topk_counts | list_counts | ovf_counts | append_counts live in one control block in front of the staged queries: the copy that
   // brings a sub-batch's queries also resets them (the host twin's control part stays zero)
-  s.ctrl_bytes = ((int64_t)Q * 28 + 255) / 256 * 256;
+  s.ctrl_bytes = ((int64_t)Q * (24 + 4 * kAppendStride) + 255) / 256 * 256;  // the append counters sit one per 128-byte line (kAppendStride)
   HIPCHK(hipMalloc((void **)&s.d_block, (size_t)(s.ctrl_bytes + Q * s.qbuf_bytes)));
   s.ctrl_clean = false;
   HIPCHK(hipHostMalloc((void **)&s.h_block, (size_t)(s.ctrl_bytes + Q * s.qbuf_bytes), hipHostMallocDefault));

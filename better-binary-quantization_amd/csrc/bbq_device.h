@@ -14,6 +14,11 @@ constexpr int kTilesPerChunk = kChunkRows / kTileRows;
 constexpr uint32_t kCountRedirect = 0x80000000u;  // chunk count: the entries live in the overflow area
 constexpr uint32_t kFlagOverflow = 1u;   // a candidate slot / list / key buffer overflowed
 constexpr uint32_t kFlagNaN = 2u;        // a NaN score was produced: order statistics are meaningless
+// Append counters (ScanArgs::append_counts, FinalizeArgs::append_counts): one per query, each in a 128-byte line of its own.  The
+// memory side retires returning atomics on ONE line one after the other (scripts/ubench/atomic_lines.hip: 5.8 ns each on 32 adjacent
+// words, 0.4 ns on 32 words in separate lines): with the counters of a sub-batch side by side the atomics of a sweep's workgroups
+// took longer than the sweep.
+constexpr int kAppendStride = 32;        // uint32 words between two queries' counters
 
 // Device layout of one index storage (DESIGN.md "HBM layout").  A tile record holds 64 rows:
 //   [w16][64] uint4    16-byte code chunk j of row r at (j*64 + r)*16      -> 1 KiB coalesced per wave load
@@ -106,7 +111,7 @@ struct ScanArgs {
   // care about the order; the rare host replay (equal scores) sorts the list by row first.
   uint64_t *append_lists;      // [Q][append_cap]
   const int32_t *append_base;  // [Q][2]: entries the list holds from the earlier segments (list_counts)
-  uint32_t *append_counts;     // [Q] entries this launch has reserved so far
+  uint32_t *append_counts;     // [Q][kAppendStride] entries this launch has reserved so far (word 0 of each query's line)
   int64_t append_cap;
   // dense output (every row), indexed by row - chunk_begin*1024
   float *dense_score32;        // [Q][dense_stride] or null
@@ -127,7 +132,7 @@ struct FinalizeArgs {
   int32_t cap;
   const uint64_t *ovf;         // flood tier of the scan launch (null: none)
   int32_t ovf_cap;
-  uint32_t *append_counts;     // [Q] non-null: the scan launch appended its candidates to the list itself (ScanArgs::append_lists);
+  uint32_t *append_counts;     // [Q][kAppendStride] non-null: the scan launch appended its candidates to the list itself (ScanArgs::append_lists);
                                // counts / entries are unused, the launch only takes the keys from list[base, base + count) and resets the counter
   // candidate list being built, ascending by global row
   uint64_t *lists;             // [Q][list_cap]

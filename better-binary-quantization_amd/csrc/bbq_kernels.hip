@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_kernel(const ScanArgs a) 
       const uint32_t cnt = *s_cnt;
       if (cnt == 0) return;
       __syncthreads();  // everyone has read *s_cnt
-      if (tid == 0) *s_cnt = atomicAdd(a.append_counts + q, cnt);
+      if (tid == 0) *s_cnt = atomicAdd(a.append_counts + (size_t)q * kAppendStride, cnt);
       __syncthreads();
       const int64_t at = (int64_t)a.append_base[2 * q] + *s_cnt;
       if (at + cnt > a.append_cap) {
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
   // the query's control words, all fetched at once (each was a memory round trip of its own on the critical path of a launch that
   // lasts ten microseconds): the scan launch that wrote them is over, nothing but thread 0 below changes them
   const int64_t base = a.emit ? a.list_counts[2 * q] : 0;
-  const uint32_t appended = a.append_counts ? a.append_counts[q] : 0u;
+  const uint32_t appended = a.append_counts ? a.append_counts[(size_t)q * kAppendStride] : 0u;
   const uint32_t tcount0 = (uint32_t)a.topk_counts[q];
   const uint32_t flags0 = a.flags[q];
   __syncthreads();  // every thread has read them before thread 0 rewrites them below
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const Fi
   } else if (a.append_counts) {
     // the scan launch appended its candidates to the list itself: only their keys are needed here
     m_new = appended;
-    if (tid == 0) a.append_counts[q] = 0u;
+    if (tid == 0) a.append_counts[(size_t)q * kAppendStride] = 0u;
     if (base + m_new > a.list_cap) m_new = 0;  // the workgroups that did not fit have flagged the query: it takes the dense path
 #pragma unroll 4
     for (uint32_t j = tid; j < m_new && j < (uint32_t)kFinalizeKeyCap; j += kFinalizeThreads) s_keys[j] = key_of_bits((uint32_t)list[base + j]);

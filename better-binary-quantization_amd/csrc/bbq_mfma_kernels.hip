@@ -39,6 +39,8 @@
 // results - are identical.
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include <math.h>
+#include <algorithm>
 #include "bbq_device.h"
 #include "bbq_launch.h"
 
@@ -172,12 +174,13 @@ struct MfmaArgs {
   const uint8_t *qbytes;   // [groups][W*4 words][2 halves][32 queries][16 B]  int8 query values in fragment order (scaled by 8 >> dword when SCALED)
   const float *qmax;       // [groups][4]: S-free maxima over the group's queries: |ay / ly|, |y1|, 1 / (cs * ly), sum of the query's values
   int32_t nq_total;
+  int32_t chunks_per_block;  // consecutive chunks one workgroup walks with the same 32 queries (launch_mfma_t)
 };
 
 // Pairs that pass the pre-filter are pushed to a per-wave LDS queue (packed qc | row-in-tile << 20 | query << 26) and
 // scored exactly afterwards by ONE copy of the exact code, 64 pairs at a time.
 constexpr int kMfmaQueueCap = 512;
-constexpr int kMfmaChunksPerBlock = 16;
+constexpr int kMfmaMaxChunksPerBlock = 16;
 
 template <int W, bool COMPACT>
 struct TileRegs {
@@ -215,8 +218,9 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
   constexpr int S = SCALED ? 8 : 1;
   u32x4m *s_B = reinterpret_cast<u32x4m *>(smem);                                    // [WORDS*2][32]
   f32x4m *s_qk = reinterpret_cast<f32x4m *>(smem + (size_t)WORDS * 2 * 32 * 16);     // [32] per-query constants -S * {zth/beta, ay/ly, y1, 1/beta}
-  float *s_x1 = reinterpret_cast<float *>(s_qk + kMfmaQueries);                      // [NW][64] component sum of every tile row, for the survivors' exact scores
-  uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_x1 + NW * 64);                  // [NW][kMfmaQueueCap]
+  f64x2m *s_lu = reinterpret_cast<f64x2m *>(s_qk + kMfmaQueries);                    // [NW][64] {lower, upper} of every tile row, for the survivors' exact scores ...
+  f64x2m *s_ax = s_lu + NW * 64;                                                     // [NW][64] ... and {additionalCorrection, component sum}: no trip to memory there
+  uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_ax + NW * 64);                  // [NW][kMfmaQueueCap]
   uint32_t *s_qcount = s_queue + NW * kMfmaQueueCap;                                 // [NW] (+ padding to 16 B)
   QueryParams *s_qp = reinterpret_cast<QueryParams *>(s_qcount + 8);                 // [32]
   float *s_gmax = reinterpret_cast<float *>(s_qp + kMfmaQueries);                    // [8]: the group's magnitude maxima (row_constants)
@@ -229,62 +233,65 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
   const int nb = min(kMfmaQueries, a.nq_total - q0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, h = lane >> 5;
-  {
-    const u32x4m *__restrict__ gb = reinterpret_cast<const u32x4m *>(a.qbytes) + (size_t)group * WORDS * 2 * 32;
-    for (int i = tid; i < WORDS * 2 * 32; i += NT) s_B[i] = gb[i];
-    if (tid < 8) s_gmax[tid] = 0.0f;
-    if (tid < NW) s_qcount[tid] = 0;
-  }
-  __syncthreads();
-  if (tid < kMfmaQueries) {
-    QueryParams p{};
-    uint32_t th = 0xFFFFFFFFu;
-    f32x4m qk;
-    // lanes without a query: the largest finite threshold - nothing of an ordinary row passes (a weird row's pairs are dropped later)
-    qk.x = -3.0e38f; qk.y = 0.0f; qk.z = 0.0f; qk.w = 0.0f;
-    if (tid < nb) {
-      p = a.s.qparams[q0 + tid];
-      th = a.s.theta[q0 + tid];
-      const double zt = z_threshold(th, p);
-      const double beta = (p.sim == 0 ? 2.0 : 1.0) * p.ly;   // > 0 and finite: the host sends no other query here (mfma_query_ok)
-      // -S * zth / beta, clamped to the finite floats: "accept everything" (zth = -DBL_MAX) becomes +3e38, which no ordinary row's sum
-      // brings back below the limit
-      double A = -(double)S * (zt / beta);
-      if (!(A <= 3.0e38)) A = 3.0e38;
-      if (!(A >= -3.0e38)) A = -3.0e38;
-      qk.x = (float)A;
-      qk.y = (float)(-(double)S * (p.ay / p.ly));
-      qk.z = (float)(-(double)S * p.y1);
-      qk.w = (float)(-(double)S / beta);
-      if (fabsf(qk.x) < 1.0e38f) atomicMax(reinterpret_cast<uint32_t *>(s_gmax), __float_as_uint(fabsf(qk.x) * 1.0000002f));  // non-negative floats order like their bits
-    }
-    s_qp[tid] = p;
-    s_theta[tid] = th;
-    s_cnt[tid] = 0;
-    s_qk[tid] = qk;
-    if (tid == 0) {  // the host's maxima are S-free and rounded up
-      const float *__restrict__ gm = a.qmax + (size_t)group * 4;
-      s_gmax[1] = (float)S * gm[0];
-      s_gmax[2] = (float)S * gm[1];
-      s_gmax[3] = (float)S * gm[2];
-      s_gmax[4] = (float)S * gm[3];
-    }
-  }
-  __syncthreads();
-
   const int64_t n_tiles = (a.s.idx.n_rows + kTileRows - 1) / kTileRows;
-  const int sim = s_qp[0].sim;                  // uniform over the call
-  const float Df = (float)a.s.idx.dim;
-  // A workgroup is persistent over kMfmaChunksPerBlock consecutive chunks of the same 32 queries: the query fragments and constants are
-  // staged once, and a wave's next tile is loaded while the current one is tested.
-  const int lc0 = blockIdx.x * kMfmaChunksPerBlock;
+  // A workgroup is persistent over chunks_per_block consecutive chunks of the same 32 queries: the query fragments and constants are
+  // staged once, and a wave's next tile is loaded while the current one is tested.  The first tile's loads are in flight during the
+  // prologue.
+  const int cpb = a.chunks_per_block;
+  const int lc0 = blockIdx.x * cpb;
   TileRegs<W, COMPACT> t;
   {
     const int64_t t0 = (a.s.chunk_begin + lc0) * kTilesPerChunk + wave;
     if (lc0 < a.s.n_chunks && t0 < n_tiles) load_tile_regs<W, COMPACT>(t, a.s.idx, t0, lane);
   }
+  // prologue: wave 0 derives the queries' constants (a few f64 divisions per query) while the other waves stage the query fragments
+  if (wave == 0) {
+    if (lane < 8) s_gmax[lane] = 0.0f;   // same wave as the atomicMax below: LDS operations of a wave execute in order
+    if (lane < NW) s_qcount[lane] = 0;
+    if (lane < kMfmaQueries) {
+      QueryParams p{};
+      uint32_t th = 0xFFFFFFFFu;
+      f32x4m qk;
+      // lanes without a query: the largest finite threshold - nothing of an ordinary row passes (a weird row's pairs are dropped later)
+      qk.x = -3.0e38f; qk.y = 0.0f; qk.z = 0.0f; qk.w = 0.0f;
+      if (lane < nb) {
+        p = a.s.qparams[q0 + lane];
+        th = a.s.theta[q0 + lane];
+        const double zt = z_threshold(th, p);
+        const double beta = (p.sim == 0 ? 2.0 : 1.0) * p.ly;   // > 0 and finite: the host sends no other query here (mfma_query_ok)
+        // -S * zth / beta, clamped to the finite floats: "accept everything" (zth = -DBL_MAX) becomes +3e38, which no ordinary row's sum
+        // brings back below the limit
+        double A = -(double)S * (zt / beta);
+        if (!(A <= 3.0e38)) A = 3.0e38;
+        if (!(A >= -3.0e38)) A = -3.0e38;
+        qk.x = (float)A;
+        qk.y = (float)(-(double)S * (p.ay / p.ly));
+        qk.z = (float)(-(double)S * p.y1);
+        qk.w = (float)(-(double)S / beta);
+        if (fabsf(qk.x) < 1.0e38f) atomicMax(reinterpret_cast<uint32_t *>(s_gmax), __float_as_uint(fabsf(qk.x) * 1.0000002f));  // non-negative floats order like their bits
+      }
+      s_qp[lane] = p;
+      s_theta[lane] = th;
+      s_cnt[lane] = 0;
+      s_qk[lane] = qk;
+      if (lane == 0) {  // the host's maxima are S-free and rounded up
+        const float *__restrict__ gm = a.qmax + (size_t)group * 4;
+        s_gmax[1] = (float)S * gm[0];
+        s_gmax[2] = (float)S * gm[1];
+        s_gmax[3] = (float)S * gm[2];
+        s_gmax[4] = (float)S * gm[3];
+      }
+    }
+  } else {
+    const u32x4m *__restrict__ gb = reinterpret_cast<const u32x4m *>(a.qbytes) + (size_t)group * WORDS * 2 * 32;
+    for (int i = tid - 64; i < WORDS * 2 * 32; i += NT - 64) s_B[i] = gb[i];
+  }
+  __syncthreads();
+
+  const int sim = s_qp[0].sim;                  // uniform over the call
+  const float Df = (float)a.s.idx.dim;
 #pragma unroll 1
-  for (int ci = 0; ci < kMfmaChunksPerBlock; ++ci) {
+  for (int ci = 0; ci < cpb; ++ci) {
   // opaque zero, redefined every iteration: keeps the compiler from hoisting the query-fragment LDS reads out of the chunk loop
   int lds_off;
   asm volatile("v_mov_b32 %0, 0" : "=v"(lds_off));
@@ -294,8 +301,6 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
   const int64_t tile = chunk * kTilesPerChunk + wave;
 
   if (tile < n_tiles) {  // wave-uniform
-    const uint8_t *__restrict__ tp = a.s.idx.tiles + tile * (int64_t)a.s.idx.tile_stride;
-    const uint8_t *__restrict__ cr = tp + (size_t)W * (kTileRows * 16);
     // ---- my row's constants (tile row `lane`), then both row groups' through one swap each: [0] = row n, [1] = row 32 + n
     uint32_t ones = 0;
 #pragma unroll
@@ -303,7 +308,12 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
     double x1row = (double)ones;                 // quantizedComponentSum of a 1-bit row is its popcount ...
     if (a.s.idx.has_x1) x1row = t.x1;            // ... unless the index says otherwise
     const RowK mine = row_constants(t.lu.x, t.lu.y, t.add, x1row, Df, sim, s_gmax);
-    s_x1[wave * 64 + lane] = (float)x1row;       // for the survivors' exact scores (any lane may score any row of the tile)
+    s_lu[wave * 64 + lane] = t.lu;               // for the survivors' exact scores (any lane may score any row of the tile)
+    {
+      f64x2m ax;
+      ax.x = t.add; ax.y = x1row;
+      s_ax[wave * 64 + lane] = ax;
+    }
     const auto k0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r0), __float_as_uint(mine.r0), false, false);
     const auto k1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r1), __float_as_uint(mine.r1), false, false);
     const auto k2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r2), __float_as_uint(mine.r2), false, false);
@@ -348,7 +358,11 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
     // ---- the codes are consumed: the next tile of this wave slot goes into the same registers while this one is tested
     {
       const int64_t tn = tile + kTilesPerChunk;
-      if (ci + 1 < kMfmaChunksPerBlock && lc + 1 < a.s.n_chunks && tn < n_tiles) load_tile_regs<W, COMPACT>(t, a.s.idx, tn, lane);
+#ifndef BBQ_MFMA_EXP_NOLOAD  // (timing experiment: every tile of a workgroup = its first one)
+      if (ci + 1 < cpb && lc + 1 < a.s.n_chunks && tn < n_tiles) load_tile_regs<W, COMPACT>(t, a.s.idx, tn, lane);
+#else
+      (void)tn;
+#endif
     }
     // ---- any accumulator above the bias?
     int mx = acc0[0];
@@ -400,40 +414,31 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
         const int qc = (int)(e & 0xFFFFFu), rit = (int)((e >> 20) & 63u), qn = (int)(e >> 26);
         const QueryParams pq = s_qp[qn];
         const int64_t row = tile * kTileRows + rit;
-        double lo, up, ad;
-        if constexpr (COMPACT) {
-          const double *__restrict__ ex = a.s.idx.exact + row * 4;
-          lo = ex[0]; up = ex[1]; ad = ex[2];
-        } else {
-          lo = reinterpret_cast<const double *>(cr)[2 * rit];
-          up = reinterpret_cast<const double *>(cr)[2 * rit + 1];
-          ad = reinterpret_cast<const double *>(cr + 1024)[rit];
-        }
-        double x1d = (double)s_x1[wave * 64 + rit];  // popcount of the row: exact in f32 (<= 2^24)
-        if (a.s.idx.has_x1) x1d = reinterpret_cast<const double *>(cr + 1536)[rit];  // explicit sums may not be f32-exact
+        const f64x2m lu = s_lu[wave * 64 + rit], ax = s_ax[wave * 64 + rit];
+        const double lo = lu.x, up = lu.y, ad = ax.x, x1d = ax.y;
         const double s64 = m_score_f64((double)qc, lo, up, ad, x1d, pq);
         const float s32 = (float)s64;
         const uint32_t bits = __float_as_uint(s32);
         if (s32 != s32) atomicOr(a.s.flags + q0 + qn, kFlagNaN);
         else if (key_of_bits(bits) > s_theta[qn]) {
           const uint64_t ent = ((uint64_t)(uint32_t)(a.s.row_id_base + row) << 32) | bits;
-          if (a.s.append_lists) {
-            // append mode: straight into the query's list (unordered inside the segment; the finalize launch takes its keys from there
-            // and the rare host replay sorts).  No per-chunk staging, so the waves of a workgroup never wait for each other
-            const uint32_t slot = atomicAdd(a.s.append_counts + q0 + qn, 1u);
-            const int64_t at = (int64_t)a.s.append_base[2 * (q0 + qn)] + slot;
+          // staged in the workgroup's LDS lists.  Slot mode: written row-ordered after every chunk.  Append mode: flushed once, when the
+          // workgroup is done - one atomic per query and workgroup reserves the room (an atomic that returns a value is a trip to the
+          // memory side: per survivor it cost the early segments, where a few per cent of the pairs survive, more than the sweep itself)
+          const uint32_t slot = atomicAdd(&s_cnt[qn], 1u);
+          if (slot < (uint32_t)a.s.cap) s_ent[(size_t)qn * a.s.cap + slot] = ent;
+          else if (a.s.append_lists) {  // the staging list is full: straight into the query's list
+            const uint32_t gs = atomicAdd(a.s.append_counts + (size_t)(q0 + qn) * kAppendStride, 1u);
+            const int64_t at = (int64_t)a.s.append_base[2 * (q0 + qn)] + gs;
             if (at < a.s.append_cap) a.s.append_lists[(size_t)(q0 + qn) * a.s.append_cap + at] = ent;
             else atomicOr(a.s.flags + q0 + qn, kFlagOverflow);
-          } else {
-            const uint32_t slot = atomicAdd(&s_cnt[qn], 1u);
-            if (slot < (uint32_t)a.s.cap) s_ent[(size_t)qn * a.s.cap + slot] = ent;
           }
         }
       }
       if (a.s.append_lists) s_qcount[wave] = 0;  // this wave's queue is its own: ready for its next tile
     }
   }
-  if (a.s.append_lists) continue;  // workgroup-uniform: nothing to flush, nobody to wait for
+  if (a.s.append_lists) continue;  // workgroup-uniform: nothing to flush per chunk, nobody to wait for
   __syncthreads();
   for (int b = wave; b < nb; b += NW) {  // each wave writes the lists of its share of the queries
     uint32_t cnt = s_cnt[b];
@@ -456,21 +461,47 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
   if (tid < NW) s_qcount[tid] = 0;
   __syncthreads();                       // ... and sees them cleared before the next chunk's survivors arrive
   }  // chunks of this workgroup
+  if (a.s.append_lists) {  // append mode: the workgroup's staged candidates go to the queries' lists (unordered inside the segment; the
+                           // finalize launch takes its keys from there and the rare host replay sorts)
+    __syncthreads();
+    for (int b = wave; b < nb; b += NW) {
+      const uint32_t cnt = min(s_cnt[b], (uint32_t)a.s.cap);
+      if (cnt == 0) continue;  // wave-uniform
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(a.s.append_counts + (size_t)(q0 + b) * kAppendStride, cnt);
+      base = __builtin_amdgcn_readfirstlane(base);
+      const int64_t at0 = (int64_t)a.s.append_base[2 * (q0 + b)] + base;
+      const uint64_t *__restrict__ src = s_ent + (size_t)b * a.s.cap;
+      uint64_t *__restrict__ out = a.s.append_lists + (size_t)(q0 + b) * a.s.append_cap;
+      for (uint32_t i = lane; i < cnt; i += 64) {
+        if (at0 + i < a.s.append_cap) out[at0 + i] = src[i];
+        else atomicOr(a.s.flags + q0 + b, kFlagOverflow);
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 
 static size_t mfma_smem_bytes(int w16, int cap) {
   constexpr int NW = kChunkRows / 64;
-  return (size_t)w16 * 4 * 2 * 32 * 16 + (size_t)kMfmaQueries * 16 + (size_t)NW * 64 * 4 + (size_t)NW * kMfmaQueueCap * 4 + 32 +
+  return (size_t)w16 * 4 * 2 * 32 * 16 + (size_t)kMfmaQueries * 16 + (size_t)NW * 64 * 32 + (size_t)NW * kMfmaQueueCap * 4 + 32 +
          kMfmaQueries * (sizeof(QueryParams) + 4 + 4) + 32 + (size_t)kMfmaQueries * (size_t)cap * 8 + 64;
 }
 
 template <int W, bool COMPACT, bool SCALED>
-static hipError_t launch_mfma_t(const MfmaArgs &a, int nq, int nc, hipStream_t s) {
+static hipError_t launch_mfma_t(MfmaArgs a, int nq, int nc, hipStream_t s) {
   const size_t smem = mfma_smem_bytes(W, a.s.cap);
-  dim3 grid((unsigned)((nc + kMfmaChunksPerBlock - 1) / kMfmaChunksPerBlock), (unsigned)((nq + kMfmaQueries - 1) / kMfmaQueries), 1),
-      block(kChunkRows, 1, 1);
+  // The chip holds 512 of these workgroups at a time (2 per CU) and a workgroup's prologue (staging the queries: 24 KB at 768-d, the
+  // constants) costs about one chunk's worth of time.  Up to 12 chunks per workgroup: ONE round of workgroups, everything resident at
+  // once.  Longer sweeps: about sqrt(2 x prologue x chunks / slots) chunks each, where the prologues and the idle tail of the last
+  // workgroups cost the same.
+  const int groups = (nq + kMfmaQueries - 1) / kMfmaQueries;
+  const int64_t units = (int64_t)nc * groups;
+  int64_t cpb = (units + 511) / 512;
+  if (cpb > 12) cpb = std::min<int64_t>(kMfmaMaxChunksPerBlock, std::max<int64_t>(4, (int64_t)llround(sqrt((double)units / 220.0))));
+  a.chunks_per_block = (int)cpb;
+  dim3 grid((unsigned)((nc + a.chunks_per_block - 1) / a.chunks_per_block), (unsigned)groups, 1), block(kChunkRows, 1, 1);
   auto kern = bbq_scan_mfma_kernel<W, COMPACT, SCALED>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -494,7 +525,7 @@ bool mfma_sweep_supported(const ScanArgs &a) {
 
 hipError_t launch_scan_mfma(const ScanArgs &sa, const uint8_t *qbytes, const float *qmax, bool scaled, int n_queries, int n_chunks, hipStream_t s) {
   if (n_chunks <= 0 || n_queries <= 0) return hipSuccess;
-  MfmaArgs a{sa, qbytes, qmax, n_queries};
+  MfmaArgs a{sa, qbytes, qmax, n_queries, 1};
   const bool compact = sa.idx.layout == kLayoutCompact;
   switch (sa.idx.w16) {
     case 1: return launch_mfma_w<1>(a, compact, scaled, n_queries, n_chunks, s);

@@ -1,0 +1,53 @@
+"""summary of scripts/profile_mfma.sh's output (kernel trace + two --pmc passes of the shared sweep on the matrix cores):
+  python scripts/summarize_mfma_pmc.py gpurun_out/<dir> [profiles/rNN_mfma_pmc.json]
+The dominant launches are the bbq_scan_mfma_kernel launches with the largest grid; their tile count is taken from SQ_INSTS_MFMA
+(48 MFMAs per 64-row tile and 32 queries at 768-d: 2 row groups x dim / 32), so the summary does not depend on how many chunks a
+workgroup walks."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+d = sys.argv[1]
+out = {"how": "scripts/profile_mfma.sh: rocprofv3 --kernel-trace --stats and two --pmc passes (8 SQ counters each) of "
+              "`python3 bench.py --steps 2 --warmup 1 ...` (10 M x 768, 32 queries per shared sweep); the dominant launches are the ones with the largest grid"}
+for p in ("pmc1", "pmc2"):
+    fs = glob.glob(os.path.join(d, p, "*", "*counter_collection.csv"))
+    if not fs:
+        continue
+    rows = [r for r in csv.DictReader(open(fs[0])) if "mfma" in r["Kernel_Name"]]
+    g = max(int(r["Grid_Size"]) for r in rows)
+    big = [r for r in rows if int(r["Grid_Size"]) == g]
+    n = len({r["Dispatch_Id"] for r in big})
+    agg = collections.defaultdict(float)
+    for r in big:
+        agg[r["Counter_Name"]] += float(r["Counter_Value"])
+    out.setdefault("per_launch", {}).update({c: v / n for c, v in agg.items()})
+    out["grid_work_items"], out["launches_" + p] = g, n
+    out["kernel"], out["vgpr_count_field"], out["lds_bytes"], out["scratch_bytes"] = big[0]["Kernel_Name"], int(big[0]["VGPR_Count"]), int(big[0]["LDS_Block_Size"]), int(big[0]["Scratch_Size"])
+fs = glob.glob(os.path.join(d, "trace", "*", "*kernel_trace.csv"))
+tr = [r for r in csv.DictReader(open(fs[0])) if "mfma" in r["Kernel_Name"]]
+g = max(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) for r in tr)
+us = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr if int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) == g]
+out["trace_avg_us"], out["trace_launches"] = sum(us) / len(us), len(us)
+pl = out["per_launch"]
+dim = int(sys.argv[3]) if len(sys.argv) > 3 else 768
+tiles = pl["SQ_INSTS_MFMA"] / (2 * dim / 32)
+out["rows_per_launch"], out["tiles_per_launch"] = tiles * 64, tiles
+out["per_tile_and_wave"] = {k_: pl[k_] / tiles for k_ in ("SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU") if k_ in pl}
+simd_cycles = out["trace_avg_us"] * 1e-6 * 1024 * 2.1e9   # 1024 SIMDs at the ~2.1 GHz the chip holds under this load
+out["derived"] = {
+    "valu_active_share_of_simd_time": pl.get("SQ_ACTIVE_INST_VALU", 0) * 4 / simd_cycles,
+    "mfma_busy_share_of_simd_time": pl.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / simd_cycles,
+    "cycles_per_valu_instruction": pl.get("SQ_ACTIVE_INST_VALU", 0) * 4 / max(pl.get("SQ_INSTS_VALU", 1), 1),
+    "wave_time_split": {k_: pl.get(k_, 0) / max(pl.get("SQ_WAVE_CYCLES", 1), 1) for k_ in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")},
+    "lds_bank_conflict_share": pl.get("SQ_LDS_BANK_CONFLICT", 0) / max(pl.get("SQ_LDS_IDX_ACTIVE", 1), 1),
+    "queries_per_s_of_this_launch_alone": 32 / (out["trace_avg_us"] * 1e-6),
+    "note": "SQ_ACTIVE_* / SQ_WAIT_* / SQ_WAVE_CYCLES count quad-cycles (MI355X_MICROARCH.md), SQ_VALU_MFMA_BUSY_CYCLES cycles; SIMD time = "
+            "launch duration x 1024 SIMDs x 2.1 GHz",
+}
+if len(sys.argv) > 2 and sys.argv[2] != "-":
+    json.dump(out, open(sys.argv[2], "w"), indent=1)
+print(json.dumps(out["per_tile_and_wave"]), json.dumps(out["derived"], indent=1), out["trace_avg_us"], out.get("scratch_bytes"), out.get("vgpr_count_field"))
