@@ -547,14 +547,13 @@ void fill_query(const bbq_index *ix, uint8_t *planes_dst, QueryParams *pp, const
   pp->pad_ = 0;
 }
 
-// MFMA shared sweep: the int8 query values in the order the code bits fall out of the packed words.  For 32-dim word
-// g, half h, dword c, byte i the kernel extracts bit p = 4h + c + 8i of the little-endian word, which is row byte 4g + (p >> 3),
-// bit (p & 7), i.e. dimension 32g + 8*(p >> 3) + 7 - (p & 7) (MSB-first packing, src/optimizedScalarQuantizer.ts:420-446).
-// `scaled` (query values <= 15): the kernel leaves that bit where it stands inside its nibble - an int8 value of 2^c - so the
-// query byte carries the factor 8 >> c and every product is 8 * q * bit.  Layout: [group][g][h][n][16 B], n = query in its group of 32.
-void fill_query_mfma(const bbq_index *ix, uint8_t *dst, int q_in_batch, const uint8_t *q, bool scaled) {
+// MFMA shared sweep, int8 form (query values up to 127): the int8 query values in the order the code bits fall out of the packed
+// words.  For 32-dim word g, half h, dword c, byte i the kernel extracts bit p = 4h + c + 8i of the little-endian word, which is row
+// byte 4g + (p >> 3), bit (p & 7), i.e. dimension 32g + 8*(p >> 3) + 7 - (p & 7) (MSB-first packing,
+// src/optimizedScalarQuantizer.ts:420-446).  Layout: [group][g][h][n][16 B], n = query in its group of 32.
+void fill_query_mfma(const bbq_index *ix, uint8_t *dst, int q_in_batch, const uint8_t *q) {
   const int words = ix->w16 * 4, group = q_in_batch / 32, n = q_in_batch % 32;
-  uint8_t *gb = dst + (size_t)group * words * 2 * 32 * 16;
+  uint8_t *gb = dst + (size_t)group * mfma_query_bytes_per_group(ix->w16, false);
   for (int g = 0; g < words; ++g)
     for (int h = 0; h < 2; ++h) {
       uint8_t *o = gb + (((size_t)g * 2 + h) * 32 + n) * 16;
@@ -562,9 +561,45 @@ void fill_query_mfma(const bbq_index *ix, uint8_t *dst, int q_in_batch, const ui
         for (int i = 0; i < 4; ++i) {
           const int p = 4 * h + cc + 8 * i;
           const int d = 32 * g + 8 * (p >> 3) + 7 - (p & 7);
-          const int v = d < ix->dim ? q[d] : 0;
-          o[4 * cc + i] = (uint8_t)(scaled ? v * (8 >> cc) : v);
+          o[4 * cc + i] = d < ix->dim ? q[d] : 0;
         }
+    }
+}
+
+// FP form (query values <= 15): v_mfma_f32_32x32x64_f8f6f4 with the rows as FP4 and the queries as FP6 (e2m3).  Step g covers the
+// code words 2g (lower half-wave) and 2g + 1 (upper); element i of a lane is bit p = 4 (i & 7) + (i >> 3) of its word - the kernel
+// masks bit c = i >> 3 of every nibble where it stands, an FP4 number of 0.5, 1.0, 2.0 and (bit 3, shifted down) 0.5 - and the query
+// value carries 1/2, 1/4, 1/8, 1/2 against it: every product is q / 4 (q / 2 or q for smaller query values, see below).  e2m3 holds q / 2, q / 4 and q / 8 exactly for q <= 15
+// (exponent 0: m / 8; exponent e: (1 + m / 8) 2^(e-1)).  A lane's 32 six-bit codes are 24 bytes: the first 16 in [g][h][n][16 B],
+// the last 8 in [g][h][n][8 B] behind all of them (two aligned LDS reads per lane and step).
+void fill_query_mfma_fp(const bbq_index *ix, uint8_t *dst, int q_in_batch, const uint8_t *q, int scale8) {
+  const int steps = ix->w16 * 2, group = q_in_batch / 32, n = q_in_batch % 32;
+  uint8_t *gb = dst + (size_t)group * mfma_query_bytes_per_group(ix->w16, true);
+  uint8_t *gb2 = gb + (size_t)steps * 2 * 32 * 16;
+  for (int g = 0; g < steps; ++g)
+    for (int h = 0; h < 2; ++h) {
+      uint8_t bits[24];
+      memset(bits, 0, sizeof bits);
+      for (int i = 0; i < 32; ++i) {
+        const int p = 4 * (i & 7) + (i >> 3);
+        const int d = 32 * (2 * g + h) + 8 * (p >> 3) + 7 - (p & 7);
+        const int v = d < ix->dim ? q[d] : 0;                        // 0..15
+        // the value x 8: q/2, q/4, q/8, q/2 at scale8 = 2 (products q/4: values up to 15); twice that for values up to 7 (scale8 = 4,
+        // products q/2), four times for values up to 3 (scale8 = 8, products q): the finest grain e2m3's range (7.5) allows
+        const int eighths = v * ((i >> 3) == 1 ? 2 : (i >> 3) == 2 ? 1 : 4) * (scale8 / 2);
+        uint32_t code;
+        if (eighths < 8) code = (uint32_t)eighths;                   // exponent field 0: m / 8
+        else {
+          int e = 1;
+          while (eighths >= (8 << e)) ++e;                           // 2^(e-1) <= value < 2^e
+          code = ((uint32_t)e << 3) | (uint32_t)((eighths >> (e - 1)) - 8);   // exact: the low e - 1 bits of eighths are zero for q <= 15
+        }
+        const int at = 6 * i;
+        bits[at >> 3] |= (uint8_t)(code << (at & 7));
+        if ((at & 7) > 2) bits[(at >> 3) + 1] |= (uint8_t)(code >> (8 - (at & 7)));
+      }
+      memcpy(gb + (((size_t)g * 2 + h) * 32 + n) * 16, bits, 16);
+      memcpy(gb2 + (((size_t)g * 2 + h) * 32 + n) * 8, bits + 16, 8);
     }
 }
 
@@ -680,19 +715,21 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const 
   size_t bytes = (size_t)nq * qb + (size_t)nq * sizeof(QueryParams);
   bool use_mfma = ix->opt_share == 32 && c.maxq <= 127 && ix->store_bits == 1;
   for (int i = 0; i < nq && use_mfma; ++i) use_mfma = mfma_query_ok(hq[i]);
-  const bool mfma_scaled = c.maxq <= 15;  // queryBits <= 4: the bit -> int8 expansion without shifts
+  const bool mfma_fp = c.maxq <= 15;  // queryBits <= 4: rows as FP4, queries as FP6 - 64 dimensions per MFMA in the time the int8 form takes for 32
+  const int mfma_scale8 = c.maxq <= 3 ? 8 : c.maxq <= 7 ? 4 : 2;   // products of scale8 / 8 * q: the accumulator's quarter-unit grain is 1, 1/2 or 1/4 of a qcDist unit
   size_t off_qbytes = 0, off_qmax = 0;
-  if (use_mfma) {  // second copy of the queries as int8 values in MFMA fragment order + per-group maxima for the rows' magnitude budget
+  if (use_mfma) {  // second copy of the queries as MFMA operands in fragment order + per-group maxima for the rows' magnitude budget
     const int groups = (nq + 31) / 32;
     off_qbytes = (bytes + 15) / 16 * 16;
-    const size_t qbytes_len = (size_t)groups * 32 * ix->w16 * 128;
+    const size_t qbytes_len = (size_t)groups * (size_t)mfma_query_bytes_per_group(ix->w16, mfma_fp);
     off_qmax = off_qbytes + qbytes_len;
     bytes = off_qmax + (size_t)groups * 16;
     memset(s.h_qbuf + off_qbytes, 0, qbytes_len);
     float *qm = reinterpret_cast<float *>(s.h_qbuf + off_qmax);
     for (int gidx = 0; gidx < groups; ++gidx) qm[4 * gidx] = qm[4 * gidx + 1] = qm[4 * gidx + 2] = qm[4 * gidx + 3] = 0.f;
     for (int i = 0; i < nq; ++i) {
-      fill_query_mfma(ix, s.h_qbuf + off_qbytes, i, c.qquant + (size_t)(q_first + i) * ix->dim, mfma_scaled);
+      if (mfma_fp) fill_query_mfma_fp(ix, s.h_qbuf + off_qbytes, i, c.qquant + (size_t)(q_first + i) * ix->dim, mfma_scale8);
+      else fill_query_mfma(ix, s.h_qbuf + off_qbytes, i, c.qquant + (size_t)(q_first + i) * ix->dim);
       float *m = qm + 4 * (i / 32);
       // upper bounds (rounded up) of the group's |ay / ly|, |y1|, 1 / (cs * ly) and of the sum of a query's values (the largest
       // qcDist there can be, whatever y1 the caller passed)
@@ -759,7 +796,7 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const 
     if (g.dominant) HIPCHK(hipEventRecord(s.ev0, st));
     const bool mfma_here = use_mfma && !g.dense && mfma_sweep_supported(a);
     if (mfma_here)
-      HIPCHK(launch_scan_mfma(a, s.d_qbuf + off_qbytes, reinterpret_cast<const float *>(s.d_qbuf + off_qmax), mfma_scaled, nq, (int)g.n_chunks, st));
+      HIPCHK(launch_scan_mfma(a, s.d_qbuf + off_qbytes, reinterpret_cast<const float *>(s.d_qbuf + off_qmax), mfma_fp ? mfma_scale8 / 8.0f : 0.0f, nq, (int)g.n_chunks, st));
     else if (!g.dense && ix->opt_share > 1 && shared_sweep_supported(a, ix->opt_share))
       HIPCHK(launch_scan_shared(a, c.planes, ix->opt_share, nq, (int)g.n_chunks, st));
     else

@@ -10,10 +10,12 @@ hipError_t launch_scan(const ScanArgs &a, int planes, bool dense, int n_queries,
 // shared sweep: `share` (4 or 8) queries per workgroup reuse every loaded row (sparse segments, fixed-width dims only)
 bool shared_sweep_supported(const ScanArgs &a, int share);
 hipError_t launch_scan_shared(const ScanArgs &a, int planes, int share, int n_queries, int n_chunks, hipStream_t s);
-// shared sweep on the matrix cores: 32 queries per workgroup (bbq_mfma_kernels.hip); query values must be <= 127 (`scaled`: <= 15 and
-// the query bytes carry the factor 8 >> dword), every query's interval width positive and finite
+// shared sweep on the matrix cores: 32 queries per workgroup (bbq_mfma_kernels.hip); query values must be <= 127 (fp_scale > 0: <= 15,
+// staged as FP6 times fp_scale against the bit weights for v_mfma_f32_32x32x64_f8f6f4; 0: int8 for v_mfma_i32_32x32x32_i8), every
+// query's interval width positive and finite
 bool mfma_sweep_supported(const ScanArgs &a);
-hipError_t launch_scan_mfma(const ScanArgs &a, const uint8_t *qbytes, const float *qmax, bool scaled, int n_queries, int n_chunks, hipStream_t s);
+int64_t mfma_query_bytes_per_group(int w16, bool fp);  // staged operand bytes of 32 queries
+hipError_t launch_scan_mfma(const ScanArgs &a, const uint8_t *qbytes, const float *qmax, float fp_scale, int n_queries, int n_chunks, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, int n_queries, hipStream_t s);
 // lists are [nq][list_stride]; a query may hold more than advertised_cap entries (a flood): such queries are only dropped
 // (flagged) when the packed buffer cannot take the sum

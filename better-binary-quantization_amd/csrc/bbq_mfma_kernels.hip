@@ -16,23 +16,28 @@
 //  * THE PRE-FILTER LIVES IN THE ACCUMULATOR.  "score > theta" is, for a row with upper > lower and a query with upper > lower,
 //    an inequality on the integer itself:  qcDist > T(query, row), where T is a sum of four (per-query constant) x (per-row
 //    constant) products (derivation at row_constants()).  The MFMA's C operand is initialised with the float
-//        1.5 * 2^23 + slack(row) - S * T(query, row)          (4 v_fma_f32 per pair, nothing else)
-//    whose BITS are the integer 0x4B400000 + round(...); the matrix cores then add S * qcDist to those bits, and a pair can only
-//    be a candidate if its accumulator ends above 0x4B400000: one v_max3_i32 per two pairs finds out whether a tile has any.
-//    4.5 vector instructions per pair instead of 16, no conversion, no compare per pair.  Tiles with a survivor (about one in
-//    five) re-derive the initial value of the few accumulators that passed and take qcDist from the difference.
+//        bias + slack(row) - S * T(query, row)          (4 v_fma_f32 per pair, nothing else)
+//    in a binade where one ulp is one unit of S * qcDist; the matrix cores add S * qcDist EXACTLY, and a pair can only be a
+//    candidate if its accumulator ends above the bias: one v_max3 per two pairs finds out whether a tile has any.  4.5 vector
+//    instructions per pair instead of 16, no conversion, no compare per pair.  Tiles with a survivor (about one in five) derive
+//    the start value of the few accumulators that passed again and take qcDist from the difference.
 //    The constants are f32 images of the EXACT f64 corrections (both layouts: the compact layout reads its side array exact[],
 //    32 B/row more per 32 queries - this kernel is nowhere near the HBM bound), so no per-pair error terms exist: every rounding
-//    is covered by a per-row slack of a few S-units (slack_of()), about 0.05 standard deviations of qcDist.
-//  * THE EXPANSION IS ONE AND PER DWORD.  With query values <= 15 (queryBits <= 4) the host scales the query bytes by 8 >> c for
-//    operand dword c and the kernel takes bit c of every nibble where it stands: (w & 0x01010101 << c) is a dword of int8 values
-//    {0, 2^c}, S = 8 and the accumulator holds 8 * qcDist.  One v_permlane32_swap of (w, w >> 4) hands BOTH row groups their
-//    operand words (own or half-wave partner's row, already aligned for the half's nibble), so a 32-dimension word costs
-//    1 shift + 1 swap + 8 ANDs for two MFMAs: 5 vector instructions per MFMA instead of 9.  Query values up to 127 keep the
-//    {0, 1} expansion with its three extra shifts (S = 1).
+//    is covered by a per-row slack of a few ulps, a few hundredths of a standard deviation of qcDist.
+//  * QUERY VALUES <= 15 (queryBits <= 4) RUN ON v_mfma_f32_32x32x64_f8f6f4, FP6 x FP4 (template FP).  A 1-bit code IS an FP4
+//    number where it stands: the nibble patterns 0001, 0010, 0100 are 0.5, 1.0 and 2.0 (e2m1), so  w & 0x11111111,  w & 0x22222222,
+//    w & 0x44444444  and  (w >> 3) & 0x11111111  turn one 32-dimension word into the 32 FP4 operands of a lane - 5 vector
+//    instructions for 64 dimensions of two row groups' worth... per MFMA, no shift per dword, no byte expansion.  The host stores the
+//    query values as FP6 (e2m3: four significant bits, exactly q / 2, q / 4, q / 8 for q <= 15) scaled against the bit's weight, so every
+//    product is q / 4 and the f32 accumulator - started in the binade [2^19, 2^20), on a grid of 1/16 - holds bias - T/4 + qcDist/4 exactly.
+//    The instruction takes 64 dimensions in the time v_mfma_i32_32x32x32_i8 takes for 32 (scripts/ubench/mfma_fp4_probe.hip: layout,
+//    exactness and rate measured on gfx950): half the matrix-core time and half the expansion of the int8 form.
+//    Query values up to 127 stay on v_mfma_i32_32x32x32_i8 with the {0, 1} byte expansion: there the start value's BITS (a float in
+//    [2^23, 2^24): 0x4B000000 + its integer distance from 2^23) are the i32 accumulator.
+//    One v_permlane32_swap hands BOTH row groups their operand words (own or half-wave partner's row).
 //  * Both row groups' accumulators are live at once, so a query fragment is read from LDS once for two MFMAs and a query's
-//    constants once for two rows (40 ds_read_b128 per tile and wave instead of 80), and the next tile's loads are issued as soon as
-//    the contraction has consumed the codes - into the same registers.
+//    constants once for two rows, and the next tile's loads are issued as soon as the contraction has consumed the codes - into the
+//    same registers.
 // Packed f32 instructions (v_pk_fma_f32) are NOT used: on gfx950 they issue at half rate (MI355X_MICROARCH.md, cycle constants).
 //
 // The rare survivors go through the exact f64 score of the one-sweep kernel, so the emitted candidates - and therefore the
@@ -41,6 +46,7 @@
 #include <float.h>
 #include <math.h>
 #include <algorithm>
+#include <type_traits>
 #include "bbq_device.h"
 #include "bbq_launch.h"
 
@@ -54,11 +60,23 @@ typedef int i32x4m __attribute__((ext_vector_type(4)));
 typedef int i32x16m __attribute__((ext_vector_type(16)));
 typedef double f64x2m __attribute__((ext_vector_type(2)));
 typedef float f32x4m __attribute__((ext_vector_type(4)));
+typedef float f32x16m __attribute__((ext_vector_type(16)));
+typedef int i32x8m __attribute__((ext_vector_type(8)));
 
 constexpr int kMfmaQueries = 32;
-constexpr int kMfmaBias = 0x4B400000;          // bits of 1.5 * 2^23: floats in [2^23, 2^24) are 0x4B000000 + their integer distance from 2^23
-constexpr float kMfmaBiasF = 12582912.0f;      // 1.5 * 2^23
-constexpr float kMfmaMagLimit = 4000000.0f;    // S * (sum of the terms' magnitudes) must stay below 2^22: every partial sum then lies in (2^23, 2^24), ulp 1
+// The accumulator's start value lies in a binade whose ulp is the grain of the threshold:
+//   int8 form (S = 1):          [2^23, 2^24), ulp 1; the i32 accumulator holds the float's bits, 0x4B000000 + its integer distance from 2^23
+//   FP form  (S = 1/4, 1/2, 1): [2^19, 2^20), ulp 1/16; the f32 accumulator holds the value.  The products are multiples of S, the start
+//                               value a multiple of 1/16: every partial sum is a multiple of 1/16 below 2^20, i.e. exact in f32
+// "bias" is the middle of the binade (1.5 x its lower end); the sum of the terms must stay below a quarter of the binade's lower end
+// so that every partial sum stays inside it.
+template <bool FP> struct MfmaNum;
+template <> struct MfmaNum<false> {
+  static constexpr float S = 1.0f, ulp = 1.0f, bias = 12582912.0f, mag_limit = 4000000.0f, pass_all = 12582912.0f + 2097152.0f;
+};
+template <> struct MfmaNum<true> {   // S is chosen per call: 1/4 for query values up to 15, 1/2 up to 7, 1 up to 3 (MfmaArgs::fp_scale)
+  static constexpr float S = 0.25f, ulp = 0.0625f, bias = 786432.0f, mag_limit = 110000.0f, pass_all = 786432.0f + 131072.0f;
+};
 
 // ---- exact pieces shared with bbq_kernels.hip (kept textually identical: same operation order) ----------------------
 __device__ __forceinline__ double m_js_max0(double x) { return (x != x) ? x : (x > 0.0 ? x : 0.0); }
@@ -118,21 +136,25 @@ __device__ __forceinline__ double z_threshold(uint32_t theta_key, const QueryPar
 // so for lx > 0 and ly > 0 (beta = cs * ly):
 //     z > zth   <=>   qc > T = (zth / beta) * (1 / lx)  -  (ay / ly) * (rho * D + x1)  -  y1 * rho  -  (1 / beta) * (ca * add / lx),    rho = ax / lx.
 // Per query (prologue, f64 -> f32):  qk = -S * {zth / beta, ay / ly, y1, 1 / beta}.   Per row (f32):  rk = {1 / lx, -(rho * D + x1), -rho, -ca * add / lx}.
-// The accumulator starts at  bits(K + qk . rk)  with K = 1.5 * 2^23 + slack, computed as four chained v_fma_f32 starting from K.
+// The accumulator starts at  K + qk . rk  with K = bias + slack, computed as four chained v_fma_f32 starting from K.
 //
-// Slack (in units of the accumulator, i.e. 1 / S of a qcDist unit).  Let mag = S * sum_j max_q |q_j| * |r_j| (the row's magnitude
-// budget, with |rho| * D + |x1| standing for |r_1|, plus S * the largest possible qcDist so that every term of s is covered).
-//  * four v_fma_f32 whose results lie in (2^23, 2^24) (guaranteed by mag < 2^22, else the row is "weird"): 4 * 0.5 ulp = 2;
+// Slack.  Let mag = S * sum_j max_q |q_j| * |r_j| (the row's magnitude budget, with |rho| * D + |x1| standing for |r_1|, plus
+// S * the largest possible qcDist so that every term of s is covered).
+//  * four v_fma_f32 whose results lie inside the binade (guaranteed by mag < mag_limit, else the row is "weird"): 4 * 0.5 ulp;
 //  * the f32 images of the constants: q_j within 2^-24 (one rounding of an f64), 1 / lx within 2^-22 (v_rcp_f32 is good to 1 ulp, lx
 //    itself is rounded once), rho and add / lx within 2^-21.4, r_1 within 2^-21.3 of |rho| * D + |x1|: every product within 2^-21 of its
 //    magnitude, together below 2^-21 * mag;  the f64 evaluation of the reference score itself (~2^-50 of the same magnitudes) and
 //    the inversion of the similarity transform (z_threshold's own allowance) are far inside.
-// slack = 3 + 2^-20 * mag, rounded up to an integer: twice the bound.  A weird row (lx <= 0, non-finite, mag too large) gets
-// K = +inf and zero constants: every one of its pairs passes and is scored exactly.
+// slack = (2.25 ulp + 2^-20 * mag) rounded up to whole ulps: above 2 ulp + twice the bound of the images.  A weird row (lx <= 0, non-finite, mag too large)
+// gets zero constants and K = pass_all, a value inside the binade that no threshold reaches: every one of its pairs passes and is
+// scored exactly, and the difference to the start value is still qcDist.  A query that accepts everything (no threshold yet) is not
+// swept here at all: the prologue flags it, as its candidates would overflow every list of this kernel anyway.
 struct RowK {
   float r0, r1, r2, r3, K;
 };
+template <bool FP>
 __device__ __forceinline__ RowK row_constants(double al, double au, double add, double x1, float D, int sim, const float *__restrict__ gmax) {
+  using N = MfmaNum<FP>;
   const float lxf = (float)(au - al), alf = (float)al, addf = (float)add, x1f = (float)x1;
   const float r0 = __builtin_amdgcn_rcpf(lxf);
   const float rho = alf * r0;
@@ -141,40 +163,36 @@ __device__ __forceinline__ RowK row_constants(double al, double au, double add, 
   k.r1 = -fmaf(rho, D, x1f);
   k.r2 = -rho;
   k.r3 = (sim == 0 ? addf : -addf) * r0;
-  // gmax: S * max over the group's queries of |zth / beta| (finite ones), |ay / ly|, |y1|, 1 / beta, and S * max sum of query values
+  // gmax: S * max over the group's queries of |zth / beta|, |ay / ly|, |y1|, 1 / beta, and S * max sum of query values
   const float mag = fmaf(gmax[0], fabsf(r0), fmaf(gmax[1], fmaf(fabsf(rho), D, fabsf(x1f)), fmaf(gmax[2], fabsf(rho), fmaf(gmax[3], fabsf(k.r3), gmax[4]))));
-  // NaN anywhere: not ok.  r0 >= 1e-6 (lx <= 1e6): a query that accepts everything carries the constant 3e38 and must still lift the
-  // sum far above the limit
-  const bool ok = lxf > 0.0f && r0 >= 1.0e-6f && mag < kMfmaMagLimit;
+  const bool ok = lxf > 0.0f && mag < N::mag_limit;  // NaN anywhere: not ok
   if (ok) {
-    k.K = kMfmaBiasF + ceilf(fmaf(mag, 9.5367431640625e-07f, 4.0f));  // 3 + 2^-20 * mag, and 1 for the roundings of this line
+    k.K = N::bias + N::ulp * ceilf(fmaf(mag, 9.5367431640625e-07f / N::ulp, 2.25f));  // whole ulps above 2.25 ulp + 2^-20 * mag: 3 for an ordinary row
   } else {
     k.r0 = k.r1 = k.r2 = k.r3 = 0.0f;
-    k.K = __uint_as_float(0x7f800000u);
+    k.K = N::pass_all;
   }
   return k;
 }
 // v_fma_f32 spelled out: left to itself the compiler pairs the chains of neighbouring accumulators into v_pk_fma_f32 (half rate on
 // gfx950) and spends a v_mov per operand pair on top
 __device__ __forceinline__ float fma_f32(float a, float b, float c) {
-#ifdef BBQ_MFMA_PLAIN_FMA
-  return fmaf(a, b, c);
-#else
   float d;
   asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
-#endif
 }
-__device__ __forceinline__ int acc_init(const f32x4m qk, float r0, float r1, float r2, float r3, float K) {
-  return (int)__float_as_uint(fma_f32(qk.x, r0, fma_f32(qk.y, r1, fma_f32(qk.z, r2, fma_f32(qk.w, r3, K)))));
+__device__ __forceinline__ float acc_init(const f32x4m qk, float r0, float r1, float r2, float r3, float K) {
+  return fma_f32(qk.x, r0, fma_f32(qk.y, r1, fma_f32(qk.z, r2, fma_f32(qk.w, r3, K))));
 }
 
 struct MfmaArgs {
   ScanArgs s;
-  const uint8_t *qbytes;   // [groups][W*4 words][2 halves][32 queries][16 B]  int8 query values in fragment order (scaled by 8 >> dword when SCALED)
+  const uint8_t *qbytes;   // int8 form: [groups][W*4 words][2 halves][32 queries][16 B] query values in fragment order; FP form: per group
+                           // [W*2 steps][2 halves][32 queries][16 B] then [W*2][2][32][8 B]: the 32 FP6 values (24 B) of a lane and step
   const float *qmax;       // [groups][4]: S-free maxima over the group's queries: |ay / ly|, |y1|, 1 / (cs * ly), sum of the query's values
   int32_t nq_total;
   int32_t chunks_per_block;  // consecutive chunks one workgroup walks with the same 32 queries (launch_mfma_t)
+  float fp_scale;            // FP form: every product is fp_scale * q (1/4, 1/2 or 1: the largest the query values leave room for in e2m3)
 };
 
 // Pairs that pass the pre-filter are pushed to a per-wave LDS queue (packed qc | row-in-tile << 20 | query << 26) and
@@ -208,16 +226,53 @@ __device__ __forceinline__ void load_tile_regs(TileRegs<W, COMPACT> &t, const In
   }
 }
 
+// ---- one k-step of the FP form, as a template over the step index: the fragment reads are inline asm (ds_read with an immediate
+// offset, waited for by hand) because they must stay where they are written - one step ahead of their use.  Left to the compiler
+// every step's fragment is read ahead of the loop (12 x 6 registers at 768-d: spills); volatile reads leave the LDS address space.
+template <int G, int STEPS, int W>
+__device__ __forceinline__ void fp_step(f32x16m &acc0, f32x16m &acc1, const u32x4m (&c)[W], u32x4m &bq, u32x2m &bq2, uint32_t addr16, uint32_t addr8) {
+  // a lane supplies 32 of a step's 64 dimensions: ONE code word - word 2G of its row group's row n in the lower half-wave, word
+  // 2G + 1 in the upper.  swap(word 2G, word 2G + 1) of my own row: [0] = {row n: 2G | row n: 2G + 1}, [1] = the same of row 32 + n
+  const uint32_t wa = (G & 1) == 0 ? c[G >> 1].x : c[G >> 1].z;
+  const uint32_t wb = (G & 1) == 0 ? c[G >> 1].y : c[G >> 1].w;
+  const auto sw = __builtin_amdgcn_permlane32_swap(wa, wb, false, false);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq), "+v"(bq2));   // this step's fragment has arrived
+  i32x8m Q, R0, R1;   // 8 dwords wide for the builtin; FP6 uses 6 of them and FP4 4: the others stay undefined
+  Q[0] = (int)bq.x; Q[1] = (int)bq.y; Q[2] = (int)bq.z; Q[3] = (int)bq.w; Q[4] = (int)bq2.x; Q[5] = (int)bq2.y;
+  if constexpr (G + 1 < STEPS) {  // the next step's fragment, one step ahead: the read is issued BEFORE this step's MFMAs (their operand
+                                  // passes through an asm behind it, or the compiler issues them first to reuse the registers)
+    asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%5"
+                 : "=v"(bq), "=v"(bq2) : "v"(addr16), "v"(addr8), "n"((G + 1) * 1024), "n"((G + 1) * 512));
+    asm volatile("" : "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2]), "+v"(Q[3]), "+v"(Q[4]), "+v"(Q[5]));
+  }
+  // bits 0, 1, 2 of every nibble where they stand are the FP4 numbers 0.5, 1.0, 2.0; bit 3 would be the sign: it moves to bit 0
+  R0[0] = (int)(sw[0] & 0x11111111u); R0[1] = (int)(sw[0] & 0x22222222u); R0[2] = (int)(sw[0] & 0x44444444u); R0[3] = (int)((sw[0] >> 3) & 0x11111111u);
+  R1[0] = (int)(sw[1] & 0x11111111u); R1[1] = (int)(sw[1] & 0x22222222u); R1[2] = (int)(sw[1] & 0x44444444u); R1[3] = (int)((sw[1] >> 3) & 0x11111111u);
+  // A = queries (FP6 e2m3, cbsz 2), B = rows (FP4 e2m1, blgp 4), block scales 2^0
+  acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Q, R0, acc0, 2, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Q, R1, acc1, 2, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  asm volatile("" : "+v"(acc0), "+v"(acc1));  // ordered with the reads: this step's MFMAs are issued before the next step begins
+  if constexpr (G + 1 < STEPS) fp_step<G + 1, STEPS, W>(acc0, acc1, c, bq, bq2, addr16, addr8);
+}
+
+// bytes of one group's staged query operands
+__host__ __device__ constexpr int mfma_query_bytes(int w16, bool fp) { return fp ? w16 * 2 * 2 * 32 * 24 : w16 * 4 * 2 * 32 * 16; }
+
 // 4 waves per SIMD = 2 workgroups per CU (128 VGPRs) up to 1024-d; 1536-d rows hold 48 code registers: one workgroup per CU
-template <int W, bool COMPACT, bool SCALED>
+template <int W, bool COMPACT, bool FP>
 __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kernel(const MfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using N = MfmaNum<FP>;
+  using Acc = typename std::conditional<FP, f32x16m, i32x16m>::type;
   constexpr int NT = kChunkRows;
   constexpr int NW = kChunkRows / 64;
   constexpr int WORDS = W * 4;
-  constexpr int S = SCALED ? 8 : 1;
-  u32x4m *s_B = reinterpret_cast<u32x4m *>(smem);                                    // [WORDS*2][32]
-  f32x4m *s_qk = reinterpret_cast<f32x4m *>(smem + (size_t)WORDS * 2 * 32 * 16);     // [32] per-query constants -S * {zth/beta, ay/ly, y1, 1/beta}
+  constexpr int STEPS = FP ? WORDS / 2 : WORDS;                                      // k-steps of 64 (FP) or 32 dimensions
+  constexpr int QBYTES = mfma_query_bytes(W, FP);
+  const float S = FP ? a.fp_scale : 1.0f;                                            // accumulator units per qcDist unit
+  u32x4m *s_B = reinterpret_cast<u32x4m *>(smem);                                    // [STEPS*2][32] 16 B per lane and step ...
+  u32x2m *s_B2 = reinterpret_cast<u32x2m *>(smem + (size_t)STEPS * 2 * 32 * 16);     // ... FP: [STEPS*2][32] + 8 B (the rest of the 32 FP6 values)
+  f32x4m *s_qk = reinterpret_cast<f32x4m *>(smem + QBYTES);                          // [32] per-query constants -S * {zth/beta, ay/ly, y1, 1/beta}
   f64x2m *s_lu = reinterpret_cast<f64x2m *>(s_qk + kMfmaQueries);                    // [NW][64] {lower, upper} of every tile row, for the survivors' exact scores ...
   f64x2m *s_ax = s_lu + NW * 64;                                                     // [NW][64] ... and {additionalCorrection, component sum}: no trip to memory there
   uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_ax + NW * 64);                  // [NW][kMfmaQueueCap]
@@ -259,16 +314,18 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
         th = a.s.theta[q0 + lane];
         const double zt = z_threshold(th, p);
         const double beta = (p.sim == 0 ? 2.0 : 1.0) * p.ly;   // > 0 and finite: the host sends no other query here (mfma_query_ok)
-        // -S * zth / beta, clamped to the finite floats: "accept everything" (zth = -DBL_MAX) becomes +3e38, which no ordinary row's sum
-        // brings back below the limit
-        double A = -(double)S * (zt / beta);
-        if (!(A <= 3.0e38)) A = 3.0e38;
-        if (!(A >= -3.0e38)) A = -3.0e38;
-        qk.x = (float)A;
-        qk.y = (float)(-(double)S * (p.ay / p.ly));
-        qk.z = (float)(-(double)S * p.y1);
-        qk.w = (float)(-(double)S / beta);
-        if (fabsf(qk.x) < 1.0e38f) atomicMax(reinterpret_cast<uint32_t *>(s_gmax), __float_as_uint(fabsf(qk.x) * 1.0000002f));  // non-negative floats order like their bits
+        const double A = -(double)S * (zt / beta);
+        if (A < 1.0e30) {  // (also false for NaN)
+          qk.x = A > -3.0e38 ? (float)A : -3.0e38f;            // a threshold beyond every score: nothing passes
+          qk.y = (float)(-(double)S * (p.ay / p.ly));
+          qk.z = (float)(-(double)S * p.y1);
+          qk.w = (float)(-(double)S / beta);
+          if (fabsf(qk.x) < 1.0e30f) atomicMax(reinterpret_cast<uint32_t *>(s_gmax), __float_as_uint(fabsf(qk.x) * 1.0000002f));  // non-negative floats order like their bits
+        } else {
+          // no threshold yet (or one below every score): every pair of this query would be a candidate, far more than the lists of
+          // this kernel hold - the query is flagged here and gets a sweep of its own (finish_replay), its lane sweeps nothing
+          atomicOr(a.s.flags + q0 + lane, kFlagOverflow);
+        }
       }
       s_qp[lane] = p;
       s_theta[lane] = th;
@@ -276,15 +333,15 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
       s_qk[lane] = qk;
       if (lane == 0) {  // the host's maxima are S-free and rounded up
         const float *__restrict__ gm = a.qmax + (size_t)group * 4;
-        s_gmax[1] = (float)S * gm[0];
-        s_gmax[2] = (float)S * gm[1];
-        s_gmax[3] = (float)S * gm[2];
-        s_gmax[4] = (float)S * gm[3];
+        s_gmax[1] = S * gm[0];
+        s_gmax[2] = S * gm[1];
+        s_gmax[3] = S * gm[2];
+        s_gmax[4] = S * gm[3];
       }
     }
   } else {
-    const u32x4m *__restrict__ gb = reinterpret_cast<const u32x4m *>(a.qbytes) + (size_t)group * WORDS * 2 * 32;
-    for (int i = tid - 64; i < WORDS * 2 * 32; i += NT - 64) s_B[i] = gb[i];
+    const u32x4m *__restrict__ gb = reinterpret_cast<const u32x4m *>(a.qbytes + (size_t)group * QBYTES);
+    for (int i = tid - 64; i < QBYTES / 16; i += NT - 64) s_B[i] = gb[i];
   }
   __syncthreads();
 
@@ -307,7 +364,7 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
     for (int j = 0; j < W; ++j) ones += __popc(t.c[j].x) + __popc(t.c[j].y) + __popc(t.c[j].z) + __popc(t.c[j].w);
     double x1row = (double)ones;                 // quantizedComponentSum of a 1-bit row is its popcount ...
     if (a.s.idx.has_x1) x1row = t.x1;            // ... unless the index says otherwise
-    const RowK mine = row_constants(t.lu.x, t.lu.y, t.add, x1row, Df, sim, s_gmax);
+    const RowK mine = row_constants<FP>(t.lu.x, t.lu.y, t.add, x1row, Df, sim, s_gmax);
     s_lu[wave * 64 + lane] = t.lu;               // for the survivors' exact scores (any lane may score any row of the tile)
     {
       f64x2m ax;
@@ -325,57 +382,70 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
       ra[rg][0] = __uint_as_float(k0[rg]); ra[rg][1] = __uint_as_float(k1[rg]); ra[rg][2] = __uint_as_float(k2[rg]);
       ra[rg][3] = __uint_as_float(k3[rg]); ra[rg][4] = __uint_as_float(kK[rg]);
     }
-    // ---- the accumulators start at the (negated, biased) thresholds of their pairs
-    i32x16m acc0, acc1;
+    // ---- the accumulators start at the (negated, biased) thresholds of their pairs (int8 form: the float's bits)
+    Acc acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = (r & 3) + 8 * (r >> 2) + 4 * h;  // query of this accumulator
       const f32x4m qk = s_qk[m + lds_off];            // the same address for the whole half-wave
-      acc0[r] = acc_init(qk, ra[0][0], ra[0][1], ra[0][2], ra[0][3], ra[0][4]);
-      acc1[r] = acc_init(qk, ra[1][0], ra[1][1], ra[1][2], ra[1][3], ra[1][4]);
+      const float i0 = acc_init(qk, ra[0][0], ra[0][1], ra[0][2], ra[0][3], ra[0][4]);
+      const float i1 = acc_init(qk, ra[1][0], ra[1][1], ra[1][2], ra[1][3], ra[1][4]);
+      if constexpr (FP) { acc0[r] = i0; acc1[r] = i1; }
+      else { acc0[r] = (int)__float_as_uint(i0); acc1[r] = (int)__float_as_uint(i1); }
     }
-    // ---- the contraction: C[m = query][n = row of the group] += sum over WORDS k-steps of 32 dims
+    // ---- the contraction: C[m = query][n = row of the group] += sum over the k-steps
+    if constexpr (FP) {
+      // LDS byte addresses of this lane's fragment of step 0 (the pointers are LDS pointers: their low 32 bits are the offset)
+      const uint32_t addr16 = (uint32_t)(uintptr_t)(s_B + h * 32 + n + lds_off), addr8 = (uint32_t)(uintptr_t)(s_B2 + h * 32 + n + lds_off);
+      u32x4m bq;
+      u32x2m bq2;
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b64 %1, %3" : "=v"(bq), "=v"(bq2) : "v"(addr16), "v"(addr8));
+      fp_step<0, STEPS, W>(acc0, acc1, t.c, bq, bq2, addr16, addr8);
+    } else {
 #pragma unroll
-    for (int g = 0; g < WORDS; ++g) {
-      const uint32_t w = (g & 3) == 0 ? t.c[g >> 2].x : (g & 3) == 1 ? t.c[g >> 2].y : (g & 3) == 2 ? t.c[g >> 2].z : t.c[g >> 2].w;
-      // swap(w, w >> 4): [0] = {row n's word | row n's word >> 4}, [1] = {row 32+n's word | row 32+n's word >> 4}: the lower half-wave
-      // supplies the low nibble of every byte, the upper one the high nibble, of the row group's row n
-      const auto sw = __builtin_amdgcn_permlane32_swap(w, w >> 4, false, false);
-      const u32x4m bq = s_B[(g * 2 + h) * 32 + n + lds_off];
-      i32x4m Q;
-      Q.x = (int)bq.x; Q.y = (int)bq.y; Q.z = (int)bq.z; Q.w = (int)bq.w;
-      i32x4m R0, R1;
-      if constexpr (SCALED) {  // bit c of every nibble where it stands: int8 values {0, 2^c} against query bytes scaled by 8 >> c
-        R0.x = (int)(sw[0] & 0x01010101u); R0.y = (int)(sw[0] & 0x02020202u); R0.z = (int)(sw[0] & 0x04040404u); R0.w = (int)(sw[0] & 0x08080808u);
-        R1.x = (int)(sw[1] & 0x01010101u); R1.y = (int)(sw[1] & 0x02020202u); R1.z = (int)(sw[1] & 0x04040404u); R1.w = (int)(sw[1] & 0x08080808u);
-      } else {
+      for (int g = 0; g < WORDS; ++g) {
+        const uint32_t w = (g & 3) == 0 ? t.c[g >> 2].x : (g & 3) == 1 ? t.c[g >> 2].y : (g & 3) == 2 ? t.c[g >> 2].z : t.c[g >> 2].w;
+        // swap(w, w >> 4): [0] = {row n's word | row n's word >> 4}, [1] = {row 32+n's word | row 32+n's word >> 4}: the lower half-wave
+        // supplies the low nibble of every byte, the upper one the high nibble, of the row group's row n
+        const auto sw = __builtin_amdgcn_permlane32_swap(w, w >> 4, false, false);
+        const u32x4m bq = s_B[(g * 2 + h) * 32 + n + lds_off];
+        i32x4m Q;
+        Q.x = (int)bq.x; Q.y = (int)bq.y; Q.z = (int)bq.z; Q.w = (int)bq.w;
+        i32x4m R0, R1;
         R0.x = (int)(sw[0] & 0x01010101u); R0.y = (int)((sw[0] >> 1) & 0x01010101u); R0.z = (int)((sw[0] >> 2) & 0x01010101u); R0.w = (int)((sw[0] >> 3) & 0x01010101u);
         R1.x = (int)(sw[1] & 0x01010101u); R1.y = (int)((sw[1] >> 1) & 0x01010101u); R1.z = (int)((sw[1] >> 2) & 0x01010101u); R1.w = (int)((sw[1] >> 3) & 0x01010101u);
+        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Q, R0, acc0, 0, 0, 0);   // A = queries (m), B = rows (n)
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Q, R1, acc1, 0, 0, 0);
       }
-      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Q, R0, acc0, 0, 0, 0);   // A = queries (m), B = rows (n)
-      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Q, R1, acc1, 0, 0, 0);
     }
     // ---- the codes are consumed: the next tile of this wave slot goes into the same registers while this one is tested
     {
       const int64_t tn = tile + kTilesPerChunk;
-#ifndef BBQ_MFMA_EXP_NOLOAD  // (timing experiment: every tile of a workgroup = its first one)
       if (ci + 1 < cpb && lc + 1 < a.s.n_chunks && tn < n_tiles) load_tile_regs<W, COMPACT>(t, a.s.idx, tn, lane);
-#else
-      (void)tn;
-#endif
     }
     // ---- any accumulator above the bias?
-    int mx = acc0[0];
+    bool any_lane;
+    if constexpr (FP) {
+      float mx = acc0[0];
 #pragma unroll
-    for (int r = 1; r < 16; r += 2) mx = max(mx, max(acc0[r], r + 1 < 16 ? acc0[r + 1] : acc0[r]));
+      for (int r = 1; r < 16; r += 2) mx = fmaxf(mx, fmaxf(acc0[r], r + 1 < 16 ? acc0[r + 1] : acc0[r]));
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) mx = max(mx, max(acc1[r], acc1[r + 1]));
+      for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(acc1[r], acc1[r + 1]));
+      any_lane = mx > N::bias;
+    } else {
+      int mx = acc0[0];
+#pragma unroll
+      for (int r = 1; r < 16; r += 2) mx = max(mx, max(acc0[r], r + 1 < 16 ? acc0[r + 1] : acc0[r]));
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) mx = max(mx, max(acc1[r], acc1[r + 1]));
+      any_lane = mx > (int)__float_as_uint(N::bias);
+    }
     uint32_t *__restrict__ queue = s_queue + (size_t)wave * kMfmaQueueCap;
-    if (__any(mx > kMfmaBias)) {
+    if (__any(any_lane)) {
       const int rows_here = (int)min((int64_t)kTileRows, a.s.idx.n_rows - tile * kTileRows);
-      // survivors: take qcDist from the difference to the accumulator's initial value, which is derived again (the same four
+      // survivors: take qcDist from the difference to the accumulator's start value, which is derived again (the same four
       // instructions on the same operands: the same bits).  The constants pass through an empty asm so that the compiler cannot keep
-      // all 32 initial values alive across the contraction instead.
+      // all 32 start values alive across the contraction instead.
       float rb[2][5];
 #pragma unroll
       for (int rg = 0; rg < 2; ++rg)
@@ -393,13 +463,18 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
         const int rit = 32 * rg + n2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int av = rg == 0 ? acc0[r] : acc1[r];
-          if (__any(av > kMfmaBias)) {  // wave-uniform: most accumulators have no survivor in any lane
+          const auto av = rg == 0 ? acc0[r] : acc1[r];
+          bool above;
+          if constexpr (FP) above = av > N::bias;
+          else above = av > (int)__float_as_uint(N::bias);
+          if (__any(above)) {  // wave-uniform: most accumulators have no survivor in any lane
             const int m = (r & 3) + 8 * (r >> 2) + 4 * h2;
             const f32x4m qk = s_qk[m];
-            const int init = acc_init(qk, rb[rg][0], rb[rg][1], rb[rg][2], rb[rg][3], rb[rg][4]);
-            if (av > kMfmaBias && m < nb && rit < rows_here) {
-              const uint32_t qc = (uint32_t)(av - init) / (uint32_t)S;
+            const float init = acc_init(qk, rb[rg][0], rb[rg][1], rb[rg][2], rb[rg][3], rb[rg][4]);
+            if (above && m < nb && rit < rows_here) {
+              uint32_t qc;
+              if constexpr (FP) qc = (uint32_t)((av - init) * (1.0f / S));   // both multiples of 1/4 inside one binade: exact (S is a power of two)
+              else qc = (uint32_t)(av - (int)__float_as_uint(init));
               const uint32_t slot = atomicAdd(&s_qcount[wave], 1u);
               if (slot < (uint32_t)kMfmaQueueCap) queue[slot] = qc | ((uint32_t)rit << 20) | ((uint32_t)m << 26);
               else atomicOr(a.s.flags + q0 + m, kFlagOverflow);  // more survivors than the queue holds: this query goes dense
@@ -483,16 +558,16 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
 
 // ---------------------------------------------------------------------------------------------------------------------
 
-static size_t mfma_smem_bytes(int w16, int cap) {
+static size_t mfma_smem_bytes(int w16, int cap, bool fp) {
   constexpr int NW = kChunkRows / 64;
-  return (size_t)w16 * 4 * 2 * 32 * 16 + (size_t)kMfmaQueries * 16 + (size_t)NW * 64 * 32 + (size_t)NW * kMfmaQueueCap * 4 + 32 +
+  return (size_t)mfma_query_bytes(w16, fp) + (size_t)kMfmaQueries * 16 + (size_t)NW * 64 * 32 + (size_t)NW * kMfmaQueueCap * 4 + 32 +
          kMfmaQueries * (sizeof(QueryParams) + 4 + 4) + 32 + (size_t)kMfmaQueries * (size_t)cap * 8 + 64;
 }
 
-template <int W, bool COMPACT, bool SCALED>
+template <int W, bool COMPACT, bool FP>
 static hipError_t launch_mfma_t(MfmaArgs a, int nq, int nc, hipStream_t s) {
-  const size_t smem = mfma_smem_bytes(W, a.s.cap);
-  // The chip holds 512 of these workgroups at a time (2 per CU) and a workgroup's prologue (staging the queries: 24 KB at 768-d, the
+  const size_t smem = mfma_smem_bytes(W, a.s.cap, FP);
+  // The chip holds 512 of these workgroups at a time (2 per CU) and a workgroup's prologue (staging the queries: 18 KB at 768-d, the
   // constants) costs about one chunk's worth of time.  Up to 12 chunks per workgroup: ONE round of workgroups, everything resident at
   // once.  Longer sweeps: about sqrt(2 x prologue x chunks / slots) chunks each, where the prologues and the idle tail of the last
   // workgroups cost the same.
@@ -502,7 +577,7 @@ static hipError_t launch_mfma_t(MfmaArgs a, int nq, int nc, hipStream_t s) {
   if (cpb > 12) cpb = std::min<int64_t>(kMfmaMaxChunksPerBlock, std::max<int64_t>(4, (int64_t)llround(sqrt((double)units / 220.0))));
   a.chunks_per_block = (int)cpb;
   dim3 grid((unsigned)((nc + a.chunks_per_block - 1) / a.chunks_per_block), (unsigned)groups, 1), block(kChunkRows, 1, 1);
-  auto kern = bbq_scan_mfma_kernel<W, COMPACT, SCALED>;
+  auto kern = bbq_scan_mfma_kernel<W, COMPACT, FP>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
@@ -512,26 +587,29 @@ static hipError_t launch_mfma_t(MfmaArgs a, int nq, int nc, hipStream_t s) {
 }
 
 template <int W>
-static hipError_t launch_mfma_w(const MfmaArgs &a, bool compact, bool scaled, int nq, int nc, hipStream_t s) {
-  if (compact) return scaled ? launch_mfma_t<W, true, true>(a, nq, nc, s) : launch_mfma_t<W, true, false>(a, nq, nc, s);
-  return scaled ? launch_mfma_t<W, false, true>(a, nq, nc, s) : launch_mfma_t<W, false, false>(a, nq, nc, s);
+static hipError_t launch_mfma_w(const MfmaArgs &a, bool compact, bool fp, int nq, int nc, hipStream_t s) {
+  if (compact) return fp ? launch_mfma_t<W, true, true>(a, nq, nc, s) : launch_mfma_t<W, true, false>(a, nq, nc, s);
+  return fp ? launch_mfma_t<W, false, true>(a, nq, nc, s) : launch_mfma_t<W, false, false>(a, nq, nc, s);
 }
 
 bool mfma_sweep_supported(const ScanArgs &a) {
   const int w = a.idx.w16;
   if (a.idx.store_bits != 1 || !(w == 1 || w == 6 || w == 8 || w == 12)) return false;
-  return mfma_smem_bytes(w, a.cap) <= 150 * 1024;
+  return mfma_smem_bytes(w, a.cap, false) <= 150 * 1024;
 }
 
-hipError_t launch_scan_mfma(const ScanArgs &sa, const uint8_t *qbytes, const float *qmax, bool scaled, int n_queries, int n_chunks, hipStream_t s) {
+int64_t mfma_query_bytes_per_group(int w16, bool fp) { return mfma_query_bytes(w16, fp); }
+
+hipError_t launch_scan_mfma(const ScanArgs &sa, const uint8_t *qbytes, const float *qmax, float fp_scale, int n_queries, int n_chunks, hipStream_t s) {
   if (n_chunks <= 0 || n_queries <= 0) return hipSuccess;
-  MfmaArgs a{sa, qbytes, qmax, n_queries, 1};
+  const bool fp = fp_scale > 0.0f;
+  MfmaArgs a{sa, qbytes, qmax, n_queries, 1, fp_scale};
   const bool compact = sa.idx.layout == kLayoutCompact;
   switch (sa.idx.w16) {
-    case 1: return launch_mfma_w<1>(a, compact, scaled, n_queries, n_chunks, s);
-    case 6: return launch_mfma_w<6>(a, compact, scaled, n_queries, n_chunks, s);
-    case 8: return launch_mfma_w<8>(a, compact, scaled, n_queries, n_chunks, s);
-    case 12: return launch_mfma_w<12>(a, compact, scaled, n_queries, n_chunks, s);
+    case 1: return launch_mfma_w<1>(a, compact, fp, n_queries, n_chunks, s);
+    case 6: return launch_mfma_w<6>(a, compact, fp, n_queries, n_chunks, s);
+    case 8: return launch_mfma_w<8>(a, compact, fp, n_queries, n_chunks, s);
+    case 12: return launch_mfma_w<12>(a, compact, fp, n_queries, n_chunks, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -54,14 +54,24 @@ def z_threshold(th, qc, cdp, sim, one_bit):
     return z - 1e-9 * (abs(z) + abs(qadd) + abs(cdp) + 1.0)
 
 
-BIAS = 0x4B400000
-BIAS_F = F32(12582912.0)
-MAG_LIMIT = F32(4000000.0)
+# bbq_mfma_kernels.hip MfmaNum<FP>: int8 form (query values up to 127: the i32 accumulator holds the start value's bits) and FP form
+# (query values <= 15 on FP6 x FP4: the f32 accumulator holds the value, in quarters of a qcDist unit)
+FORMS = {"int8": dict(S=1.0, ulp=1.0, bias=12582912.0, mag_limit=4000000.0, pass_all=12582912.0 + 2097152.0),
+         "fp": dict(S=0.25, ulp=0.0625, bias=786432.0, mag_limit=110000.0, pass_all=786432.0 + 131072.0)}
 
 
-def prefilter_pass(qcdist, lower, upper, add, x1, qc, cdp, dim, sim, one_bit, theta_score, qsum, S, rcp_ulps=0):
+def fp_scale(max_q):
+    """bbq_core.cpp enqueue_subbatch: products of q, q / 2 or q / 4 - the largest the query values leave room for in e2m3"""
+    return 1.0 if max_q <= 3 else 0.5 if max_q <= 7 else 0.25
+
+
+
+def prefilter_pass(qcdist, lower, upper, add, x1, qc, cdp, dim, sim, one_bit, theta_score, qsum, form, rcp_ulps=0, max_q=15):
     """bbq_mfma_kernels.hip: the prologue's per-query constants, row_constants(), acc_init() and the final compare, one query against
-    all rows.  rcp_ulps moves the reciprocal by that many ulps (v_rcp_f32 is good to one)."""
+    all rows.  rcp_ulps moves the reciprocal by that many ulps (v_rcp_f32 is good to one).  Returns (passes, ordinary rows, flagged):
+    flagged = the prologue hands the query to a sweep of its own (no usable threshold)."""
+    N = FORMS[form]
+    S, ulp, bias = (fp_scale(max_q) if form == "fp" else 1.0), F32(N["ulp"]), F32(N["bias"])
     with np.errstate(all="ignore"):
         ay = qc[0]
         ly = (qc[1] - qc[0]) if one_bit else (qc[1] - qc[0]) * FBS
@@ -69,10 +79,11 @@ def prefilter_pass(qcdist, lower, upper, add, x1, qc, cdp, dim, sim, one_bit, th
         cs = 2.0 if sim == 0 else 1.0
         beta = cs * ly
         zt = z_threshold(float(theta_score), qc, cdp, sim, one_bit)
-        A = -float(S) * (zt / beta)
-        A = min(max(A, -3.0e38), 3.0e38) if A == A else 3.0e38
-        qk = [F32(A), F32(-float(S) * (ay / ly)), F32(-float(S) * y1), F32(-float(S) / beta)]
-        g0 = F32(np.abs(qk[0]) * F32(1.0000002)) if np.abs(qk[0]) < F32(1.0e38) else F32(0.0)
+        A = -S * (zt / beta)
+        if not A < 1.0e30:
+            return np.ones(len(qcdist), bool), np.ones(len(qcdist), bool), True
+        qk = [F32(A) if A > -3.0e38 else F32(-3.0e38), F32(-S * (ay / ly)), F32(-S * y1), F32(-S / beta)]
+        g0 = F32(np.abs(qk[0]) * F32(1.0000002)) if np.abs(qk[0]) < F32(1.0e30) else F32(0.0)
         g1 = F32(S) * F32(abs(ay / ly) * 1.000001)
         g2 = F32(S) * F32(abs(y1) * 1.000001)
         g3 = F32(S) * F32(1.0 / beta * 1.000001)
@@ -88,26 +99,32 @@ def prefilter_pass(qcdist, lower, upper, add, x1, qc, cdp, dim, sim, one_bit, th
         r2 = -rho
         r3 = ((addf if sim == 0 else -addf) * r0).astype(F32)
         mag = fma32(g0, np.abs(r0), fma32(g1, fma32(np.abs(rho), D, np.abs(x1f)), fma32(g2, np.abs(rho), fma32(g3, np.abs(r3), g4))))
-        ok = (lxf > 0) & (r0 >= F32(1.0e-6)) & (mag < MAG_LIMIT)
-        K = np.where(ok, BIAS_F + np.ceil(fma32(mag, F32(9.5367431640625e-07), F32(4.0))), F32(np.inf)).astype(F32)
+        ok = (lxf > 0) & (mag < F32(N["mag_limit"]))
+        K = np.where(ok, bias + ulp * np.ceil(fma32(mag, F32(9.5367431640625e-07) / ulp, F32(2.25))), F32(N["pass_all"])).astype(F32)
         r0, r1, r2, r3 = [np.where(ok, v, F32(0.0)).astype(F32) for v in (r0, r1, r2, r3)]
         init = fma32(qk[0], r0, fma32(qk[1], r1, fma32(qk[2], r2, fma32(qk[3], r3, K))))
-        final = init.view(np.int32).astype(np.int64) + np.int64(S) * qcdist.astype(np.int64)
-        # the kernel's i32 accumulator wraps; it never does for a finite start value (S * qcDist < 2^21)
-        final = ((final + 2**31) % 2**32) - 2**31
-        return final > BIAS, ok
+        if form == "int8":     # the i32 accumulator: the start value's bits + qcDist
+            final = init.view(np.int32).astype(np.int64) + qcdist.astype(np.int64)
+            passed = final > np.int64(F32(bias).view(np.int32))
+            back = final - init.view(np.int32).astype(np.int64)
+        else:                  # the f32 accumulator: every partial sum is a multiple of 1/16 inside one binade, so the sum is exact
+            final = (init.astype(np.float64) + S * qcdist).astype(F32)
+            passed = final > bias
+            back = (final.astype(np.float64) - init.astype(np.float64)) / S
+        # whatever passes must give qcDist back exactly (the survivors' exact scores are computed from it)
+        assert (back[passed] == qcdist[passed]).all()
+        return passed, ok, False
 
 
 @pytest.mark.parametrize("sim", [0, 1, 2])
-@pytest.mark.parametrize("qb", [1, 4, 7])
-def test_prefilter_never_rejects_a_candidate(sim, qb):
+@pytest.mark.parametrize("qb,form", [(1, "fp"), (2, "fp"), (3, "fp"), (4, "fp"), (4, "int8"), (7, "int8")])
+def test_prefilter_never_rejects_a_candidate(sim, qb, form):
     rng = np.random.default_rng(31 * sim + qb)
     n, dim = 150000, 128
     codes = rng.integers(0, 256, size=(n, dim // 8), dtype=np.uint8)
     pop = np.unpackbits(codes, axis=1).sum(axis=1).astype(np.float64)
     qq = rng.integers(0, 1 << qb, dim).astype(np.uint8)
     qsum = float(qq.sum())
-    S = 8 if qq.max() <= 15 else 1
     for flavour in range(3):
         corr = np.zeros((n, 4))
         if flavour == 0:      # what a real index looks like
@@ -135,27 +152,30 @@ def test_prefilter_never_rejects_a_candidate(sim, qb):
             theta_score = np.float32(np.quantile(s32[ok], quantile))
             wins = ok & (key_of(s32) > key_of(np.array([theta_score]))[0])
             for ulps in (0, 1, -1):
-                passed, ordinary = prefilter_pass(d.astype(np.float64), corr[:, 0], corr[:, 1], corr[:, 2], pop, qc, cdp, dim, sim, one_bit,
-                                                  theta_score, qsum, S, ulps)
+                passed, ordinary, flagged = prefilter_pass(d.astype(np.float64), corr[:, 0], corr[:, 1], corr[:, 2], pop, qc, cdp, dim, sim,
+                                                           one_bit, theta_score, qsum, form, ulps, int(qq.max()))
                 assert passed[wins].all(), "the pre-filter rejected %d winning pairs (flavour %d, quantile %g, rcp %+d ulp)" % (
                     (~passed[wins]).sum(), flavour, quantile, ulps)
             if flavour == 0:
-                assert ordinary.all()                   # no real row takes the pass-everything exit
+                assert ordinary.all() and not flagged   # no real row takes the pass-everything exit
                 if quantile == 0.9999:                  # and it is a filter (EUCLIDEAN rows with a negative denominator are beyond z-space: a few %)
-                    assert passed[~wins & ok].mean() < (0.05 if sim == 0 else 2e-4)
-        # threshold key 0 (nothing known yet): every pair passes, weird rows included
-        passed, _ = prefilter_pass(d.astype(np.float64), corr[:, 0], corr[:, 1], corr[:, 2], pop, qc, cdp, dim, sim, one_bit, np.float32(np.nan), qsum, S)
-        assert passed.all()
+                    # (1-bit queries over 128 dimensions: qcDist has a standard deviation of 4 and the slack is 1.25)
+                    assert passed[~wins & ok].mean() < (0.05 if sim == 0 else 5e-3 if qb == 1 else 2e-4)
+        # threshold key 0 (nothing known yet): the query is handed to a sweep of its own
+        assert prefilter_pass(d.astype(np.float64), corr[:, 0], corr[:, 1], corr[:, 2], pop, qc, cdp, dim, sim, one_bit, np.float32(np.nan), qsum, form,
+                              0, int(qq.max()))[2]
 
 
-def test_prefilter_slack_is_small_on_a_real_shape():
-    """768-d, 4-bit query, corrections of a really quantized COSINE index: the start value's slack is a few accumulator units
-    (eighths of a qcDist unit), i.e. the test on the integer is as sharp as the f64 score itself"""
+@pytest.mark.parametrize("form,qb", [("fp", 4), ("int8", 7)])
+def test_prefilter_slack_is_small_on_a_real_shape(form, qb):
+    """768-d, corrections of a really quantized COSINE index, each form with the query values it is used for: the start value's slack
+    is three grains (3/4 of a qcDist unit in the FP form, 3 units in the int8 form, whose qcDist is eight times as wide), i.e. the
+    test on the integer is as sharp as the f64 score itself"""
     rng = np.random.default_rng(5)
-    n, dim, qb, sim = 20000, 768, 4, 1
+    n, dim, sim = 20000, 768, 1
     codes = rng.integers(0, 256, size=(n, dim // 8), dtype=np.uint8)
     pop = np.unpackbits(codes, axis=1).sum(axis=1).astype(np.float64)
-    qq = rng.integers(0, 16, dim).astype(np.uint8)
+    qq = rng.integers(0, 1 << qb, dim).astype(np.uint8)
     corr = np.zeros((n, 4))
     corr[:, 0] = -0.04 * (0.9 + 0.2 * rng.random(n))
     corr[:, 1] = 0.04 * (0.9 + 0.2 * rng.random(n))
@@ -165,7 +185,28 @@ def test_prefilter_slack_is_small_on_a_real_shape():
     d, s64, s32 = O.score_all(codes, corr, dim, qq, qc, qb, sim, 0.0009)
     theta_score = np.float32(np.quantile(s32, 0.999))
     wins = key_of(s32) > key_of(np.array([theta_score]))[0]
-    passed, ordinary = prefilter_pass(d.astype(np.float64), corr[:, 0], corr[:, 1], corr[:, 2], pop, qc, 0.0009, dim, sim, False, theta_score,
-                                      float(qq.sum()), 8)
-    assert ordinary.all() and passed[wins].all()
-    assert (passed & ~wins).sum() <= max(3, int(0.05 * wins.sum()))
+    passed, ordinary, flagged = prefilter_pass(d.astype(np.float64), corr[:, 0], corr[:, 1], corr[:, 2], pop, qc, 0.0009, dim, sim, False,
+                                               theta_score, float(qq.sum()), form, 0, int(qq.max()))
+    assert ordinary.all() and not flagged and passed[wins].all()
+    assert (passed & ~wins).sum() <= max(3, int(0.1 * wins.sum()))
+
+
+def test_fp6_codes_of_the_staged_query_values():
+    """fill_query_mfma_fp (bbq_core.cpp): e2m3 holds q / 2, q / 4, q / 8 exactly for q = 0..15; restated here and decoded again"""
+    for q in range(16):
+        for mult in (4, 2, 1, 8, 16):                # the value x 8 (x 2 and x 4 on top for query values up to 7 and up to 3)
+            if (mult == 8 and q > 7) or (mult == 16 and q > 3):
+                continue
+            e8 = q * mult
+            if e8 < 8:
+                code = e8
+            else:
+                e = 1
+                while e8 >= (8 << e):
+                    e += 1
+                assert (e8 & ((1 << (e - 1)) - 1)) == 0
+                code = (e << 3) | ((e8 >> (e - 1)) - 8)
+            assert 0 <= code < 32                    # no sign bit
+            ex, m = code >> 3, code & 7
+            val = m / 8.0 if ex == 0 else (1 + m / 8.0) * 2.0 ** (ex - 1)
+            assert val == e8 / 8.0
