@@ -174,17 +174,6 @@ __device__ __forceinline__ RowK row_constants(double al, double au, double add, 
   }
   return k;
 }
-// v_fma_f32 spelled out: left to itself the compiler pairs the chains of neighbouring accumulators into v_pk_fma_f32 (half rate on
-// gfx950) and spends a v_mov per operand pair on top
-__device__ __forceinline__ float fma_f32(float a, float b, float c) {
-  float d;
-  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
-__device__ __forceinline__ float acc_init(const f32x4m qk, float r0, float r1, float r2, float r3, float K) {
-  return fma_f32(qk.x, r0, fma_f32(qk.y, r1, fma_f32(qk.z, r2, fma_f32(qk.w, r3, K))));
-}
-
 struct MfmaArgs {
   ScanArgs s;
   const uint8_t *qbytes;   // int8 form: [groups][W*4 words][2 halves][32 queries][16 B] query values in fragment order; FP form: per group
@@ -226,6 +215,22 @@ __device__ __forceinline__ void load_tile_regs(TileRegs<W, COMPACT> &t, const In
   }
 }
 
+__device__ __forceinline__ int abits(float v) { return (int)__float_as_uint(v); }
+__device__ __forceinline__ int abits(int v) { return v; }
+
+// the 16 start values of a lane (16 queries x its row-group row): qk . rk + K as three chained v_mfma_f32_32x32x2_f32 on C = 0, K last
+// (the four products are summed at their own, much finer grain; only the last addition rounds at the binade's ulp).  The same call
+// on the same operands gives the same bits: the survivors' path calls it again.
+template <bool FP>
+__device__ __forceinline__ typename std::conditional<FP, f32x16m, i32x16m>::type start_values(float aq0, float aq1, float aq2, float b0, float b1, float b2) {
+  f32x16m c = {0};
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(aq0, b0, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(aq1, b1, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(aq2, b2, c, 0, 0, 0);
+  if constexpr (FP) return c;
+  else return __builtin_bit_cast(i32x16m, c);   // the int8 form accumulates onto the float's bits
+}
+
 // ---- one k-step of the FP form, as a template over the step index: the fragment reads are inline asm (ds_read with an immediate
 // offset, waited for by hand) because they must stay where they are written - one step ahead of their use.  Left to the compiler
 // every step's fragment is read ahead of the loop (12 x 6 registers at 768-d: spills); volatile reads leave the LDS address space.
@@ -243,7 +248,7 @@ __device__ __forceinline__ void fp_step(f32x16m &acc0, f32x16m &acc1, const u32x
                                   // passes through an asm behind it, or the compiler issues them first to reuse the registers)
     asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%5"
                  : "=v"(bq), "=v"(bq2) : "v"(addr16), "v"(addr8), "n"((G + 1) * 1024), "n"((G + 1) * 512));
-    asm volatile("" : "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2]), "+v"(Q[3]), "+v"(Q[4]), "+v"(Q[5]));
+    asm volatile("" : "+v"(Q));
   }
   // bits 0, 1, 2 of every nibble where they stand are the FP4 numbers 0.5, 1.0, 2.0; bit 3 would be the sign: it moves to bit 0
   R0[0] = (int)(sw[0] & 0x11111111u); R0[1] = (int)(sw[0] & 0x22222222u); R0[2] = (int)(sw[0] & 0x44444444u); R0[3] = (int)((sw[0] >> 3) & 0x11111111u);
@@ -347,6 +352,14 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
 
   const int sim = s_qp[0].sim;                  // uniform over the call
   const float Df = (float)a.s.idx.dim;
+  // A operands of the start-value contraction (start_values): query n's constants, k = 0 in the lower half-wave, k = 1 in the upper
+  float aq0, aq1, aq2;
+  {
+    const f32x4m qkm = s_qk[n];
+    aq0 = h ? qkm.y : qkm.x;
+    aq1 = h ? qkm.w : qkm.z;
+    aq2 = h ? 0.0f : 1.0f;
+  }
 #pragma unroll 1
   for (int ci = 0; ci < cpb; ++ci) {
   // opaque zero, redefined every iteration: keeps the compiler from hoisting the query-fragment LDS reads out of the chunk loop
@@ -371,28 +384,19 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
       ax.x = t.add; ax.y = x1row;
       s_ax[wave * 64 + lane] = ax;
     }
-    const auto k0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r0), __float_as_uint(mine.r0), false, false);
-    const auto k1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r1), __float_as_uint(mine.r1), false, false);
-    const auto k2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r2), __float_as_uint(mine.r2), false, false);
-    const auto k3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r3), __float_as_uint(mine.r3), false, false);
-    const auto kK = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.K), __float_as_uint(mine.K), false, false);
-    float ra[2][5];
+    // ---- the accumulators start at the (negated, biased) thresholds of their pairs:  C[query][row] = qk[query] . rk[row] + K[row],
+    // itself a contraction (six terms: four products, K x 1, 0 x 0) - three v_mfma_f32_32x32x2_f32 per row group, which evaluate it
+    // as a chain of f32 FMAs (as 128 v_fma_f32 per tile and wave it was a third of the kernel's vector instructions).  The B operand
+    // of k-step s is {rk[2s] in the lower half-wave, rk[2s + 1] in the upper} of the row group's row n: one swap of my own row's two
+    // constants gives both row groups' operands ([0]: rows 0..31, [1]: rows 32..63).
+    const auto b0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r0), __float_as_uint(mine.r1), false, false);
+    const auto b1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r2), __float_as_uint(mine.r3), false, false);
+    const auto b2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.K), 0u, false, false);
+    float rb[2][3];
 #pragma unroll
-    for (int rg = 0; rg < 2; ++rg) {
-      ra[rg][0] = __uint_as_float(k0[rg]); ra[rg][1] = __uint_as_float(k1[rg]); ra[rg][2] = __uint_as_float(k2[rg]);
-      ra[rg][3] = __uint_as_float(k3[rg]); ra[rg][4] = __uint_as_float(kK[rg]);
-    }
-    // ---- the accumulators start at the (negated, biased) thresholds of their pairs (int8 form: the float's bits)
-    Acc acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = (r & 3) + 8 * (r >> 2) + 4 * h;  // query of this accumulator
-      const f32x4m qk = s_qk[m + lds_off];            // the same address for the whole half-wave
-      const float i0 = acc_init(qk, ra[0][0], ra[0][1], ra[0][2], ra[0][3], ra[0][4]);
-      const float i1 = acc_init(qk, ra[1][0], ra[1][1], ra[1][2], ra[1][3], ra[1][4]);
-      if constexpr (FP) { acc0[r] = i0; acc1[r] = i1; }
-      else { acc0[r] = (int)__float_as_uint(i0); acc1[r] = (int)__float_as_uint(i1); }
-    }
+    for (int rg = 0; rg < 2; ++rg) { rb[rg][0] = __uint_as_float(b0[rg]); rb[rg][1] = __uint_as_float(b1[rg]); rb[rg][2] = __uint_as_float(b2[rg]); }
+    Acc acc0 = start_values<FP>(aq0, aq1, aq2, rb[0][0], rb[0][1], rb[0][2]);
+    Acc acc1 = start_values<FP>(aq0, aq1, aq2, rb[1][0], rb[1][1], rb[1][2]);
     // ---- the contraction: C[m = query][n = row of the group] += sum over the k-steps
     if constexpr (FP) {
       // LDS byte addresses of this lane's fragment of step 0 (the pointers are LDS pointers: their low 32 bits are the offset)
@@ -424,35 +428,27 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
       if (ci + 1 < cpb && lc + 1 < a.s.n_chunks && tn < n_tiles) load_tile_regs<W, COMPACT>(t, a.s.idx, tn, lane);
     }
     // ---- any accumulator above the bias?
-    bool any_lane;
-    if constexpr (FP) {
-      float mx = acc0[0];
+    // (compared as integers in both forms: positive floats order like their bits, a negative start value - a lane without a query - is
+    // a negative integer, NaN cannot arise; v_max3_i32 takes two accumulators per instruction, the f32 maximum with its NaN rules one)
+    int mx = abits(acc0[0]);
 #pragma unroll
-      for (int r = 1; r < 16; r += 2) mx = fmaxf(mx, fmaxf(acc0[r], r + 1 < 16 ? acc0[r + 1] : acc0[r]));
+    for (int r = 1; r < 16; r += 2) mx = max(mx, max(abits(acc0[r]), r + 1 < 16 ? abits(acc0[r + 1]) : abits(acc0[r])));
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(acc1[r], acc1[r + 1]));
-      any_lane = mx > N::bias;
-    } else {
-      int mx = acc0[0];
-#pragma unroll
-      for (int r = 1; r < 16; r += 2) mx = max(mx, max(acc0[r], r + 1 < 16 ? acc0[r + 1] : acc0[r]));
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) mx = max(mx, max(acc1[r], acc1[r + 1]));
-      any_lane = mx > (int)__float_as_uint(N::bias);
-    }
+    for (int r = 0; r < 16; r += 2) mx = max(mx, max(abits(acc1[r]), abits(acc1[r + 1])));
+    const bool any_lane = mx > (int)__float_as_uint(N::bias);
     uint32_t *__restrict__ queue = s_queue + (size_t)wave * kMfmaQueueCap;
     if (__any(any_lane)) {
       const int rows_here = (int)min((int64_t)kTileRows, a.s.idx.n_rows - tile * kTileRows);
-      // survivors: take qcDist from the difference to the accumulator's start value, which is derived again (the same four
-      // instructions on the same operands: the same bits).  The constants pass through an empty asm so that the compiler cannot keep
-      // all 32 start values alive across the contraction instead.
-      float rb[2][5];
+      // survivors: take qcDist from the difference to the accumulator's start value, which is derived again (the same instructions on
+      // the same operands: the same bits).  The operands pass through an empty asm so that the compiler cannot keep all 32 start values
+      // alive across the contraction instead.
+      float rc[2][3];
 #pragma unroll
       for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          rb[rg][j] = ra[rg][j];
-          asm volatile("" : "+v"(rb[rg][j]));
+        for (int j = 0; j < 3; ++j) {
+          rc[rg][j] = rb[rg][j];
+          asm volatile("" : "+v"(rc[rg][j]));
         }
       // (the lane's coordinates as well: everything derived from them here - 32 queue words, 16 query-exists masks - would otherwise be
       // hoisted out of the chunk loop and held in registers for the whole kernel)
@@ -461,20 +457,22 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
 #pragma unroll
       for (int rg = 0; rg < 2; ++rg) {
         const int rit = 32 * rg + n2;
+        const Acc &accv = rg == 0 ? acc0 : acc1;
+        bool any_rg = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) any_rg = any_rg || abits(accv[r]) > (int)__float_as_uint(N::bias);
+        if (!__any(any_rg)) continue;  // wave-uniform
+        const Acc init = start_values<FP>(aq0, aq1, aq2, rc[rg][0], rc[rg][1], rc[rg][2]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const auto av = rg == 0 ? acc0[r] : acc1[r];
-          bool above;
-          if constexpr (FP) above = av > N::bias;
-          else above = av > (int)__float_as_uint(N::bias);
+          const auto av = accv[r];
+          const bool above = abits(av) > (int)__float_as_uint(N::bias);
           if (__any(above)) {  // wave-uniform: most accumulators have no survivor in any lane
             const int m = (r & 3) + 8 * (r >> 2) + 4 * h2;
-            const f32x4m qk = s_qk[m];
-            const float init = acc_init(qk, rb[rg][0], rb[rg][1], rb[rg][2], rb[rg][3], rb[rg][4]);
             if (above && m < nb && rit < rows_here) {
               uint32_t qc;
-              if constexpr (FP) qc = (uint32_t)((av - init) * (1.0f / S));   // both multiples of 1/4 inside one binade: exact (S is a power of two)
-              else qc = (uint32_t)(av - (int)__float_as_uint(init));
+              if constexpr (FP) qc = (uint32_t)((av - init[r]) * (1.0f / S));   // both on the 1/16 grid inside one binade: exact (S is a power of two)
+              else qc = (uint32_t)(av - init[r]);
               const uint32_t slot = atomicAdd(&s_qcount[wave], 1u);
               if (slot < (uint32_t)kMfmaQueueCap) queue[slot] = qc | ((uint32_t)rit << 20) | ((uint32_t)m << 26);
               else atomicOr(a.s.flags + q0 + m, kFlagOverflow);  // more survivors than the queue holds: this query goes dense
