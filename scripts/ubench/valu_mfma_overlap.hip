@@ -6,7 +6,7 @@
 #include <cstdio>
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
-template <int NV, int NM>
+template <int NV, int NM, int PIN>
 __global__ __launch_bounds__(256) void k(float *sink, int iters) {
   v8i a, b;
   for (int i = 0; i < 8; ++i) { a[i] = threadIdx.x * 2654435761u + i; b[i] = 0x11111111 * (i & 1); }
@@ -24,12 +24,24 @@ __global__ __launch_bounds__(256) void k(float *sink, int iters) {
     for (int i = 0; i < NM / 2; ++i) {
       c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c0, 2, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
       c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c1, 2, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-      asm volatile("" : "+v"(c0), "+v"(c1));
+      if (PIN == 1) asm volatile("" : "+v"(c0), "+v"(c1));
+      if (PIN == 2) {  // five vector instructions in each MFMA's shadow, like the expansion of the sweep kernel
+        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f0) : "v"(f1), "v"(f2));
+        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f1) : "v"(f2), "v"(f3));
+        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f2) : "v"(f3), "v"(f0));
+        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f3) : "v"(f0), "v"(f1));
+        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f0) : "v"(f1), "v"(f2));
+        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f1) : "v"(f2), "v"(f3));
+        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f2) : "v"(f3), "v"(f0));
+        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f3) : "v"(f0), "v"(f1));
+        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f0) : "v"(f1), "v"(f2));
+        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f1) : "v"(f2), "v"(f3));
+      }
     }
   }
   if (c0[0] + c1[0] + f0 + f1 + f2 + f3 == 12345.f) sink[0] = 1.f;
 }
-template <int NV, int NM>
+template <int NV, int NM, int PIN = 0>
 static float run(int waves_per_simd, int iters, float *sink) {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -37,7 +49,7 @@ static float run(int waves_per_simd, int iters, float *sink) {
   float ms = 0;
   for (int rep = 0; rep < 2; ++rep) {
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((k<NV, NM>), dim3(blocks), dim3(256), 0, 0, sink, iters);
+    hipLaunchKernelGGL((k<NV, NM, PIN>), dim3(blocks), dim3(256), 0, 0, sink, iters);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     (void)hipEventElapsedTime(&ms, e0, e1);
@@ -53,6 +65,9 @@ int main() {
     const float tv2 = run<160, 0>(w, iters, sink), tb2 = run<160, 24>(w, iters, sink);
     // per wave and iteration, in ns: time / iters / waves per SIMD
     const float s = 1e6f / iters / w;
+    const float tmp = run<0, 24, 1>(w, iters, sink), tbp = run<320, 24, 1>(w, iters, sink), tsh = run<0, 24, 2>(w, iters, sink), tshv = run<200, 24, 2>(w, iters, sink);
+    printf("%d waves/SIMD: accumulators named between MFMA pairs: 24 MFMA %6.0f ns, with 320 VALU %6.0f | 24 MFMA with 120 VALU in their shadows %6.0f ns, + a block of 200 VALU %6.0f\n", w,
+           tmp * s, tbp * s, tsh * s, tshv * s);
     printf("%d waves/SIMD: per wave-iteration  320 VALU %6.0f ns   24 MFMA %6.0f ns   both %6.0f ns  (sum %6.0f, max %6.0f) | 160 VALU %6.0f, with 24 MFMA %6.0f\n", w,
            tv * s, tm * s, tb * s, (tv + tm) * s, (tv > tm ? tv : tm) * s, tv2 * s, tb2 * s);
   }
