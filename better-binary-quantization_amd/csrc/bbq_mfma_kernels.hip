@@ -12,32 +12,38 @@
 //
 // Round 4: the kernel was bound by vector issue (profiles/r03_mfma_pmc.json: 1 349 vector instructions per tile and wave next to
 // 48 MFMAs, the matrix cores 24 % busy) - 16 instructions per (row, query) pair of pre-filter and 9 per MFMA of bit -> int8
-// expansion.  Both are gone:
+// expansion.  Both are gone (profiles/r04_mfma_pmc.json: ~340 vector instructions and 30 MFMAs per tile and wave):
 //  * THE PRE-FILTER LIVES IN THE ACCUMULATOR.  "score > theta" is, for a row with upper > lower and a query with upper > lower,
 //    an inequality on the integer itself:  qcDist > T(query, row), where T is a sum of four (per-query constant) x (per-row
 //    constant) products (derivation at row_constants()).  The MFMA's C operand is initialised with the float
-//        bias + slack(row) - S * T(query, row)          (4 v_fma_f32 per pair, nothing else)
-//    in a binade where one ulp is one unit of S * qcDist; the matrix cores add S * qcDist EXACTLY, and a pair can only be a
-//    candidate if its accumulator ends above the bias: one v_max3 per two pairs finds out whether a tile has any.  4.5 vector
-//    instructions per pair instead of 16, no conversion, no compare per pair.  Tiles with a survivor (about one in five) derive
-//    the start value of the few accumulators that passed again and take qcDist from the difference.
+//        bias + slack(row) - S * T(query, row)
+//    in a binade where one ulp is the grain of the threshold; the matrix cores add S * qcDist EXACTLY, and a pair can only be a
+//    candidate if its accumulator ends above the bias: one v_max3_i32 per two pairs finds out whether a tile has any.  No
+//    conversion, no compare per pair.  Tiles with a survivor (one in twelve in the largest segment) derive the start values of the
+//    row group again and take qcDist from the difference.
+//    The start values are themselves a contraction - C[query][row] = qk[query] . rk[row] + K[row] - and run on
+//    v_mfma_f32_32x32x2_f32 (start_values(): three per row group), not on the vector ALUs.
 //    The constants are f32 images of the EXACT f64 corrections (both layouts: the compact layout reads its side array exact[],
 //    32 B/row more per 32 queries - this kernel is nowhere near the HBM bound), so no per-pair error terms exist: every rounding
-//    is covered by a per-row slack of a few ulps, a few hundredths of a standard deviation of qcDist.
+//    is covered by a per-row slack of three grains, a few hundredths of a standard deviation of qcDist.
 //  * QUERY VALUES <= 15 (queryBits <= 4) RUN ON v_mfma_f32_32x32x64_f8f6f4, FP6 x FP4 (template FP).  A 1-bit code IS an FP4
 //    number where it stands: the nibble patterns 0001, 0010, 0100 are 0.5, 1.0 and 2.0 (e2m1), so  w & 0x11111111,  w & 0x22222222,
-//    w & 0x44444444  and  (w >> 3) & 0x11111111  turn one 32-dimension word into the 32 FP4 operands of a lane - 5 vector
-//    instructions for 64 dimensions of two row groups' worth... per MFMA, no shift per dword, no byte expansion.  The host stores the
-//    query values as FP6 (e2m3: four significant bits, exactly q / 2, q / 4, q / 8 for q <= 15) scaled against the bit's weight, so every
-//    product is q / 4 and the f32 accumulator - started in the binade [2^19, 2^20), on a grid of 1/16 - holds bias - T/4 + qcDist/4 exactly.
-//    The instruction takes 64 dimensions in the time v_mfma_i32_32x32x32_i8 takes for 32 (scripts/ubench/mfma_fp4_probe.hip: layout,
-//    exactness and rate measured on gfx950): half the matrix-core time and half the expansion of the int8 form.
+//    w & 0x44444444  and  (w >> 3) & 0x11111111  turn one 32-dimension word into the 32 FP4 operands of a lane: 5 vector
+//    instructions per MFMA of 64 dimensions, no byte expansion.  The host stores the query values as FP6 (e2m3: four significant
+//    bits, exactly q / 2, q / 4, q / 8 for q <= 15) scaled against the bit's weight, so every product is q / 4 and the f32 accumulator -
+//    started in the binade [2^19, 2^20), on a grid of 1/16 - holds bias - T/4 + qcDist/4 exactly.  The instruction takes 64 dimensions
+//    in the time v_mfma_i32_32x32x32_i8 takes for 32 (scripts/ubench/mfma_fp4_probe.hip: layout, exactness and rate measured on
+//    gfx950): half the matrix-core time and half the expansion of the int8 form.
 //    Query values up to 127 stay on v_mfma_i32_32x32x32_i8 with the {0, 1} byte expansion: there the start value's BITS (a float in
 //    [2^23, 2^24): 0x4B000000 + its integer distance from 2^23) are the i32 accumulator.
 //    One v_permlane32_swap hands BOTH row groups their operand words (own or half-wave partner's row).
-//  * Both row groups' accumulators are live at once, so a query fragment is read from LDS once for two MFMAs and a query's
-//    constants once for two rows, and the next tile's loads are issued as soon as the contraction has consumed the codes - into the
-//    same registers.
+//  * Both row groups' accumulators are live at once, so a query fragment is read from LDS once for two MFMAs, and the next tile's
+//    loads are issued as soon as the contraction has consumed the codes - into the same registers.
+// What binds it now (scripts/ubench/valu_mfma_overlap.hip, four waves per SIMD): a vector instruction issued in the shadow of the
+// SAME wave's MFMA is nearly free (five per MFMA: + 19 %), but a wave in a vector-only phase and a wave in an MFMA phase barely
+// overlap on one SIMD (a block of 320 v_fma_f32 and a block of 24 MFMAs: 710 ns together, 431 and 391 ns alone).  The contraction's
+// shadows are full (the operand expansion), so the ~190 vector instructions outside it - the row's popcount and constants, the
+// addresses of the next tile, the survivor test - add their time to the matrix cores' instead of hiding behind it.
 // Packed f32 instructions (v_pk_fma_f32) are NOT used: on gfx950 they issue at half rate (MI355X_MICROARCH.md, cycle constants).
 //
 // The rare survivors go through the exact f64 score of the one-sweep kernel, so the emitted candidates - and therefore the
@@ -231,46 +237,33 @@ __device__ __forceinline__ typename std::conditional<FP, f32x16m, i32x16m>::type
   else return __builtin_bit_cast(i32x16m, c);   // the int8 form accumulates onto the float's bits
 }
 
-// ---- one k-step of the FP form, as a template over the step index.
-// The MFMAs of the contraction are inline asm: they must stay where they are written - behind the read of the NEXT step's query
-// fragment, in front of the read after that - and nothing in the compiler's vocabulary keeps a builtin MFMA in place without naming
-// its accumulator, which stops the chain from streaming (an empty asm on the accumulators per step: 2.5 x the MFMA time,
-// scripts/ubench/valu_mfma_overlap.hip).  Left alone the compiler reads every step's fragment ahead of the loop (12 x 6 registers at
-// 768-d) and spills.  The fragment reads stay the compiler's (its own s_waitcnt, the six registers of the operand filled in place);
-// their address passes through the preceding MFMA's asm, which is what keeps them behind it.
-// Hazards the compiler would have handled: a vector instruction's result read by an MFMA needs 2 wait states (s_nop 1 in front of
-// every MFMA); the accumulators are read by vector instructions only behind fp_steps_done().
-typedef int i32x6m __attribute__((ext_vector_type(6)));
-typedef const u32x4m __attribute__((address_space(3))) *LdsFrag16;   // LDS pointers (32-bit): they pass through the asm as the tokens
-typedef const u32x2m __attribute__((address_space(3))) *LdsFrag8;
-__device__ __forceinline__ void mfma_fp6_fp4(f32x16m &acc, const i32x6m q, const i32x4m r, uint32_t scale, LdsFrag16 &t16, LdsFrag8 &t8) {
-  // A = queries (FP6 e2m3, cbsz 2), B = rows (FP4 e2m1, blgp 4), block scales 2^0
-  asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %3, %4, %0, %5, %5 op_sel_hi:[0,0,0] cbsz:2 blgp:4"
-               : "+v"(acc), "+v"(t16), "+v"(t8) : "v"(q), "v"(r), "v"(scale));
-}
-__device__ __forceinline__ void fp_steps_done(f32x16m &acc0, f32x16m &acc1) {
-  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc0), "+v"(acc1));   // a 16-pass MFMA's result may be read 18 wait states after its issue
-}
+// ---- one k-step of the FP form, as a template over the step index: the fragment reads are inline asm (ds_read with an immediate
+// offset, waited for by hand) because they must stay where they are written - one step ahead of their use.  Left to the compiler
+// every step's fragment is read ahead of the loop (12 x 6 registers at 768-d: spills); volatile reads leave the LDS address space.
 template <int G, int STEPS, int W>
-__device__ __forceinline__ void fp_step(f32x16m &acc0, f32x16m &acc1, const u32x4m (&c)[W], u32x4m &bq, u32x2m &bq2, LdsFrag16 &pB, LdsFrag8 &pB2, uint32_t scale) {
+__device__ __forceinline__ void fp_step(f32x16m &acc0, f32x16m &acc1, const u32x4m (&c)[W], u32x4m &bq, u32x2m &bq2, uint32_t addr16, uint32_t addr8) {
   // a lane supplies 32 of a step's 64 dimensions: ONE code word - word 2G of its row group's row n in the lower half-wave, word
   // 2G + 1 in the upper.  swap(word 2G, word 2G + 1) of my own row: [0] = {row n: 2G | row n: 2G + 1}, [1] = the same of row 32 + n
   const uint32_t wa = (G & 1) == 0 ? c[G >> 1].x : c[G >> 1].z;
   const uint32_t wb = (G & 1) == 0 ? c[G >> 1].y : c[G >> 1].w;
   const auto sw = __builtin_amdgcn_permlane32_swap(wa, wb, false, false);
-  i32x6m Q;
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq), "+v"(bq2));   // this step's fragment has arrived
+  i32x8m Q, R0, R1;   // 8 dwords wide for the builtin; FP6 uses 6 of them and FP4 4: the others stay undefined
   Q[0] = (int)bq.x; Q[1] = (int)bq.y; Q[2] = (int)bq.z; Q[3] = (int)bq.w; Q[4] = (int)bq2.x; Q[5] = (int)bq2.y;
-  if constexpr (G + 1 < STEPS) {  // the next step's fragment, one step ahead (behind the previous step's MFMAs: the token)
-    bq = pB[(G + 1) * 64];
-    bq2 = pB2[(G + 1) * 64];
+  if constexpr (G + 1 < STEPS) {  // the next step's fragment, one step ahead: the read is issued BEFORE this step's MFMAs (their operand
+                                  // passes through an asm behind it, or the compiler issues them first to reuse the registers)
+    asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%5"
+                 : "=v"(bq), "=v"(bq2) : "v"(addr16), "v"(addr8), "n"((G + 1) * 1024), "n"((G + 1) * 512));
+    asm volatile("" : "+v"(Q));
   }
   // bits 0, 1, 2 of every nibble where they stand are the FP4 numbers 0.5, 1.0, 2.0; bit 3 would be the sign: it moves to bit 0
-  i32x4m R0, R1;
-  R0.x = (int)(sw[0] & 0x11111111u); R0.y = (int)(sw[0] & 0x22222222u); R0.z = (int)(sw[0] & 0x44444444u); R0.w = (int)((sw[0] >> 3) & 0x11111111u);
-  R1.x = (int)(sw[1] & 0x11111111u); R1.y = (int)(sw[1] & 0x22222222u); R1.z = (int)(sw[1] & 0x44444444u); R1.w = (int)((sw[1] >> 3) & 0x11111111u);
-  mfma_fp6_fp4(acc0, Q, R0, scale, pB, pB2);
-  mfma_fp6_fp4(acc1, Q, R1, scale, pB, pB2);
-  if constexpr (G + 1 < STEPS) fp_step<G + 1, STEPS, W>(acc0, acc1, c, bq, bq2, pB, pB2, scale);
+  R0[0] = (int)(sw[0] & 0x11111111u); R0[1] = (int)(sw[0] & 0x22222222u); R0[2] = (int)(sw[0] & 0x44444444u); R0[3] = (int)((sw[0] >> 3) & 0x11111111u);
+  R1[0] = (int)(sw[1] & 0x11111111u); R1[1] = (int)(sw[1] & 0x22222222u); R1[2] = (int)(sw[1] & 0x44444444u); R1[3] = (int)((sw[1] >> 3) & 0x11111111u);
+  // A = queries (FP6 e2m3, cbsz 2), B = rows (FP4 e2m1, blgp 4), block scales 2^0
+  acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Q, R0, acc0, 2, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Q, R1, acc1, 2, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  asm volatile("" : "+v"(acc0), "+v"(acc1));  // ordered with the reads: this step's MFMAs are issued before the next step begins
+  if constexpr (G + 1 < STEPS) fp_step<G + 1, STEPS, W>(acc0, acc1, c, bq, bq2, addr16, addr8);
 }
 
 // bytes of one group's staged query operands
@@ -412,14 +405,12 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
     Acc acc1 = start_values<FP>(aq0, aq1, aq2, rb[1][0], rb[1][1], rb[1][2]);
     // ---- the contraction: C[m = query][n = row of the group] += sum over the k-steps
     if constexpr (FP) {
-      LdsFrag16 pB = (LdsFrag16)(s_B + h * 32 + n + lds_off);
-      LdsFrag8 pB2 = (LdsFrag8)(s_B2 + h * 32 + n + lds_off);
-      uint32_t scale = 0x7f7f7f7fu;
-      asm volatile("" : "+v"(scale));    // (a register, not a literal: the asm below names it)
-      u32x4m bq = pB[0];
-      u32x2m bq2 = pB2[0];
-      fp_step<0, STEPS, W>(acc0, acc1, t.c, bq, bq2, pB, pB2, scale);
-      fp_steps_done(acc0, acc1);
+      // LDS byte addresses of this lane's fragment of step 0 (the pointers are LDS pointers: their low 32 bits are the offset)
+      const uint32_t addr16 = (uint32_t)(uintptr_t)(s_B + h * 32 + n + lds_off), addr8 = (uint32_t)(uintptr_t)(s_B2 + h * 32 + n + lds_off);
+      u32x4m bq;
+      u32x2m bq2;
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b64 %1, %3" : "=v"(bq), "=v"(bq2) : "v"(addr16), "v"(addr8));
+      fp_step<0, STEPS, W>(acc0, acc1, t.c, bq, bq2, addr16, addr8);
     } else {
 #pragma unroll
       for (int g = 0; g < WORDS; ++g) {
