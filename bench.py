@@ -220,13 +220,28 @@ def time_steps(ix, batches, QB, SIM, k):
     return time.perf_counter() - t0, res
 
 
-# the sweeps keep a prefix of the index in the 256 MiB Infinity Cache (library option resident_mb, bbq_stats.resident_bytes)
-RESIDENT_NOTE = ("achieved = ALGORITHMIC bytes per second against the HBM peak; cache_resident_bytes_per_sweep of the bytes one query sweeps "
-                 "(every scan launch of a sub-batch keeps up to 224 MiB of ITS row range) are loaded with the default cache policy and stay "
-                 "in the 256 MiB Infinity Cache between the sweeps of successive queries, the rest is streamed with "
-                 "non-temporal loads: the resident part's re-reads do not reach HBM, and an index that fits entirely is bounded by "
-                 "the cache's delivery rate, not by HBM.  `traffic` (FETCH_SIZE x2 + WRITE_SIZE) counts the bytes that left the L2s; the "
-                 "Infinity Cache sits behind that counter, so traffic stays ~= the algorithmic bytes and is an upper bound of the HBM bytes")
+# Part of every sweep is served by the 256 MiB Infinity Cache (library option resident_mb, bbq_stats.resident_bytes): the default run's
+# rate of ALGORITHMIC bytes is therefore not an HBM rate.  What the roofline object calls `frac` is the strict figure: the same step with
+# resident_mb = 0 (nothing kept in the cache, every byte of every sweep streamed from HBM).
+RESIDENT_NOTE = ("frac / achieved = the dominant launch with resident_mb 0: nothing is kept in the Infinity Cache, every byte of every sweep comes "
+                 "from HBM (the HBM roofline in its strict sense).  frac_algorithmic / achieved_algorithmic = the default run: "
+                 "cache_resident_frac_of_sweep of the bytes a query sweeps stay in the 256 MiB Infinity Cache between the sweeps of successive "
+                 "queries, so the algorithmic bytes per second exceed what HBM delivered; it is NOT an HBM fraction.  `traffic` (FETCH_SIZE x2 "
+                 "+ WRITE_SIZE) counts the bytes that left the L2s; the Infinity Cache sits behind that counter")
+
+
+def roofline_object(strict_gbps, algorithmic_gbps, resident_frac, extra):
+    """the bench line's roofline object.  `frac` is ALWAYS an HBM fraction in the strict sense (resident_mb 0) or null when that leg was
+    skipped; the default run's cache-assisted rate stands beside it under names that do not claim HBM.  An index that lives in the
+    Infinity Cache (resident fraction >= 0.9) is labelled as bound by the cache in its default mode."""
+    r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "achieved": strict_gbps, "frac": (strict_gbps / HBM_PEAK_GBS) if strict_gbps else None,
+         "frac_is": "strict HBM: dominant launch with nothing kept in the Infinity Cache (resident_mb 0)" if strict_gbps else "not measured (--no-hbm-only)",
+         "achieved_algorithmic": algorithmic_gbps, "frac_algorithmic": algorithmic_gbps / HBM_PEAK_GBS,
+         "default_mode_bound": "infinity_cache" if resident_frac >= 0.9 else "hbm + infinity_cache (%.0f %% of a sweep's bytes cache-resident)" % (100 * resident_frac),
+         "cache_resident_frac_of_sweep": resident_frac, "note": RESIDENT_NOTE}
+    r.update(extra)
+    return r
 
 
 def config_leg(B, torch, name, N, dim, k, QB, IB, sim_name, device, steps, warmup, Q, slots, replay_threads, parity=True):
@@ -255,15 +270,30 @@ def config_leg(B, torch, name, N, dim, k, QB, IB, sim_name, device, steps, warmu
     launch_ms = st["total_scan_ms"] / max(st["total_scan_launches"], 1)
     achieved = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
     qps = steps * Q / dt
+    # the same step with nothing kept in the Infinity Cache (resident_mb 0): every byte of every sweep from HBM - the HBM roofline's figure
+    ix.set_option("resident_mb", 0)
+    strict_steps = max(2, steps // 2)
+    time_steps(ix, batches[:1], QB, SIM, k)
+    ix.reset_stats()
+    torch.cuda.synchronize()
+    dts, res_s = time_steps(ix, batches[warmup:warmup + strict_steps], QB, SIM, k)
+    torch.cuda.synchronize()
+    sts = ix.stats()
+    ix.set_option("resident_mb", -1)
+    lbs = sts["total_scan_bytes"] / max(sts["total_scan_launches"], 1)
+    lms = sts["total_scan_ms"] / max(sts["total_scan_launches"], 1)
+    strict = lbs / (lms * 1e-3) / 1e9 if lms > 0 else 0.0
     out = {"workload": "%dx%d-dim %d-bit index, queryBits=%d, k=%d, %s" % (N, dim, IB, QB, k, sim_name), "value": qps, "unit": "queries/s",
            "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "queries_per_step": Q, "bytes_per_row": bpr,
-           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "bytes_per_launch": launch_bytes, "avg_launch_ms": launch_ms, "launches_timed": st["total_scan_launches"],
-                        "how": "HIP events around the largest-segment launch on its own stream",
-                        "cache_resident_bytes_per_sweep": st["resident_bytes"], "cache_resident_frac_of_sweep": st["resident_bytes"] / float(N * bpr),
-                        "note": RESIDENT_NOTE},
-           "end_to_end_hbm_frac": qps * N * bpr / 1e9 / HBM_PEAK_GBS, "host_replays": st["host_replays"], "dense_fallbacks": st["dense_fallbacks"],
-           "build_s": round(build_s, 1)}
+           "roofline": roofline_object(strict, achieved, st["resident_bytes"] / float(N * bpr),
+                                       {"bytes_per_launch": launch_bytes, "avg_launch_ms": launch_ms, "launches_timed": st["total_scan_launches"],
+                                        "strict_avg_launch_ms": lms, "strict_launches_timed": sts["total_scan_launches"],
+                                        "how": "HIP events around the largest-segment launch on its own stream",
+                                        "cache_resident_bytes_per_sweep": st["resident_bytes"]}),
+           "end_to_end_hbm_frac_strict": (strict_steps * Q / dts) * N * bpr / 1e9 / HBM_PEAK_GBS,
+           "end_to_end_frac_algorithmic": qps * N * bpr / 1e9 / HBM_PEAK_GBS,
+           "strict_identical_to_default": bool((res_s[0][0] == res[0][0]).all() and (res_s[0][1].view(np.uint32) == res[0][1].view(np.uint32)).all()),
+           "host_replays": st["host_replays"], "dense_fallbacks": st["dense_fallbacks"], "build_s": round(build_s, 1)}
     if parity:
         s32 = oracle_scores(O, codes, corr, dim, qq_all[warmup * Q], qc_all[warmup * Q], QB, SIM, cdp, IB)
         oi, osc = O.heap_topk(s32, k)
@@ -313,6 +343,58 @@ def napi_leg(B, ix, centroid, dim, k, sim_name, SIM, QB, nq=512):
         return {"error": str(e)[:300]}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def c1_leg():
+    """BASELINE config 1 (the reference's README bench: quickSearch over 1000 x 128-d, k = 10, COSINE; /root/reference/README.md:115-116 quotes
+    "~2 ms" per quickSearch on its CPU path): the same calls through the JavaScript drop-in API on this box (tests/js/bench_c1.js) - ms per
+    quickSearch (re-quantizes and re-uploads the 1000 targets every call, as src/index.ts:95-111 does) and per search on a pre-built
+    index; the top 10 must be the reference's."""
+    import shutil
+    import subprocess
+    if shutil.which("node") is None:
+        return {"error": "node not installed"}
+    if not os.path.exists(os.path.join(ROOT, "better-binary-quantization_amd", "lib", "bbq_napi.node")):
+        return {"error": "bbq_napi.node is not built"}
+    try:
+        r = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "bench_c1.js")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        if r.returncode != 0:
+            return {"error": ("node exited with %d: " % r.returncode) + r.stderr[-300:]}
+        js = json.loads(r.stdout.strip().splitlines()[-1])
+        js["reference_readme"] = "~2 ms per quickSearch, pure-TS CPU path (README.md:115-116); 25.7 ms / 0.53 ms measured for quickSearch / pre-built search in SURVEY 3.5"
+        js["what"] = "not a roofline case: 1000 rows are one launch chain; the call is bound by the host (quantizing 1000 targets per quickSearch) and launch latency"
+        return js
+    except Exception as e:  # informational leg
+        return {"error": str(e)[:300]}
+
+
+def shard_shape_leg(args, headline_qps):
+    """The 8-GPU shard shape on ONE GPU, driver-timed: rank 1 of 8 of the headline index (1.25 M x 768 rows + its 32 K-row pilot replica),
+    2048 queries per batch through ShardedSearcher with an RCCL process group of one rank - every per-rank cost of the --gpus 8 step
+    (sweep, packing, exchange with itself, merge, answers) except the other ranks' traffic.  A child process (the process group and the
+    sharded code path must not leak into this one)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--force-dist", "--shard-of", "1/8", "--batch", "2048", "--steps", str(max(args.steps // 4, 4)),
+           "--warmup", "2", "--rows", str(args.rows), "--dim", str(args.dim), "--k", str(args.k), "--no-recall", "--no-cpu-baseline", "--no-parity",
+           "--latency-calls", "0", "--shared-sweep", "0", "--no-configs", "--no-napi", "--no-raw", "--no-hbm-only", "--inprocess-shards", "0",
+           "--slots", str(args.slots), "--replay-threads", str(args.replay_threads)]
+    env = dict(os.environ, MASTER_PORT="29571", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+        if r.returncode != 0:
+            return {"error": ("child exited with %d: " % r.returncode) + r.stderr[-400:]}
+        c = json.loads(r.stdout.strip().splitlines()[-1])
+        ph = (c.get("sharded_phases") or {}).get("rank0")
+        return {"value_per_rank": c["value"], "unit": "queries/s", "ms_per_batch": c["ms_per_step"], "queries_per_batch": 2048,
+                "rows_of_the_shard": c["config"].get("shard_rows"), "pilot_rows": c["config"].get("pilot_rows"),
+                "phases_ms_per_batch": ph, "replayed_queries_per_batch": c.get("replayed_queries_per_batch"),
+                "identical_to_direct": c.get("identical_to_direct"), "frac_algorithmic_dominant_launch": c["roofline"].get("frac_algorithmic"),
+                "projected_8gpu": c["value"], "projected_8gpu_vs_n1_headline": c["value"] / headline_qps if headline_qps else None,
+                "what": "rank 1 of 8 of the 10 M-row index (its 1.25 M rows + the 32 K-row pilot replica), batches of 2048 queries through "
+                        "ShardedSearcher over RCCL with ONE rank; at --gpus 8 every rank does this per batch while the others do the same, so the "
+                        "job's rate is this rank's rate as long as the exchange (k + 3 words per query and pair of ranks) stays hidden"}
+    except Exception as e:  # informational leg
+        return {"error": str(e)[:300]}
 
 
 def inprocess_only(args):
@@ -471,6 +553,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1: nccl (= RCCL) or gloo (rehearsal)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the sharded code path (process group, collectives) even with one rank")
+    ap.add_argument("--shard-of", default=None, help=argparse.SUPPRESS)   # "r/w" with --force-dist: this process is rank r of w of the index (shard_shape_leg)
+    ap.add_argument("--no-shard-shape", action="store_true", help="skip the leg that times the 8-GPU shard shape on this GPU (a child process with an RCCL group of one rank)")
+    ap.add_argument("--no-c1", action="store_true", help="skip BASELINE config 1 through the JavaScript host (tests/js/bench_c1.js)")
     ap.add_argument("--no-configs", action="store_true", help="skip the short legs of BASELINE configs 2, 4 and 5 (default run on one GPU only)")
     ap.add_argument("--no-napi", action="store_true", help="skip the Node/N-API leg (the drop-in boundary driven from node at the timed size)")
     ap.add_argument("--no-hbm-only", action="store_true", help="skip the leg that repeats the timed step with nothing kept in the Infinity Cache")
@@ -553,10 +638,16 @@ def main():
 
     shard = (N + world - 1) // world
     r0, r1 = min(rank * shard, N), min((rank + 1) * shard, N)
+    emu = None
+    if args.shard_of:   # one rank of a larger world, alone in its process group (shard_shape_leg)
+        er, ew = [int(x) for x in args.shard_of.split("/")]
+        shard = (N + ew - 1) // ew
+        r0, r1 = min(er * shard, N), min((er + 1) * shard, N)
+        emu = (er, ew)
     t0 = time.perf_counter()
     codes, corr = rows_of(r0, r1)
     pilot = None
-    if rank > 0:
+    if rank > 0 or (emu and emu[0] > 0):
         P = min(args.pilot, r0) // 1024 * 1024
         if P > 0:
             pilot = rows_of(0, P)
@@ -634,6 +725,14 @@ def main():
         allf = [torch.zeros_like(fr) for _ in range(world)]
         dist.all_gather(allf, fr)
         sharded["frac_hipevent_per_rank"] = [round(float(x.item()), 4) for x in allf]
+        sharded["list_path_batches"] = searcher.list_batches
+        sharded["last_exchange"] = searcher.last_exchange
+    shard_direct = None
+    if dist is not None and args.shard_of:
+        # shard_shape_leg: the same shard handle answering the same batch through the plain batch call
+        dres = ix.search_batch(batches[args.warmup][0], batches[args.warmup][1], QB, SIM, k)
+        sres = results[args.warmup]
+        shard_direct = bool((dres[0] == sres[0]).all() and (dres[1].view(np.uint32) == sres[1].view(np.uint32)).all())
     batched = None
     if dist is None and args.shared_sweep in (4, 8, 32) and IB == 1:
         # API extension, reported separately: `shared_sweep` queries share one sweep of the index
@@ -652,14 +751,19 @@ def main():
         lms = stb["total_scan_ms"] / max(stb["total_scan_launches"], 1)
         bq = args.steps * Q / dtb
         stream_gbps = lb / (lms * 1e-3) / 1e9 if lms > 0 else None
-        # int8 MFMA work of the shared sweep: rows x dim x 2 ops per query (the popcount path is priced as the same contraction)
-        i8_peak = 5.0e15   # dense I8 = 2 x the 2.5 PFLOP/s bf16 figure of /opt/skills/guides/MI355X_MICROARCH.md
+        # matrix-core work of the shared sweep: rows x dim x 2 ops per query.  Query values <= 15 run as FP6 x FP4 on
+        # v_mfma_f32_32x32x64_f8f6f4 (dense peak ~10 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md), larger ones as int8 (~5 POP/s)
+        fp_form = args.shared_sweep == 32 and QB <= 4
+        mx_peak = 10.0e15 if fp_form else 5.0e15
         batched = {"queries_per_sweep": args.shared_sweep, "value": bq, "unit": "queries/s",
                    "roofline": {"frac_hbm": (stream_gbps / HBM_PEAK_GBS) if stream_gbps else None,
-                                "frac_i8_mfma": bq * N * dim * 2 / i8_peak if args.shared_sweep == 32 else None,
-                                "bound": "neither: dependent LDS -> MFMA -> pre-filter latencies per tile (profiles/, DESIGN.md 'Shared sweeps')",
-                                "index_stream_GBps": stream_gbps, "i8_peak_ops": i8_peak},
-                   "identical_to_unshared": same, "bound": "matrix cores + valu pre-filter (32 queries share each row load)" if args.shared_sweep == 32 else "valu (popcount + f64 bound per query; HBM bytes amortised over the sweep)",
+                                "frac_matrix_peak": bq * N * dim * 2 / mx_peak if args.shared_sweep == 32 else None,
+                                "matrix_form": ("FP6 x FP4 (v_mfma_f32_32x32x64_f8f6f4)" if fp_form else "int8 (v_mfma_i32_32x32x32_i8)") if args.shared_sweep == 32 else None,
+                                "bound": "vector issue next to the matrix cores: the instructions outside the contraction do not hide behind it "
+                                         "(profiles/r04_mfma_pmc.json, scripts/ubench/valu_mfma_overlap.hip, DESIGN.md 'Shared sweeps')",
+                                "index_stream_GBps": stream_gbps, "matrix_peak_ops": mx_peak,
+                                "bytes_per_row_of_the_sweep": (lb / max(stb["last_scan_rows"], 1) * args.shared_sweep) if stb.get("last_scan_rows") else None},
+                   "identical_to_unshared": same, "bound": "matrix cores + vector issue (32 queries share each row load)" if args.shared_sweep == 32 else "valu (popcount + f64 bound per query; HBM bytes amortised over the sweep)",
                    "index_stream_GBps": lb / (lms * 1e-3) / 1e9 if lms > 0 else None}
         ix.set_option("sweep_share", 1)
 
@@ -702,6 +806,7 @@ def main():
         hbm_only = {"value": args.steps * Q / dth, "unit": "queries/s", "ms_per_step": dth / args.steps * 1e3,
                     "end_to_end_hbm_frac": (args.steps * Q / dth) * N * bytes_per_row / 1e9 / HBM_PEAK_GBS,
                     "roofline_frac_dominant_launch": (lb / (lm * 1e-3) / 1e9 / HBM_PEAK_GBS) if lm > 0 else None,
+                    "dominant_launch_GBps": (lb / (lm * 1e-3) / 1e9) if lm > 0 else None, "dominant_launch_ms": lm,
                     "cache_resident_bytes": sth["resident_bytes"],
                     "identical_to_default": bool((res_h[0][0] == results[args.warmup][0]).all() and
                                                  (res_h[0][1].view(np.uint32) == results[args.warmup][1].view(np.uint32)).all()),
@@ -757,7 +862,7 @@ def main():
         achieved = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         # committed rocprofv3 evidence for THIS kernel and layout (profiles/dominant_kernel.json, scripts/summarize_profiles.py): the
         # PMC traffic per row and the kernel-trace average; anything measured on another layout / width is not quoted
-        traffic, traffic_src, frac_rocprof, rocprof_src = None, None, None, None
+        traffic, traffic_src, frac_rocprof, rocprof_src, frac_rocprof_strict, rocprof_src_strict = None, None, None, None, None, None
         try:
             reg = json.load(open(os.path.join(ROOT, "profiles", "dominant_kernel.json")))
             for e in reg["entries"]:
@@ -770,6 +875,10 @@ def main():
                         frac_rocprof = e["trace_avg_GBps"] / HBM_PEAK_GBS
                         rocprof_src = {"file": "profiles/dominant_kernel.json", "trace_avg_us": e["trace_avg_us"], "launches": e["trace_launches"],
                                        "bytes_per_launch": e["trace_bytes_per_launch"], "collected": e["collected"]}
+                    if e.get("strict_trace_avg_GBps") is not None:   # the same kernel traced with resident_mb 0
+                        frac_rocprof_strict = e["strict_trace_avg_GBps"] / HBM_PEAK_GBS
+                        rocprof_src_strict = {"file": "profiles/dominant_kernel.json", "trace_avg_us": e["strict_trace_avg_us"],
+                                              "launches": e["strict_trace_launches"], "collected": e["collected"]}
                     break
         except Exception:
             pass
@@ -784,22 +893,34 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%dx%d-dim %d-bit index, queryBits=%d, k=%d, %s, row-sharded over %d GPU(s)" % (N, dim, IB, QB, k, args.sim, world),
                        "queries_per_step": Q, "queries_per_launch": sub_batch, "sweeps_per_query": 1,
+                       "queries_per_step_rule": "256 at --gpus 1; min(2048, max(512, 256 x N)) at --gpus N: every rank sweeps 1/N of the rows per "
+                                                "query, so the step grows with N to keep a rank's sweep per step what it is on one GPU "
+                                                "(512 / 1024 / 2048 at 2 / 4 / 8 GPUs); each query still sweeps the whole index once",
                        "pipeline_slots": args.slots, "replay_threads": args.replay_threads, "bytes_per_row": bytes_per_row,
                        "parallelism": "row-shard x%d" % world},
-            # frac / frac_hipevent: this run, HIP events on the kernel's own stream; frac_rocprof_avg: the committed kernel-trace
-            # average of the same kernel on the same layout (a different box and run: the pool has faster and slower boxes)
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "frac_hipevent": achieved / HBM_PEAK_GBS, "frac_rocprof_avg": frac_rocprof, "rocprof_source": rocprof_src,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "bbq_scan_kernel (largest segment launch)",
-                         "bytes_per_launch": launch_bytes, "avg_launch_ms": launch_ms, "launches_timed": st["total_scan_launches"],
-                         "cache_resident_bytes_per_sweep": st["resident_bytes"],
-                         "cache_resident_frac_of_sweep": st["resident_bytes"] / float(max(1, (N // world) * bytes_per_row)), "note": RESIDENT_NOTE},
+            # frac: this run's strict HBM figure (hbm_only leg), HIP events on the kernel's own stream; frac_rocprof_avg(_strict): the
+            # committed kernel-trace averages of the same kernel on the same layout (a different box and run: the pool has faster and
+            # slower boxes; `collected` names the round)
+            "roofline": roofline_object(
+                (hbm_only or {}).get("dominant_launch_GBps"), achieved, st["resident_bytes"] / float(max(1, (N // world) * bytes_per_row)),
+                {"frac_hipevent_algorithmic": achieved / HBM_PEAK_GBS, "frac_rocprof_avg": frac_rocprof, "rocprof_source": rocprof_src,
+                 "frac_rocprof_avg_strict": frac_rocprof_strict, "rocprof_source_strict": rocprof_src_strict,
+                 "traffic": traffic, "traffic_source": traffic_src, "kernel": "bbq_scan_kernel (largest segment launch)",
+                 "bytes_per_launch": launch_bytes, "avg_launch_ms": launch_ms, "launches_timed": st["total_scan_launches"],
+                 "strict_avg_launch_ms": (hbm_only or {}).get("dominant_launch_ms"),
+                 "cache_resident_bytes_per_sweep": st["resident_bytes"]}),
             "ranks": dist.get_world_size() if dist is not None else 1, "backend": (dist.get_backend() if dist is not None else None),
-            "end_to_end_hbm_frac": (qps * (N / world) * bytes_per_row / 1e9) / HBM_PEAK_GBS,
+            "end_to_end_frac_algorithmic": (qps * (N / world) * bytes_per_row / 1e9) / HBM_PEAK_GBS,
+            "end_to_end_hbm_frac_strict": (hbm_only or {}).get("end_to_end_hbm_frac"),
             "candidates_per_query": st["candidates"] / float(Q) if dist is None else None,
             "dense_fallbacks": st["dense_fallbacks"],
         }
         out["argv"] = " ".join(sys.argv[1:])
+        out["config"]["shard_rows"] = r1 - r0
+        out["config"]["pilot_rows"] = 0 if pilot is None else int(pilot[0].shape[0])
+        if shard_direct is not None:
+            out["identical_to_direct"] = shard_direct
+            out["replayed_queries_per_batch"] = (searcher.last_exchange or {}).get("replayed_queries")
         if sharded is not None:
             out["sharded_phases"] = sharded
         if latency is not None:
@@ -869,7 +990,20 @@ def main():
                 except Exception as e:
                     legs[name] = {"error": str(e)[:300]}
                 log("config leg %s: %s" % (name, json.dumps(legs[name])[:400]))
+            if not args.no_c1:
+                legs["c1"] = c1_leg()
+                log("config leg c1: %s" % json.dumps(legs["c1"])[:400])
             out["configs"] = legs
+            notes = {n_: l_["parity_note"] for n_, l_ in legs.items() if isinstance(l_, dict) and "parity_note" in l_}
+            if notes:
+                out["parity_notes"] = notes   # what no fixture of the reference can pin (it throws there), said at the top level
+        if world == 1 and dist is None and headline and not args.no_shard_shape:
+            try:
+                ix.close()
+            except Exception:
+                pass
+            out["shard_shape_8gpu"] = shard_shape_leg(args, qps)
+            log("shard shape leg: %s" % json.dumps(out["shard_shape_8gpu"])[:500])
         if not args.no_recall and IB == 1:
             ix.close()   # the probe needs the memory (30.7 GB of fp32 at the headline size, twice on the device while the index is built)
             rec, desc = recall_probe(B, device, n=args.recall_rows if args.recall_rows > 0 else min(N, 10_000_000), dim=dim)

@@ -811,7 +811,11 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const 
       s.timed_rows = g.rows * nq;
       // a shared sweep reads each row once for `share` queries
       const int share = mfma_here ? 32 : (!g.dense && ix->opt_share > 1 && shared_sweep_supported(a, ix->opt_share)) ? ix->opt_share : 1;
-      s.timed_bytes = g.rows * ((nq + share - 1) / share) * (int64_t)ix->bytes_per_row;
+      // the matrix-core sweep reads the codes and the EXACT corrections (compact layout: 24 of the side array's 32 B per row instead of
+      // the tile's 4-byte word), once per 32 queries
+      const int64_t row_bytes = !mfma_here ? (int64_t)ix->bytes_per_row
+                                           : sto.view.layout == kLayoutCompact ? (int64_t)sto.view.w16 * 16 + 24 : (int64_t)sto.view.tile_stride / kTileRows;
+      s.timed_bytes = g.rows * ((nq + share - 1) / share) * row_bytes;
     }
     FinalizeArgs f{};
     f.counts = s.d_counts;
