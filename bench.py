@@ -324,11 +324,14 @@ def napi_leg(B, ix, centroid, dim, k, sim_name, SIM, QB, nq=512):
         raw.tofile(os.path.join(tmp, "queries.f32"))
         qq, qc = B.quantize_queries(raw, centroid, SIM, QB)
         gi, gs, gc = ix.search_batch(qq, qc, QB, SIM, k)
-        r = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "bench_scale.js"), prefix, os.path.join(tmp, "queries.f32"), str(dim), str(k),
+        node_cmd = ["node"] + (["--trace-gc"] if os.environ.get("BBQ_BENCH_TRACE_GC") else [])
+        r = subprocess.run(node_cmd + [os.path.join(ROOT, "tests", "js", "bench_scale.js"), prefix, os.path.join(tmp, "queries.f32"), str(dim), str(k),
                             sim_name, os.path.join(tmp, "answers.bin"), "10", "200"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         if r.returncode != 0:
             return {"error": ("node exited with %d: " % r.returncode) + r.stderr[-300:]}
         js = json.loads(r.stdout.strip().splitlines()[-1])
+        if os.environ.get("BBQ_BENCH_TRACE_GC"):
+            log("node --trace-gc:\n" + "\n".join(r.stdout.strip().splitlines()[-40:-1]))
         blob = np.fromfile(os.path.join(tmp, "answers.bin"), np.uint8)
         ji = blob[:nq * k * 4].view(np.int32).reshape(nq, k)
         jsx = blob[nq * k * 4:nq * k * 8].view(np.uint32).reshape(nq, k)
@@ -338,6 +341,7 @@ def napi_leg(B, ix, centroid, dim, k, sim_name, SIM, QB, nq=512):
                 "batch_ms_per_call": js["batch_ms_per_call"], "batch_ms_per_call_inside_addon": js.get("batch_ms_per_call_inside_addon"), "p50_ms": js["single_p50_ms"], "p99_ms": js["single_p99_ms"], "min_ms": js["single_min_ms"],
                 "single_call": "format.searchNearestNeighbors(raw fp32 query, values, k): normalise + quantize + sweep + top-k per call (src/binaryQuantizationFormat.ts:308-412)",
                 "single_queries_per_s": js["single_queries_per_s"], "single_equals_batch": js["single_equals_batch"], "identical_to_ctypes": same,
+                "single_slowest_calls": js.get("single_slowest_calls"),
                 "index": "loaded by the node process from the .veb/.vemb pair this process saved (%d rows)" % js["rows"], "load_ms": js["load_ms"], "node": js["node"]}
     except Exception as e:  # informational leg: never fail the bench for it
         return {"error": str(e)[:300]}

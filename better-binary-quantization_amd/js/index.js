@@ -434,7 +434,27 @@ class BinaryQuantizationFormat {
     if (k < 0) throw new Error('k值不能为负数');
     if (queryVector.length !== targetVectors.dimension()) throw new Error('查询向量维度与目标向量维度不匹配');
     if (k === 0) return [];
-    return this.searchNearestNeighborsBatch([queryVector], targetVectors, k)[0];
+    if (isMultiBit(targetVectors) || !native.searchRawInto) return this.searchNearestNeighborsBatch([queryVector], targetVectors, k)[0];
+    // the one-query call allocates nothing but its result: the query goes to the addon as it is (or through one staging array kept by
+    // this format when it is not a Float32Array), the answer comes back in two arrays kept per format
+    const dim = queryVector.length, q = this.quantizer;
+    let flat = queryVector;
+    if (!(queryVector instanceof Float32Array)) {
+      if (!this._stage || this._stage.length !== dim) this._stage = new Float32Array(dim);
+      flat = this._stage;
+      flat.set(queryVector);
+    }
+    if (!this._outIdx || this._outIdx.length < k) {
+      this._outIdx = new Int32Array(Math.max(k, 128));
+      this._outScore = new Float32Array(Math.max(k, 128));
+    }
+    const tNative = process.hrtime.bigint();
+    const n = native.searchRawInto(targetVectors._deviceIndex(), flat, targetVectors.getCentroid(), simOrdinal(q.similarityFunction), this.config.queryBits,
+      q.lambda, q.iters, k, this._outIdx, this._outScore);
+    hostClock.insideAddonNs += process.hrtime.bigint() - tNative;
+    const indices = this._outIdx, scores = this._outScore, res = new Array(n);
+    for (let j = 0; j < n; j++) res[j] = { index: indices[j], score: scores[j] };
+    return res;
   }
 
   /** extension (not in the reference): many queries per call, pipelined on the device; each query sweeps the index itself */

@@ -307,6 +307,34 @@ static napi_value SearchRawBatch(napi_env env, napi_callback_info info) {
   return o;
 }
 
+/* searchRawInto(handle, query Float32Array[dim] raw, centroid Float32Array[dim], sim, queryBits, lambda, iters, k, outIndices Int32Array[>= k],
+ *               outScores Float32Array[>= k]) -> count
+ * The reference's own call shape - ONE synchronous searchNearestNeighbors (src/binaryQuantizationFormat.ts:308-412) - without a typed
+ * array or an object created per call: the caller owns and reuses the output arrays.  (Every ArrayBuffer the batch form creates counts
+ * as external memory; their collection was the 0.8 ms tail of a 0.2 ms call.) */
+static napi_value SearchRawInto(napi_env env, napi_callback_info info) {
+  napi_value a[10];
+  if (!get_args(env, info, 10, a)) return NULL;
+  bbq_index *ix = unbox(env, a[0]);
+  if (!ix) return NULL;
+  void *q, *cen, *oi, *os; size_t ql, cl, il, sl;
+  int64_t sim, qb, iters, k; double lambda;
+  if (!get_typed(env, a[1], napi_float32_array, &q, &ql) || !get_typed(env, a[2], napi_float32_array, &cen, &cl) ||
+      !get_i64(env, a[3], &sim) || !get_i64(env, a[4], &qb) || !get_f64(env, a[5], &lambda) || !get_i64(env, a[6], &iters) ||
+      !get_i64(env, a[7], &k) || !get_typed(env, a[8], napi_int32_array, &oi, &il) || !get_typed(env, a[9], napi_float32_array, &os, &sl)) return NULL;
+  if (cl != (size_t)bbq_index_dimension(ix) || ql != cl) { napi_throw_error(env, "BBQ6", "查询向量维度与目标向量维度不匹配"); return NULL; }
+  if (k < 0) { napi_throw_error(env, "BBQ7", "k值不能为负数"); return NULL; }
+  int64_t keff = k < bbq_index_size(ix) ? k : bbq_index_size(ix);
+  if (il < (size_t)keff || sl < (size_t)keff) { napi_throw_error(env, NULL, "bbq_napi: output arrays shorter than k"); return NULL; }
+  int64_t cnt[2] = {0, 0};
+  int rc = bbq_search_raw_batch(ix, 1, (const float *)q, (const float *)cen, (int32_t)sim, (int32_t)qb, lambda, (int32_t)iters, 1, keff,
+                                (int32_t *)oi, (float *)os, cnt, NULL, NULL, NULL);
+  if (rc != BBQ_OK) return throw_bbq(env, rc);
+  napi_value n;
+  NAPI_CALL(env, napi_create_double(env, (double)cnt[0], &n));
+  return n;
+}
+
 /* scoreRows(handle, qquant, qcorr, queryBits, sim, rowBegin, rowCount) -> {qcDist Int32Array, score64 Float64Array, score32 Float32Array} */
 static napi_value ScoreRows(napi_env env, napi_callback_info info) {
   napi_value a[7];
@@ -594,6 +622,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"indexDestroy", NULL, IndexDestroy, NULL, NULL, NULL, napi_default, NULL},
       {"searchBatch", NULL, SearchBatch, NULL, NULL, NULL, napi_default, NULL},
       {"searchRawBatch", NULL, SearchRawBatch, NULL, NULL, NULL, napi_default, NULL},
+      {"searchRawInto", NULL, SearchRawInto, NULL, NULL, NULL, napi_default, NULL},
       {"scoreRows", NULL, ScoreRows, NULL, NULL, NULL, napi_default, NULL},
       {"setOption", NULL, SetOption, NULL, NULL, NULL, napi_default, NULL},
       {"stats", NULL, Stats, NULL, NULL, NULL, napi_default, NULL},

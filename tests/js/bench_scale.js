@@ -59,6 +59,7 @@ for (let i = 0; i < singleCalls; i++) {
   if (r.length !== res[q].length) sameAsBatch = false;
   for (let j = 0; j < r.length && sameAsBatch; j++) if (r[j].index !== res[q][j].index || r[j].score !== res[q][j].score) sameAsBatch = false;
 }
+const slowest = ms.map(function (v, i) { return { call: i, ms: v }; }).sort(function (a, b) { return b.ms - a.ms; }).slice(0, 5);
 ms.sort(function (a, b) { return a - b; });
 const stats = values.deviceStats();
 console.log(JSON.stringify({
@@ -66,6 +67,6 @@ console.log(JSON.stringify({
   batch_queries_per_s: nq * batchReps / batchS, batch_ms_per_call: batchS / batchReps * 1e3, batch_ms_per_call_inside_addon: Number(nativeNs) / 1e6 / batchReps,
   single_p50_ms: ms[ms.length >> 1], single_p99_ms: ms[Math.min(ms.length - 1, Math.floor(ms.length * 0.99))], single_min_ms: ms[0],
   single_queries_per_s: 1e3 / (ms.reduce(function (a, b) { return a + b; }, 0) / ms.length),
-  single_equals_batch: sameAsBatch, host_replays_last_call: stats.hostReplays,
+  single_equals_batch: sameAsBatch, host_replays_last_call: stats.hostReplays, single_slowest_calls: slowest,
 }));
 process.exit(0);   // the device copy goes with the process (dispose() would first fetch the rows back for vectorValue())

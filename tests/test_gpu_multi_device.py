@@ -152,8 +152,10 @@ def test_multi_device_rerank_recipe_and_errors():
         B.Vectors(base, device=99)
 
 
-def test_multi_device_full_size_10m():
-    """the headline size through the multi-device handle (4 shards on the one GPU): same answers as the single-device index"""
+@pytest.mark.parametrize("shards", [4, 8])
+def test_multi_device_full_size_10m(shards):
+    """the headline size through the multi-device handle (4 shards, and the 8 shards of the --gpus 8 target, all on the one GPU): same
+    answers as the single-device index"""
     import bench
     n, dim, k, pb = 10_000_000, 768, 100, 96
     codes, corr = bench.synth_rows(1, 0, n, pb)
@@ -166,9 +168,9 @@ def test_multi_device_full_size_10m():
     _, s101, _ = single.search_batch(qq, qc, 4, 1, k + 1)
     tied = sum(len(np.unique(s101[q].astype(np.float64))) != k + 1 for q in range(len(qq)))
     single.close()
-    ix = B.Index.create_multi(codes, corr, dim, cdp, [0, 0, 0, 0])
+    ix = B.Index.create_multi(codes, corr, dim, cdp, [0] * shards)
     try:
-        assert ix.shards == 4
+        assert ix.shards == shards
         ix.set_option("round_queries", 16)
         got = ix.search_batch(qq, qc, 4, 1, k)
         np.testing.assert_array_equal(got[0], want[0])
