@@ -1,5 +1,7 @@
 """Pins the CPU oracle (oracle/bbq_oracle.c) bit-for-bit against golden vectors produced by RUNNING the
 reference (type-erased TypeScript under Node 12, oracle/tools/gen_fixtures.js).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -198,3 +200,17 @@ def test_true_similarity_and_rerank_selectors(name):
             np.testing.assert_array_equal(cand[pos], O.dec(rec[how]["idx_i32"], np.int32))
             np.testing.assert_array_equal(b32(qsc[pos]), b32(O.dec(rec[how]["quantized_f32"], np.float32)))
             np.testing.assert_array_equal(b64(t[pos]), b64(O.dec(rec[how]["true_f64"], np.float64)))
+
+
+def test_cpu_baseline_js_crosscheck_fixture():
+    """the JS restatement that bench.py times as cpu_baseline_js was run next to the type-erased reference on the same host
+    (oracle/tools/crosscheck_js_baseline.js, build container only): their per-row costs lie in the same band"""
+    import json
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "api_cpu_baseline_crosscheck.json")))
+    assert len(d["runs"]) >= 2
+    ref = [x for r in d["runs"] for x in r["reference_passes_us_per_row"]]
+    mine = [x for r in d["runs"] for x in r["restatement_passes_us_per_row"]]
+    assert all(r["rows"] == 50000 and r["dim"] == 768 and r["k"] == 100 for r in d["runs"])
+    # the bands overlap and the medians over all passes agree within 35 % (both programs are bimodal under V8: see the fixture's note)
+    assert max(min(ref), min(mine)) <= min(max(ref), max(mine))
+    assert 0.65 <= sorted(mine)[len(mine) // 2] / sorted(ref)[len(ref) // 2] <= 1.35
