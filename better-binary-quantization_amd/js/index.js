@@ -224,19 +224,22 @@ class OptimizedScalarQuantizer {
     const total = transposeCache.hits + transposeCache.misses;
     return { size: 0, hitRate: total > 0 ? transposeCache.hits / total : 0 };
   }
-  /** packAsBinary, src/optimizedScalarQuantizer.ts:420-446 */
+  /**
+   * packAsBinary(vector, packed): dimension d -> byte d >> 3, bit 7 - (d & 7)  (the packing of src/optimizedScalarQuantizer.ts:420-446; same
+   * errors in the same order: a value other than 0 / 1 is reported before a destination that is too short for its byte)
+   */
   static packAsBinary(vector, packed) {
-    for (let i = 0; i < vector.length;) {
-      let result = 0;
-      for (let j = 7; j >= 0 && i < vector.length; j--) {
-        const v = vector[i];
+    const n = vector.length;
+    for (let byte = 0, d = 0; d < n; byte++) {
+      const stop = Math.min(d + 8, n);
+      let bits = 0;
+      for (let shift = 7; d < stop; d++, shift--) {
+        const v = vector[d];
         if (v !== 0 && v !== 1) throw new Error('1位量化值必须为0或1');
-        result |= (v & 1) << j;
-        i++;
+        bits |= v << shift;
       }
-      const index = Math.floor((i - 1) / 8);
-      if (index >= packed.length) throw new Error('打包数组长度不足');
-      packed[index] = result;
+      if (byte >= packed.length) throw new Error('打包数组长度不足');
+      packed[byte] = bits;
     }
   }
 }
@@ -330,34 +333,34 @@ class BinaryQuantizedScorer {
     return { difference: difference, relativeError: relativeError, correlation: correlation };
   }
 
-  /** computeQuantizationAccuracy(originalScores, quantizedScores) -> {meanError, maxError, minError, stdError, correlation (Pearson)}  (:524-617) */
+  /**
+   * computeQuantizationAccuracy(originalScores, quantizedScores) -> {meanError, maxError, minError, stdError, correlation}
+   * (what src/binaryQuantizedScorer.ts:524-617 reports; every sum runs left to right over the pairs, so the floats are the reference's).
+   * Pairs with an undefined member are skipped by the error statistics and by the sums of the correlation, whose n stays the array length.
+   */
   computeQuantizationAccuracy(originalScores, quantizedScores) {
-    if (originalScores.length !== quantizedScores.length) throw new Error('原始分数和量化分数数组长度不匹配');
-    const errors = [];
-    let sumError = 0, maxError = 0, minError = Infinity;
-    for (let i = 0; i < originalScores.length; i++) {
-      const orig = originalScores[i], quant = quantizedScores[i];
-      if (orig !== undefined && quant !== undefined) {
-        const error = Math.abs(orig - quant);
-        errors.push(error);
-        sumError += error;
-        maxError = Math.max(maxError, error);
-        minError = Math.min(minError, error);
-      }
-    }
-    const meanError = sumError / errors.length;
-    let sq = 0;
-    for (const e of errors) { const d = e - meanError; sq += d * d; }
-    const stdError = Math.sqrt(sq / errors.length);
     const n = originalScores.length;
-    let sumX = 0, sumY = 0, sumXY = 0, sumX2 = 0, sumY2 = 0;
-    for (let i = 0; i < n; i++) {
-      const xv = originalScores[i], yv = quantizedScores[i];
-      if (xv !== undefined && yv !== undefined) { sumX += xv; sumY += yv; sumXY += xv * yv; sumX2 += xv * xv; sumY2 += yv * yv; }
+    if (n !== quantizedScores.length) throw new Error('原始分数和量化分数数组长度不匹配');
+    const defined = [];
+    for (let i = 0; i < n; i++) if (originalScores[i] !== undefined && quantizedScores[i] !== undefined) defined.push(i);
+    const abs = defined.map(function (i) { return Math.abs(originalScores[i] - quantizedScores[i]); });
+    const total = abs.reduce(function (acc, e) { return acc + e; }, 0);
+    const meanError = total / abs.length;
+    const spread = abs.reduce(function (acc, e) { return acc + (e - meanError) * (e - meanError); }, 0);
+    // Pearson's r from the five running sums
+    const m = { x: 0, y: 0, xy: 0, xx: 0, yy: 0 };
+    for (const i of defined) {
+      const a = originalScores[i], b = quantizedScores[i];
+      m.x += a; m.y += b; m.xy += a * b; m.xx += a * a; m.yy += b * b;
     }
-    const numerator = n * sumXY - sumX * sumY;
-    const denominator = Math.sqrt((n * sumX2 - sumX * sumX) * (n * sumY2 - sumY * sumY));
-    return { meanError: meanError, maxError: maxError, minError: minError, stdError: stdError, correlation: denominator === 0 ? 0 : numerator / denominator };
+    const cov = n * m.xy - m.x * m.y, norm = Math.sqrt((n * m.xx - m.x * m.x) * (n * m.yy - m.y * m.y));
+    return {
+      meanError: meanError,
+      maxError: abs.reduce(function (acc, e) { return Math.max(acc, e); }, 0),
+      minError: abs.reduce(function (acc, e) { return Math.min(acc, e); }, Infinity),
+      stdError: Math.sqrt(spread / abs.length),
+      correlation: norm === 0 ? 0 : cov / norm,
+    };
   }
 
   getSimilarityFunction() { return this.similarityFunction; }
