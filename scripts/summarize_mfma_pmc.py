@@ -1,8 +1,8 @@
 """summary of scripts/profile_mfma.sh's output (kernel trace + two --pmc passes of the shared sweep on the matrix cores):
   python scripts/summarize_mfma_pmc.py gpurun_out/<dir> [profiles/rNN_mfma_pmc.json]
 The dominant launches are the bbq_scan_mfma_kernel launches with the largest grid; their tile count is taken from SQ_INSTS_MFMA
-(48 MFMAs per 64-row tile and 32 queries at 768-d: 2 row groups x dim / 32), so the summary does not depend on how many chunks a
-workgroup walks."""
+(30 MFMAs per 64-row tile and 32 queries at 768-d with 4-bit queries: 2 row groups x (12 of the contraction + 3 of the start values)),
+so the summary does not depend on how many chunks a workgroup walks."""
 import collections
 import csv
 import glob
@@ -17,7 +17,7 @@ for p in ("pmc1", "pmc2"):
     fs = glob.glob(os.path.join(d, p, "*", "*counter_collection.csv"))
     if not fs:
         continue
-    rows = [r for r in csv.DictReader(open(fs[0])) if "mfma" in r["Kernel_Name"]]
+    rows = [r for f in fs for r in csv.DictReader(open(f)) if "mfma" in r["Kernel_Name"]]   # (child processes of the run leave files of their own)
     g = max(int(r["Grid_Size"]) for r in rows)
     big = [r for r in rows if int(r["Grid_Size"]) == g]
     n = len({r["Dispatch_Id"] for r in big})
@@ -28,13 +28,14 @@ for p in ("pmc1", "pmc2"):
     out["grid_work_items"], out["launches_" + p] = g, n
     out["kernel"], out["vgpr_count_field"], out["lds_bytes"], out["scratch_bytes"] = big[0]["Kernel_Name"], int(big[0]["VGPR_Count"]), int(big[0]["LDS_Block_Size"]), int(big[0]["Scratch_Size"])
 fs = glob.glob(os.path.join(d, "trace", "*", "*kernel_trace.csv"))
-tr = [r for r in csv.DictReader(open(fs[0])) if "mfma" in r["Kernel_Name"]]
+tr = [r for f in fs for r in csv.DictReader(open(f)) if "mfma" in r["Kernel_Name"]]
 g = max(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) for r in tr)
 us = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr if int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) == g]
 out["trace_avg_us"], out["trace_launches"] = sum(us) / len(us), len(us)
 pl = out["per_launch"]
 dim = int(sys.argv[3]) if len(sys.argv) > 3 else 768
-tiles = pl["SQ_INSTS_MFMA"] / (2 * dim / 32)
+# MFMAs per 64-row tile and 32 queries: 2 row groups x (dim / 64 of the contraction in its FP6 x FP4 form + 3 of the start values)
+tiles = pl["SQ_INSTS_MFMA"] / (2 * (dim / 64 + 3))
 out["rows_per_launch"], out["tiles_per_launch"] = tiles * 64, tiles
 out["per_tile_and_wave"] = {k_: pl[k_] / tiles for k_ in ("SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU") if k_ in pl}
 simd_cycles = out["trace_avg_us"] * 1e-6 * 1024 * 2.1e9   # 1024 SIMDs at the ~2.1 GHz the chip holds under this load

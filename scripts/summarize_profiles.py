@@ -48,7 +48,7 @@ def main():
         "launches": len(us), "trace_avg_us": sum(us) / len(us), "trace_min_us": min(us), "trace_max_us": max(us),
         "algorithmic_bytes_per_launch": bpl,
         "trace_avg_GBps": bpl / (sum(us) / len(us) * 1e-6) / 1e9, "trace_min_us_GBps": bpl / (min(us) * 1e-6) / 1e9,
-        "hipEvent_avg_ms_same_profiled_run": roof["avg_launch_ms"], "hipEvent_GBps_same_profiled_run": roof["achieved"],
+        "hipEvent_avg_ms_same_profiled_run": roof["avg_launch_ms"], "hipEvent_GBps_same_profiled_run": roof.get("achieved_algorithmic", roof.get("achieved")),
     }
     entry = {"rows": None, "dim": None, "index_bits": None, "query_bits": None, "bytes_per_row": bench["config"]["bytes_per_row"], "kernel": dom[0]["Kernel_Name"],
              "collected": "%s, %s" % (rnd, tag), "trace_avg_us": out["trace_avg_us"], "trace_launches": len(us), "trace_bytes_per_launch": bpl,
@@ -81,6 +81,16 @@ def main():
     regp = os.path.join(ROOT, "profiles", "dominant_kernel.json")
     reg = json.load(open(regp)) if os.path.exists(regp) else {"entries": []}
     key = (entry["rows"], entry["dim"], entry["index_bits"], entry["query_bits"], entry["bytes_per_row"])
+    if tag.endswith("_strict"):
+        # the same launches traced with resident_mb 0 (nothing kept in the Infinity Cache): strict_* fields of the configuration's entry
+        out["resident_mb"] = 0
+        for e in reg["entries"]:
+            if (e.get("rows"), e["dim"], e["index_bits"], e["query_bits"], e["bytes_per_row"]) == key:
+                e["strict_trace_avg_us"], e["strict_trace_launches"], e["strict_trace_avg_GBps"] = out["trace_avg_us"], len(us), out["trace_avg_GBps"]
+                e["strict_collected"] = "%s, %s" % (rnd, tag)
+        json.dump(reg, open(regp, "w"), indent=1)
+        print(json.dumps(out, indent=1))
+        return
     reg["entries"] = [e for e in reg["entries"] if (e.get("rows"), e["dim"], e["index_bits"], e["query_bits"], e["bytes_per_row"]) != key] + [entry]
     json.dump(reg, open(regp, "w"), indent=1)
     print(json.dumps(out, indent=1))
