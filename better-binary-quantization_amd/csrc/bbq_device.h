@@ -226,6 +226,8 @@ constexpr int kFinalizeJobs = 4096;      // non-empty chunks one finalize launch
 constexpr int kFinalizeKeyCap = 12288;   // LDS key buffer of the finalize kernel (new keys + running top-k)
 constexpr int kFinalizeCountCap = 24576; // chunk counters one launch stages in LDS, 16 bits each (12.6 M rows per segment; longer segments read them from memory)
 constexpr int kFinalizeLdsBytes = (kFinalizeKeyCap + 3 * kFinalizeJobs + 512 + 16 + 16) * 4 + kFinalizeCountCap * 2;  // 146 KB of the CU's 160 KB
+// a finalize launch behind an appending or a dense sweep: keys, histogram, scratch and the 8 KB of the job table the final selection sorts in
+constexpr int kFinalizeLdsBytesSmall = (kFinalizeKeyCap + 512 + 16 + 16) * 4 + kFinalSelectMax * 8;
 
 __host__ __device__ inline uint32_t key_of_bits(uint32_t b) { return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 

@@ -391,14 +391,18 @@ __global__ __launch_bounds__(kChunkRows) void bbq_scan_shared_kernel(const ScanA
 // finalize: one workgroup (1024 threads) per query
 
 __global__ __launch_bounds__(kFinalizeThreads) void bbq_finalize_kernel(const FinalizeArgs a) {
-  // dynamic LDS (kFinalizeLdsBytes, above the 64 KB a kernel gets without asking): keys | copy jobs | histogram | scratch
+  // dynamic LDS: keys | histogram | scratch | copy jobs | chunk counters.  A launch that compacts chunk slots gets all of it
+  // (kFinalizeLdsBytes, 146 KB); a launch behind an appending or a dense sweep uses neither the counters nor, beyond the 8 KB the final
+  // selection sorts in, the job table, and is launched with kFinalizeLdsBytesSmall (58 KB): two of them fit a CU, and one fits beside a
+  // workgroup of another slot's matrix-core sweep (measured: the dispatcher still serves the running sweep's workgroups first, so
+  // the finalize launches of the other slots keep waiting for it - no gain there; launch_finalize)
   extern __shared__ __attribute__((aligned(16))) unsigned char fin_smem[];
   uint32_t *s_keys = reinterpret_cast<uint32_t *>(fin_smem);                      // [kFinalizeKeyCap]
-  uint32_t *s_jobs = s_keys + kFinalizeKeyCap;                                      // [3 * kFinalizeJobs] {chunk | redirect, list offset, source offset}
-  uint32_t *s_hist = s_jobs + 3 * kFinalizeJobs;                                    // [2][256]
+  uint32_t *s_hist = s_keys + kFinalizeKeyCap;                                      // [2][256]
   uint32_t *s_wave = s_hist + 512;                                                  // [16]
   uint32_t *s_misc = s_wave + 16;                                                   // [16]: 0..7 this kernel's, 8..15 the key selection's
-  uint16_t *s_counts = reinterpret_cast<uint16_t *>(s_misc + 16);                   // [kFinalizeCountCap] chunk counters of the launch, 16 bits each
+  uint32_t *s_jobs = s_misc + 16;                                                   // [3 * kFinalizeJobs] {chunk | redirect, list offset, source offset}
+  uint16_t *s_counts = reinterpret_cast<uint16_t *>(s_jobs + 3 * kFinalizeJobs);    // [kFinalizeCountCap] chunk counters of the launch, 16 bits each
   const int q = blockIdx.x;
   const int tid = threadIdx.x;
   uint32_t flags = 0;
@@ -971,7 +975,8 @@ hipError_t launch_finalize(const FinalizeArgs &a, int n_queries, hipStream_t s) 
   static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(bbq_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                kFinalizeLdsBytes);  // once per process: more than the 64 KB a launch gets by default
   if (attr != hipSuccess) return attr;
-  hipLaunchKernelGGL(bbq_finalize_kernel, dim3((unsigned)n_queries), dim3(kFinalizeThreads), kFinalizeLdsBytes, s, a);
+  const bool compacts = !(a.dense_rows > 0) && a.append_counts == nullptr;
+  hipLaunchKernelGGL(bbq_finalize_kernel, dim3((unsigned)n_queries), dim3(kFinalizeThreads), compacts ? kFinalizeLdsBytes : kFinalizeLdsBytesSmall, s, a);
   return hipGetLastError();
 }
 
