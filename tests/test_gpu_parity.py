@@ -376,6 +376,69 @@ def test_bound_filter_nonfinite_corrections_take_the_exact_path():
         ix.close()
 
 
+@pytest.mark.parametrize("sim", [0, 1, 2])
+@pytest.mark.parametrize("qb,dim", [(1, 128), (2, 768), (3, 128), (4, 768), (4, 1024), (7, 128), (4, 1536)])
+def test_matrix_core_sweep_hostile_rows_and_queries(sim, qb, dim):
+    """the shared sweep on the matrix cores (sweep_share 32: the threshold on the integer dot product as the MFMA's start value, FP6 x FP4
+    operands for query values <= 15, int8 above) on rows its threshold cannot bound - zero and NEGATIVE interval widths, widths lost in
+    f32, huge / tiny / non-finite corrections - and on queries it must refuse (zero width: the sub-batch sweeps on the vector ALUs):
+    every answer is the oracle's, for both corrections layouts, 70 queries per call (three groups, the last one partial)."""
+    rng = np.random.default_rng(1000 * sim + 10 * qb + dim)
+    n, k, nq = 60000, 50, 70
+    codes = rng.integers(0, 256, size=(n, dim // 8), dtype=np.uint8)
+    pop = np.unpackbits(codes, axis=1).sum(axis=1).astype(np.float64)
+    corr = np.zeros((n, 4))
+    corr[:, 0] = -0.04 * (0.9 + 0.2 * rng.random(n))
+    corr[:, 1] = 0.04 * (0.9 + 0.2 * rng.random(n))
+    corr[:, 2] = np.abs(rng.standard_normal(n)) * 1e-2 if sim == 0 else 1e-3 * rng.standard_normal(n)
+    hostile = rng.choice(n, 6000, replace=False)
+    scale = 10.0 ** rng.uniform(-6, 3, len(hostile))
+    corr[hostile, 0] = -scale * rng.uniform(0.1, 1.0, len(hostile))
+    corr[hostile, 1] = scale * rng.uniform(0.1, 1.0, len(hostile))
+    corr[hostile[:500], 1] = corr[hostile[:500], 0]                                   # zero width
+    corr[hostile[500:1000], 1] = corr[hostile[500:1000], 0] - 0.01                    # negative width
+    corr[hostile[1000:1500], 1] = corr[hostile[1000:1500], 0] * (1 - 2.0 ** -30)      # a width lost in f32
+    corr[hostile[1500:1600], 1] = 1e300                                               # overflows f32
+    corr[hostile[1600:1700], 2] = 3.0e38
+    corr[hostile[1700:1800], 0] = -1e-320                                             # f64 subnormal
+    corr[hostile[1800:2300], 2] = rng.standard_normal(500) * 1e4
+    corr[:, 3] = pop
+    cdp = 0.02
+    qq = rng.integers(0, 1 << qb, size=(nq, dim), dtype=np.uint8)
+    qc = np.empty((nq, 4))
+    qc[:, 0] = -0.15 * (0.9 + 0.2 * rng.random(nq))
+    qc[:, 1] = 0.148 * (0.9 + 0.2 * rng.random(nq))
+    qc[:, 2] = 0.7 * rng.random(nq) if sim == 0 else -0.0028 * rng.random(nq)
+    qc[:, 3] = qq.sum(axis=1)
+    qc[5, 3] *= 0.25                                                                  # a quantizedComponentSum that is not the sum of the values
+    want = []
+    for q in range(nq):
+        _, _, s32 = O.score_all(codes, corr, dim, qq[q], qc[q], qb, sim, cdp)
+        assert not np.isnan(s32).any()
+        want.append(O.heap_topk(s32, k))
+    for compact in (True, False):
+        ix = _make_index(codes, corr, dim, cdp, compact)
+        try:
+            ix.set_option("sweep_share", 32)
+            ix.set_option("first_segment_rows", 2048)
+            ix.set_option("segment_growth", 4)
+            idx, sc, cnt = ix.search_batch(qq, qc, qb, sim, k)
+            for q in range(nq):
+                np.testing.assert_array_equal(idx[q], want[q][0], err_msg="query %d compact %s" % (q, compact))
+                np.testing.assert_array_equal(canon32(sc[q]), canon32(want[q][1]))
+            # a query with zero interval width cannot be swept there (the threshold divides by it): same answers through the fallback
+            qz = qc.copy()
+            qz[3, 1] = qz[3, 0]
+            _, _, s32 = O.score_all(codes, corr, dim, qq[3], qz[3], qb, sim, cdp)
+            zi, zs = O.heap_topk(s32, k)
+            idx, sc, cnt = ix.search_batch(qq[:40], qz[:40], qb, sim, k)
+            np.testing.assert_array_equal(idx[3], zi)
+            np.testing.assert_array_equal(canon32(sc[3]), canon32(zs))
+            np.testing.assert_array_equal(idx[7], want[7][0])
+        finally:
+            ix.close()
+
+
 @pytest.mark.parametrize("name,shards,pilot", [("ties_cos_qb4", 3, 1024), ("big_20000x128_cos", 4, 2048), ("ties_euc_qb4", 2, 0),
                                                ("big_50000x768_cos", 5, 4096)])
 def test_sharded_scan_and_replay_single_process(name, shards, pilot):
