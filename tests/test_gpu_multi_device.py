@@ -411,3 +411,45 @@ def test_multi_device_save_load_roundtrip(tmp_path, name, shards, pilot):
             shutil.copy(prefix + ".s001" + ext, prefix + ".s000" + ext)
         with pytest.raises(B.BBQError):
             B.Index.load_multi(prefix, [0])
+
+
+@pytest.mark.gpu
+def test_shard_without_rows_leaves_empty_answer_blocks():
+    """a shard handle with no rows and no pilot replica (a rank beyond the end of a small index) launches nothing that would write its
+    answer blocks: they must come back as "nothing listed, no cut, no flags" - not as whatever the caller's buffer held - and merge
+    with the root shard's blocks into the reference's answers (advisor, round 3)"""
+    import torch
+    g, sim, base, queries, codes, corr, cen, cdp = _case("big_20000x128_cos")
+    n, dim, qb, k = g["n"], g["dim"], g["qb"], 10
+    root = B.Index(codes, corr, dim, cdp)
+    empty = B.Index(codes[:0], corr[:0], dim, cdp, row_base=n)
+    qs = [B.quantize_query(q, cen, sim, qb, g["lambda"], g["iters"]) for q in queries]
+    qq, qc = np.stack([a for a, _ in qs]), np.stack([b for _, b in qs])
+    nq, stride = len(qq), k + 3
+    try:
+        blocks = []
+        for ix in (root, empty):
+            cap = max(int(ix.shard_list_cap(k)), 1) * nq
+            packed = torch.zeros(cap, dtype=torch.int64, device="cuda")
+            off = torch.zeros(nq + 1, dtype=torch.int64, device="cuda")
+            flags = torch.zeros(nq, dtype=torch.int32, device="cuda")
+            ans = torch.full((nq * stride,), -1, dtype=torch.int64, device="cuda")      # garbage the scan has to overwrite
+            ix.shard_scan_begin(qq, qc, qb, sim, k, packed.data_ptr(), cap, off.data_ptr(), flags.data_ptr(), ans.data_ptr(), stride)
+            total = ix.shard_scan_wait()
+            blk = ans.cpu().numpy().view(np.uint64).reshape(nq, stride)
+            if ix is empty:
+                assert total == 0
+                assert (blk[:, :3] == 0).all(), "the empty shard's headers are not zero"
+                assert int(flags.cpu().numpy().sum()) == 0 and int(off.cpu().numpy()[nq]) == 0
+            blocks.append(blk)
+        idx, sc, cnt, status = B.merge_answers(blocks, nq, n, k)
+        for q in range(nq):
+            _, _, s32 = O.score_all(codes, corr, dim, qq[q], qc[q], qb, sim, cdp)
+            oi, osc = O.heap_topk(s32, k)
+            if status[q] == 0:
+                np.testing.assert_array_equal(idx[q], oi)
+                np.testing.assert_array_equal(canon32(sc[q]), canon32(osc))
+        assert (status == 0).sum() >= nq // 2      # (queries with equal scores in their answer ask for the lists: status 1)
+    finally:
+        root.close()
+        empty.close()
