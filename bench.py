@@ -230,6 +230,17 @@ RESIDENT_NOTE = ("frac / achieved = the dominant launch with resident_mb 0: noth
                  "+ WRITE_SIZE) counts the bytes that left the L2s; the Infinity Cache sits behind that counter")
 
 
+def flush_infinity_cache(torch):
+    """the strict runs stream with non-temporal loads, which neither allocate in the 256 MiB Infinity Cache nor displace what is there:
+    lines the default mode left resident would go on serving hits.  Two passes of ordinary writes and reads over 1 GiB evict them."""
+    buf = torch.empty(1 << 28, dtype=torch.float32, device="cuda")   # 1 GiB
+    for _ in range(2):
+        buf.fill_(1.0)
+        float(buf[::4096].sum().item())
+        torch.cuda.synchronize()
+    del buf
+
+
 def roofline_object(strict_gbps, algorithmic_gbps, resident_frac, extra):
     """the bench line's roofline object.  `frac` is ALWAYS an HBM fraction in the strict sense (resident_mb 0) or null when that leg was
     skipped; the default run's cache-assisted rate stands beside it under names that do not claim HBM.  An index that lives in the
@@ -273,6 +284,7 @@ def config_leg(B, torch, name, N, dim, k, QB, IB, sim_name, device, steps, warmu
     # the same step with nothing kept in the Infinity Cache (resident_mb 0): every byte of every sweep from HBM - the HBM roofline's figure
     ix.set_option("resident_mb", 0)
     strict_steps = max(2, steps // 2)
+    flush_infinity_cache(torch)
     time_steps(ix, batches[:1], QB, SIM, k)
     ix.reset_stats()
     torch.cuda.synchronize()
@@ -833,6 +845,8 @@ def main():
         # sharded run: the same batches with nothing kept in the Infinity Cache on any rank; the slowest rank's dominant launch is the
         # job's strict HBM figure (roofline.frac)
         ix.set_option("resident_mb", 0)
+        if args.backend == "nccl" or torch.cuda.is_available():
+            flush_infinity_cache(torch)
         run(batches[:1])
         ix.reset_stats()
         barrier()
@@ -857,6 +871,7 @@ def main():
         # the same timed step with NOTHING kept in the Infinity Cache (resident_mb 0: every byte of every sweep streamed from HBM with
         # non-temporal loads): the figure the HBM roofline in its strict sense applies to, next to the default above
         ix.set_option("resident_mb", 0)
+        flush_infinity_cache(torch)   # what the default mode left resident must not serve the strict run
         time_steps(ix, batches[:1], QB, SIM, k)
         ix.reset_stats()
         dth, res_h = time_steps(ix, batches[args.warmup:], QB, SIM, k)
@@ -870,7 +885,8 @@ def main():
                     "cache_resident_bytes": sth["resident_bytes"],
                     "identical_to_default": bool((res_h[0][0] == results[args.warmup][0]).all() and
                                                  (res_h[0][1].view(np.uint32) == results[args.warmup][1].view(np.uint32)).all()),
-                    "what": "library option resident_mb=0: no part of the index is kept in the Infinity Cache between sweeps"}
+                    "what": "library option resident_mb=0 after the Infinity Cache has been flushed (1 GiB written and read twice): no part of the index "
+                            "is kept in, or served by, the cache between sweeps"}
         ix.set_option("resident_mb", -1)
         time_steps(ix, batches[:1], QB, SIM, k)    # warm the cache again for the legs below
 
