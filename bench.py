@@ -283,9 +283,9 @@ def config_leg(B, torch, name, N, dim, k, QB, IB, sim_name, device, steps, warmu
     qps = steps * Q / dt
     # the same step with nothing kept in the Infinity Cache (resident_mb 0): every byte of every sweep from HBM - the HBM roofline's figure
     ix.set_option("resident_mb", 0)
-    strict_steps = max(2, steps // 2)
+    strict_steps = min(steps, max(4, steps // 2))
     flush_infinity_cache(torch)
-    time_steps(ix, batches[:1], QB, SIM, k)
+    time_steps(ix, batches[:2], QB, SIM, k)
     ix.reset_stats()
     torch.cuda.synchronize()
     dts, res_s = time_steps(ix, batches[warmup:warmup + strict_steps], QB, SIM, k)
