@@ -142,11 +142,13 @@ __device__ __forceinline__ double z_threshold(uint32_t theta_key, const QueryPar
 // so for lx > 0 and ly > 0 (beta = cs * ly):
 //     z > zth   <=>   qc > T = (zth / beta) * (1 / lx)  -  (ay / ly) * (rho * D + x1)  -  y1 * rho  -  (1 / beta) * (ca * add / lx),    rho = ax / lx.
 // Per query (prologue, f64 -> f32):  qk = -S * {zth / beta, ay / ly, y1, 1 / beta}.   Per row (f32):  rk = {1 / lx, -(rho * D + x1), -rho, -ca * add / lx}.
-// The accumulator starts at  K + qk . rk  with K = bias + slack, computed as four chained v_fma_f32 starting from K.
+// The accumulator starts at  qk . rk + K  with K = bias + slack: the four products summed first, K last (start_values()).
 //
 // Slack.  Let mag = S * sum_j max_q |q_j| * |r_j| (the row's magnitude budget, with |rho| * D + |x1| standing for |r_1|, plus
 // S * the largest possible qcDist so that every term of s is covered).
-//  * four v_fma_f32 whose results lie inside the binade (guaranteed by mag < mag_limit, else the row is "weird"): 4 * 0.5 ulp;
+//  * the sum: four fused multiply-adds at the grain of the products (each within 2^-24 of the partial sum: together below 2^-22 * mag)
+//    and ONE addition whose result lies inside the binade (guaranteed by mag < mag_limit, else the row is "weird"): 0.5 ulp.  The budget
+//    below would also cover four FMAs onto K, 4 * 0.5 ulp (tests/test_prefilter_math_cpu.py checks both orders);
 //  * the f32 images of the constants: q_j within 2^-24 (one rounding of an f64), 1 / lx within 2^-22 (v_rcp_f32 is good to 1 ulp, lx
 //    itself is rounded once), rho and add / lx within 2^-21.4, r_1 within 2^-21.3 of |rho| * D + |x1|: every product within 2^-21 of its
 //    magnitude, together below 2^-21 * mag;  the f64 evaluation of the reference score itself (~2^-50 of the same magnitudes) and

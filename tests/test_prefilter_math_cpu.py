@@ -1,8 +1,9 @@
-"""CPU: the pre-filter of the shared sweep on the matrix cores (bbq_mfma_kernels.hip: z_threshold, row_constants, acc_init - the
-threshold on the integer dot product that the accumulator is initialised with), restated in numpy with f32 arithmetic, must never
-reject a (row, query) pair whose exact f32 score beats the threshold - for all similarities, both query scalings (S = 8 for query
-values <= 15, S = 1 up to 127), ordinary and hostile magnitudes, a v_rcp_f32 that is off by an ulp either way, and a caller-supplied
-quantizedComponentSum that is NOT the sum of the query values (the slack must not depend on it being consistent)."""
+"""CPU: the pre-filter of the shared sweep on the matrix cores (bbq_mfma_kernels.hip: z_threshold, row_constants, start_values -
+the threshold on the integer dot product that the accumulator is initialised with), restated in numpy with f32 arithmetic, must
+never reject a (row, query) pair whose exact f32 score beats the threshold - for all similarities, both forms (FP6 x FP4 with
+products of q, q / 2 or q / 4 for query values <= 15; int8 up to 127), ordinary and hostile magnitudes, a v_rcp_f32 that is off by
+an ulp either way, either order of summing the start value's terms, and a caller-supplied quantizedComponentSum that is NOT the sum
+of the query values (the slack must not depend on it being consistent)."""
 import numpy as np
 import pytest
 
@@ -66,10 +67,12 @@ def fp_scale(max_q):
 
 
 
-def prefilter_pass(qcdist, lower, upper, add, x1, qc, cdp, dim, sim, one_bit, theta_score, qsum, form, rcp_ulps=0, max_q=15):
-    """bbq_mfma_kernels.hip: the prologue's per-query constants, row_constants(), acc_init() and the final compare, one query against
-    all rows.  rcp_ulps moves the reciprocal by that many ulps (v_rcp_f32 is good to one).  Returns (passes, ordinary rows, flagged):
-    flagged = the prologue hands the query to a sweep of its own (no usable threshold)."""
+def prefilter_pass(qcdist, lower, upper, add, x1, qc, cdp, dim, sim, one_bit, theta_score, qsum, form, rcp_ulps=0, max_q=15, start="mfma"):
+    """bbq_mfma_kernels.hip: the prologue's per-query constants, row_constants(), start_values() and the final compare, one query
+    against all rows.  rcp_ulps moves the reciprocal by that many ulps (v_rcp_f32 is good to one).  start: how the start value's terms
+    are summed - "mfma" as the kernel does (three v_mfma_f32_32x32x2_f32 on C = 0, an FMA per k, K x 1 last), "k_first" the other way
+    round (four FMAs onto K: every rounding at the binade's ulp) - the slack must cover both.  Returns (passes, ordinary rows,
+    flagged): flagged = the prologue hands the query to a sweep of its own (no usable threshold)."""
     N = FORMS[form]
     S, ulp, bias = (fp_scale(max_q) if form == "fp" else 1.0), F32(N["ulp"]), F32(N["bias"])
     with np.errstate(all="ignore"):
@@ -102,7 +105,10 @@ def prefilter_pass(qcdist, lower, upper, add, x1, qc, cdp, dim, sim, one_bit, th
         ok = (lxf > 0) & (mag < F32(N["mag_limit"]))
         K = np.where(ok, bias + ulp * np.ceil(fma32(mag, F32(9.5367431640625e-07) / ulp, F32(2.25))), F32(N["pass_all"])).astype(F32)
         r0, r1, r2, r3 = [np.where(ok, v, F32(0.0)).astype(F32) for v in (r0, r1, r2, r3)]
-        init = fma32(qk[0], r0, fma32(qk[1], r1, fma32(qk[2], r2, fma32(qk[3], r3, K))))
+        if start == "mfma":
+            init = fma32(F32(1.0), K, fma32(qk[3], r3, fma32(qk[2], r2, fma32(qk[1], r1, fma32(qk[0], r0, F32(0.0))))))
+        else:
+            init = fma32(qk[0], r0, fma32(qk[1], r1, fma32(qk[2], r2, fma32(qk[3], r3, K))))
         if form == "int8":     # the i32 accumulator: the start value's bits + qcDist
             final = init.view(np.int32).astype(np.int64) + qcdist.astype(np.int64)
             passed = final > np.int64(F32(bias).view(np.int32))
@@ -151,11 +157,11 @@ def test_prefilter_never_rejects_a_candidate(sim, qb, form):
         for quantile in (0.5, 0.99, 0.9999):
             theta_score = np.float32(np.quantile(s32[ok], quantile))
             wins = ok & (key_of(s32) > key_of(np.array([theta_score]))[0])
-            for ulps in (0, 1, -1):
+            for ulps, start in ((0, "mfma"), (1, "mfma"), (-1, "mfma"), (0, "k_first")):
                 passed, ordinary, flagged = prefilter_pass(d.astype(np.float64), corr[:, 0], corr[:, 1], corr[:, 2], pop, qc, cdp, dim, sim,
-                                                           one_bit, theta_score, qsum, form, ulps, int(qq.max()))
-                assert passed[wins].all(), "the pre-filter rejected %d winning pairs (flavour %d, quantile %g, rcp %+d ulp)" % (
-                    (~passed[wins]).sum(), flavour, quantile, ulps)
+                                                           one_bit, theta_score, qsum, form, ulps, int(qq.max()), start)
+                assert passed[wins].all(), "the pre-filter rejected %d winning pairs (flavour %d, quantile %g, rcp %+d ulp, %s)" % (
+                    (~passed[wins]).sum(), flavour, quantile, ulps, start)
             if flavour == 0:
                 assert ordinary.all() and not flagged   # no real row takes the pass-everything exit
                 if quantile == 0.9999:                  # and it is a filter (EUCLIDEAN rows with a negative denominator are beyond z-space: a few %)
