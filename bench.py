@@ -578,6 +578,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size oracle check of one timed query")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value")
+    ap.add_argument("--batched-sub-batch", type=int, default=0, help="queries per launch chain of the batched mode (0: the library's choice, 64 on the matrix cores)")
     ap.add_argument("--shared-sweep", type=int, default=32, help="also time the batched mode (queries per shared sweep; 0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1: nccl (= RCCL) or gloo (rehearsal)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
@@ -785,6 +786,11 @@ def main():
     if dist is None and args.shared_sweep in (4, 8, 32) and IB == 1:
         # API extension, reported separately: `shared_sweep` queries share one sweep of the index
         ix.set_option("sweep_share", args.shared_sweep)
+        # on the matrix cores a workgroup serves two groups of 32 queries per tile load: 64 queries per launch chain
+        # (the library's choice there, bbq_core.cpp effective_batch)
+        b_sub = min(Q, args.batched_sub_batch or 64) if args.shared_sweep == 32 else sub_batch
+        if args.batched_sub_batch > 0:
+            ix.set_option("batch_queries", min(Q, args.batched_sub_batch))
         res_b = ix.search_batch(batches[args.warmup][0], batches[args.warmup][1], QB, SIM, k)
         same = bool((res_b[0] == results[args.warmup][0]).all() and (res_b[1].view(np.uint32) == results[args.warmup][1].view(np.uint32)).all())
         ix.reset_stats()
@@ -813,7 +819,9 @@ def main():
                                 "bytes_per_row_of_the_sweep": (lb / max(stb["last_scan_rows"], 1) * args.shared_sweep) if stb.get("last_scan_rows") else None},
                    "identical_to_unshared": same, "bound": "matrix cores + vector issue (32 queries share each row load)" if args.shared_sweep == 32 else "valu (popcount + f64 bound per query; HBM bytes amortised over the sweep)",
                    "index_stream_GBps": lb / (lms * 1e-3) / 1e9 if lms > 0 else None}
+        batched["queries_per_launch"] = b_sub
         ix.set_option("sweep_share", 1)
+        ix.set_option("batch_queries", min(args.sub_batch, Q))
 
     raw = None
     if dist is None and not args.no_raw:

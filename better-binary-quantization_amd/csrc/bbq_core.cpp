@@ -273,6 +273,8 @@ int effective_batch(const bbq_index *ix, int64_t n_queries = 0) {
   const int64_t rows = ix->main.view.n_rows;
   int q = rows >= 6000000 ? 32 : rows >= 2500000 ? 64 : 128;
   while (n_queries > 0 && q > 32 && n_queries < 4 * (int64_t)q) q >>= 1;
+  // the sweep on the matrix cores serves two groups of 32 queries per tile load (bbq_mfma_kernels.hip): 64 queries per launch chain
+  if (ix->opt_share == 32 && q < 64 && (n_queries == 0 || n_queries > 32)) q = 64;
   return q;
 }
 
@@ -813,7 +815,7 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const 
       s.timed = true;
       s.timed_rows = g.rows * nq;
       // a shared sweep reads each row once for `share` queries
-      const int share = mfma_here ? 32 : (!g.dense && ix->opt_share > 1 && shared_sweep_supported(a, ix->opt_share)) ? ix->opt_share : 1;
+      const int share = mfma_here ? mfma_queries_per_tile_load(a, nq, mfma_fp) : (!g.dense && ix->opt_share > 1 && shared_sweep_supported(a, ix->opt_share)) ? ix->opt_share : 1;
       // the matrix-core sweep reads the codes and the EXACT corrections (compact layout: 24 of the side array's 32 B per row instead of
       // the tile's 4-byte word), once per 32 queries
       const int64_t row_bytes = !mfma_here ? (int64_t)ix->bytes_per_row

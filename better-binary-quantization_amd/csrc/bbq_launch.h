@@ -15,6 +15,7 @@ hipError_t launch_scan_shared(const ScanArgs &a, int planes, int share, int n_qu
 // query's interval width positive and finite
 bool mfma_sweep_supported(const ScanArgs &a);
 int64_t mfma_query_bytes_per_group(int w16, bool fp);  // staged operand bytes of 32 queries
+int mfma_queries_per_tile_load(const ScanArgs &a, int n_queries, bool fp);  // 32, or 64 where a workgroup serves two groups per tile
 hipError_t launch_scan_mfma(const ScanArgs &a, const uint8_t *qbytes, const float *qmax, float fp_scale, int n_queries, int n_chunks, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, int n_queries, hipStream_t s);
 // lists are [nq][list_stride]; a query may hold more than advertised_cap entries (a flood): such queries are only dropped

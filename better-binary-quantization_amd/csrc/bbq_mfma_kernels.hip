@@ -188,13 +188,18 @@ struct MfmaArgs {
                            // [W*2 steps][2 halves][32 queries][16 B] then [W*2][2][32][8 B]: the 32 FP6 values (24 B) of a lane and step
   const float *qmax;       // [groups][4]: S-free maxima over the group's queries: |ay / ly|, |y1|, 1 / (cs * ly), sum of the query's values
   int32_t nq_total;
-  int32_t chunks_per_block;  // consecutive chunks one workgroup walks with the same 32 queries (launch_mfma_t)
+  int32_t chunks_per_block;  // consecutive chunks one workgroup walks with the same queries (launch_mfma_t)
   float fp_scale;            // FP form: every product is fp_scale * q (1/4, 1/2 or 1: the largest the query values leave room for in e2m3)
+  int32_t groups_per_block;  // 1 or 2 groups of 32 queries per workgroup: a tile is loaded (and its row constants derived) once for all of them
+  int32_t stage_cap;         // candidates per query a workgroup stages in LDS (slot mode: the chunk slots' capacity)
+  int32_t queue_cap;         // survivors per wave, tile and group that wait for their exact scores
 };
 
 // Pairs that pass the pre-filter are pushed to a per-wave LDS queue (packed qc | row-in-tile << 20 | query << 26) and
 // scored exactly afterwards by ONE copy of the exact code, 64 pairs at a time.
-constexpr int kMfmaQueueCap = 512;
+constexpr int kMfmaQueueCap = 512;        // one group per workgroup
+constexpr int kMfmaQueueCapTwo = 128;     // two groups per workgroup (append mode only): LDS for two workgroups per CU
+constexpr int kMfmaStageCapTwo = 32;
 constexpr int kMfmaMaxChunksPerBlock = 16;
 
 template <int W, bool COMPACT>
@@ -271,8 +276,12 @@ __device__ __forceinline__ void fp_step(f32x16m &acc0, f32x16m &acc1, const u32x
 // bytes of one group's staged query operands
 __host__ __device__ constexpr int mfma_query_bytes(int w16, bool fp) { return fp ? w16 * 2 * 2 * 32 * 24 : w16 * 4 * 2 * 32 * 16; }
 
-// 4 waves per SIMD = 2 workgroups per CU (128 VGPRs) up to 1024-d; 1536-d rows hold 48 code registers: one workgroup per CU
-template <int W, bool COMPACT, bool FP>
+// 4 waves per SIMD = 2 workgroups per CU (128 VGPRs) up to 1024-d; 1536-d rows hold 48 code registers: one workgroup per CU.
+// A workgroup serves groups_per_block groups of 32 queries (grid y = pairs of groups): the tile's codes stay in registers and its row
+// constants are derived once, then each group runs its own contraction and test.  With ONE group per tile load the 10 M-row sweep reads
+// 120 B per row and 32 queries - 1.2 GB in ~175 us, within a few per cent of what the memory side delivers - so both bounds are met at
+// once; two groups halve the bytes, the popcounts, the conversions and the loads per query.
+template <int W, bool COMPACT, bool FP, int G>
 __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kernel(const MfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using N = MfmaNum<FP>;
@@ -283,26 +292,29 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
   constexpr int STEPS = FP ? WORDS / 2 : WORDS;                                      // k-steps of 64 (FP) or 32 dimensions
   constexpr int QBYTES = mfma_query_bytes(W, FP);
   const float S = FP ? a.fp_scale : 1.0f;                                            // accumulator units per qcDist unit
-  u32x4m *s_B = reinterpret_cast<u32x4m *>(smem);                                    // [STEPS*2][32] 16 B per lane and step ...
-  u32x2m *s_B2 = reinterpret_cast<u32x2m *>(smem + (size_t)STEPS * 2 * 32 * 16);     // ... FP: [STEPS*2][32] + 8 B (the rest of the 32 FP6 values)
-  f32x4m *s_qk = reinterpret_cast<f32x4m *>(smem + QBYTES);                          // [32] per-query constants -S * {zth/beta, ay/ly, y1, 1/beta}
-  f64x2m *s_lu = reinterpret_cast<f64x2m *>(s_qk + kMfmaQueries);                    // [NW][64] {lower, upper} of every tile row, for the survivors' exact scores ...
+  constexpr int gpb = G, nqb = gpb * kMfmaQueries;                                   // query slots of this workgroup (G = a.groups_per_block)
+  const int scap = a.stage_cap, qcap = a.queue_cap;
+  // per group: u32x4 [STEPS*2][32] 16 B per lane and step; FP: then u32x2 [STEPS*2][32], the rest of the lane's 32 FP6 values
+  f32x4m *s_qk = reinterpret_cast<f32x4m *>(smem + (size_t)gpb * QBYTES);            // [nqb] per-query constants -S * {zth/beta, ay/ly, y1, 1/beta}
+  f64x2m *s_lu = reinterpret_cast<f64x2m *>(s_qk + nqb);                             // [NW][64] {lower, upper} of every tile row, for the survivors' exact scores ...
   f64x2m *s_ax = s_lu + NW * 64;                                                     // [NW][64] ... and {additionalCorrection, component sum}: no trip to memory there
-  uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_ax + NW * 64);                  // [NW][kMfmaQueueCap]
-  uint32_t *s_qcount = s_queue + NW * kMfmaQueueCap;                                 // [NW] (+ padding to 16 B)
-  QueryParams *s_qp = reinterpret_cast<QueryParams *>(s_qcount + 8);                 // [32]
-  float *s_gmax = reinterpret_cast<float *>(s_qp + kMfmaQueries);                    // [8]: the group's magnitude maxima (row_constants)
-  uint32_t *s_theta = reinterpret_cast<uint32_t *>(s_gmax + 8);                      // [32]
-  uint32_t *s_cnt = s_theta + kMfmaQueries;                                          // [32]
-  uint64_t *s_ent = reinterpret_cast<uint64_t *>(s_cnt + kMfmaQueries);              // [32][cap]
+  uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_ax + NW * 64);                  // [NW][qcap]
+  uint32_t *s_qcount = s_queue + NW * qcap;                                          // [NW] (+ padding to 16 B)
+  QueryParams *s_qp = reinterpret_cast<QueryParams *>(s_qcount + 8);                 // [nqb]
+  float *s_gmax = reinterpret_cast<float *>(s_qp + nqb);                             // [8]: the workgroup's magnitude maxima (row_constants)
+  uint32_t *s_theta = reinterpret_cast<uint32_t *>(s_gmax + 8);                      // [nqb]
+  uint32_t *s_cnt = s_theta + nqb;                                                   // [nqb]
+  uint64_t *s_ent = reinterpret_cast<uint64_t *>(s_cnt + nqb);                       // [nqb][scap]
 
-  const int group = blockIdx.y;
-  const int q0 = group * kMfmaQueries;
-  const int nb = min(kMfmaQueries, a.nq_total - q0);
+  const int groups_total = (a.nq_total + kMfmaQueries - 1) / kMfmaQueries;
+  const int group0 = blockIdx.y * gpb;
+  const int ng = min(gpb, groups_total - group0);                                    // groups present here
+  const int q0 = group0 * kMfmaQueries;
+  const int nb = min(nqb, a.nq_total - q0);                                          // queries present here
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, h = lane >> 5;
   const int64_t n_tiles = (a.s.idx.n_rows + kTileRows - 1) / kTileRows;
-  // A workgroup is persistent over chunks_per_block consecutive chunks of the same 32 queries: the query fragments and constants are
+  // A workgroup is persistent over chunks_per_block consecutive chunks of the same queries: the query fragments and constants are
   // staged once, and a wave's next tile is loaded while the current one is tested.  The first tile's loads are in flight during the
   // prologue.
   const int cpb = a.chunks_per_block;
@@ -316,7 +328,7 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
   if (wave == 0) {
     if (lane < 8) s_gmax[lane] = 0.0f;   // same wave as the atomicMax below: LDS operations of a wave execute in order
     if (lane < NW) s_qcount[lane] = 0;
-    if (lane < kMfmaQueries) {
+    if (lane < nqb) {
       QueryParams p{};
       uint32_t th = 0xFFFFFFFFu;
       f32x4m qk;
@@ -344,35 +356,29 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
       s_theta[lane] = th;
       s_cnt[lane] = 0;
       s_qk[lane] = qk;
-      if (lane == 0) {  // the host's maxima are S-free and rounded up
-        const float *__restrict__ gm = a.qmax + (size_t)group * 4;
-        s_gmax[1] = S * gm[0];
-        s_gmax[2] = S * gm[1];
-        s_gmax[3] = S * gm[2];
-        s_gmax[4] = S * gm[3];
+      if (lane == 0) {  // the host's maxima are S-free and rounded up; the workgroup's groups share one budget
+        float g1 = 0.0f, g2 = 0.0f, g3 = 0.0f, g4 = 0.0f;
+        for (int g = 0; g < ng; ++g) {
+          const float *__restrict__ gm = a.qmax + (size_t)(group0 + g) * 4;
+          g1 = fmaxf(g1, gm[0]); g2 = fmaxf(g2, gm[1]); g3 = fmaxf(g3, gm[2]); g4 = fmaxf(g4, gm[3]);
+        }
+        s_gmax[1] = S * g1;
+        s_gmax[2] = S * g2;
+        s_gmax[3] = S * g3;
+        s_gmax[4] = S * g4;
       }
     }
   } else {
-    const u32x4m *__restrict__ gb = reinterpret_cast<const u32x4m *>(a.qbytes + (size_t)group * QBYTES);
-    for (int i = tid - 64; i < QBYTES / 16; i += NT - 64) s_B[i] = gb[i];
+    const u32x4m *__restrict__ gb = reinterpret_cast<const u32x4m *>(a.qbytes + (size_t)group0 * QBYTES);
+    u32x4m *__restrict__ sb = reinterpret_cast<u32x4m *>(smem);
+    for (int i = tid - 64; i < ng * (QBYTES / 16); i += NT - 64) sb[i] = gb[i];
   }
   __syncthreads();
 
   const int sim = s_qp[0].sim;                  // uniform over the call
   const float Df = (float)a.s.idx.dim;
-  // A operands of the start-value contraction (start_values): query n's constants, k = 0 in the lower half-wave, k = 1 in the upper
-  float aq0, aq1, aq2;
-  {
-    const f32x4m qkm = s_qk[n];
-    aq0 = h ? qkm.y : qkm.x;
-    aq1 = h ? qkm.w : qkm.z;
-    aq2 = h ? 0.0f : 1.0f;
-  }
 #pragma unroll 1
   for (int ci = 0; ci < cpb; ++ci) {
-  // opaque zero, redefined every iteration: keeps the compiler from hoisting the query-fragment LDS reads out of the chunk loop
-  int lds_off;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(lds_off));
   const int lc = lc0 + ci;           // chunk index inside this launch
   if (lc >= a.s.n_chunks) break;     // block-uniform
   const int64_t chunk = a.s.chunk_begin + lc;
@@ -403,6 +409,27 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
     float rb[2][3];
 #pragma unroll
     for (int rg = 0; rg < 2; ++rg) { rb[rg][0] = __uint_as_float(b0[rg]); rb[rg][1] = __uint_as_float(b1[rg]); rb[rg][2] = __uint_as_float(b2[rg]); }
+    const int rows_here = (int)min((int64_t)kTileRows, a.s.idx.n_rows - tile * kTileRows);
+    uint32_t *__restrict__ queue = s_queue + (size_t)wave * qcap;
+    // (straight-line code over the groups: as a loop the tile's registers were carried around it and spilled.  A group that does not
+    // exist - the last workgroup row of an odd number of groups - is computed all the same: its queries' start values are -inf)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+    // opaque zero, redefined for every group of every tile: keeps the compiler from hoisting the query-fragment LDS reads out of the loops
+    int lds_off;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lds_off));
+    const int gq = g * kMfmaQueries;             // first query slot of this group
+    const int nbg = min(kMfmaQueries, nb - gq);  // its queries (<= 0: none)
+    const u32x4m *__restrict__ s_B = reinterpret_cast<const u32x4m *>(smem + (size_t)g * QBYTES);
+    const u32x2m *__restrict__ s_B2 = reinterpret_cast<const u32x2m *>(smem + (size_t)g * QBYTES + (size_t)STEPS * 2 * 32 * 16);
+    // A operands of the start-value contraction (start_values): query n's constants, k = 0 in the lower half-wave, k = 1 in the upper
+    float aq0, aq1, aq2;
+    {
+      const f32x4m qkm = s_qk[gq + n + lds_off];
+      aq0 = h ? qkm.y : qkm.x;
+      aq1 = h ? qkm.w : qkm.z;
+      aq2 = h ? 0.0f : 1.0f;
+    }
     Acc acc0 = start_values<FP>(aq0, aq1, aq2, rb[0][0], rb[0][1], rb[0][2]);
     Acc acc1 = start_values<FP>(aq0, aq1, aq2, rb[1][0], rb[1][1], rb[1][2]);
     // ---- the contraction: C[m = query][n = row of the group] += sum over the k-steps
@@ -415,12 +442,12 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
       fp_step<0, STEPS, W>(acc0, acc1, t.c, bq, bq2, addr16, addr8);
     } else {
 #pragma unroll
-      for (int g = 0; g < WORDS; ++g) {
-        const uint32_t w = (g & 3) == 0 ? t.c[g >> 2].x : (g & 3) == 1 ? t.c[g >> 2].y : (g & 3) == 2 ? t.c[g >> 2].z : t.c[g >> 2].w;
+      for (int w8 = 0; w8 < WORDS; ++w8) {
+        const uint32_t w = (w8 & 3) == 0 ? t.c[w8 >> 2].x : (w8 & 3) == 1 ? t.c[w8 >> 2].y : (w8 & 3) == 2 ? t.c[w8 >> 2].z : t.c[w8 >> 2].w;
         // swap(w, w >> 4): [0] = {row n's word | row n's word >> 4}, [1] = {row 32+n's word | row 32+n's word >> 4}: the lower half-wave
         // supplies the low nibble of every byte, the upper one the high nibble, of the row group's row n
         const auto sw = __builtin_amdgcn_permlane32_swap(w, w >> 4, false, false);
-        const u32x4m bq = s_B[(g * 2 + h) * 32 + n + lds_off];
+        const u32x4m bq = s_B[(w8 * 2 + h) * 32 + n + lds_off];
         i32x4m Q;
         Q.x = (int)bq.x; Q.y = (int)bq.y; Q.z = (int)bq.z; Q.w = (int)bq.w;
         i32x4m R0, R1;
@@ -430,8 +457,8 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
         acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Q, R1, acc1, 0, 0, 0);
       }
     }
-    // ---- the codes are consumed: the next tile of this wave slot goes into the same registers while this one is tested
-    {
+    // ---- the codes are consumed by the last group: the next tile of this wave slot goes into the same registers while this one is tested
+    if (g + 1 == G) {
       const int64_t tn = tile + kTilesPerChunk;
       if (ci + 1 < cpb && lc + 1 < a.s.n_chunks && tn < n_tiles) load_tile_regs<W, COMPACT>(t, a.s.idx, tn, lane);
     }
@@ -444,9 +471,7 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
 #pragma unroll
     for (int r = 0; r < 16; r += 2) mx = max(mx, max(abits(acc1[r]), abits(acc1[r + 1])));
     const bool any_lane = mx > (int)__float_as_uint(N::bias);
-    uint32_t *__restrict__ queue = s_queue + (size_t)wave * kMfmaQueueCap;
     if (__any(any_lane)) {
-      const int rows_here = (int)min((int64_t)kTileRows, a.s.idx.n_rows - tile * kTileRows);
       // survivors: take qcDist from the difference to the accumulator's start value, which is derived again (the same instructions on
       // the same operands: the same bits).  The operands pass through an empty asm so that the compiler cannot keep all 32 start values
       // alive across the contraction instead.
@@ -477,22 +502,22 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
           const bool above = abits(av) > (int)__float_as_uint(N::bias);
           if (__any(above)) {  // wave-uniform: most accumulators have no survivor in any lane
             const int m = (r & 3) + 8 * (r >> 2) + 4 * h2;
-            if (above && m < nb && rit < rows_here) {
+            if (above && m < nbg && rit < rows_here) {
               uint32_t qc;
               if constexpr (FP) qc = (uint32_t)((av - init[r]) * (1.0f / S));   // both on the 1/16 grid inside one binade: exact (S is a power of two)
               else qc = (uint32_t)(av - init[r]);
               const uint32_t slot = atomicAdd(&s_qcount[wave], 1u);
-              if (slot < (uint32_t)kMfmaQueueCap) queue[slot] = qc | ((uint32_t)rit << 20) | ((uint32_t)m << 26);
-              else atomicOr(a.s.flags + q0 + m, kFlagOverflow);  // more survivors than the queue holds: this query goes dense
+              if (slot < (uint32_t)qcap) queue[slot] = qc | ((uint32_t)rit << 20) | ((uint32_t)m << 26);
+              else atomicOr(a.s.flags + q0 + gq + m, kFlagOverflow);  // more survivors than the queue holds: this query goes dense
             }
           }
         }
       }
       // ---- exact scores of the survivors (same-wave LDS traffic: program order is enough)
-      const uint32_t n_pass = min(s_qcount[wave], (uint32_t)kMfmaQueueCap);
+      const uint32_t n_pass = min(s_qcount[wave], (uint32_t)qcap);
       for (uint32_t i = lane; i < n_pass; i += 64) {
         const uint32_t e = queue[i];
-        const int qc = (int)(e & 0xFFFFFu), rit = (int)((e >> 20) & 63u), qn = (int)(e >> 26);
+        const int qc = (int)(e & 0xFFFFFu), rit = (int)((e >> 20) & 63u), qn = gq + (int)(e >> 26);
         const QueryParams pq = s_qp[qn];
         const int64_t row = tile * kTileRows + rit;
         const f64x2m lu = s_lu[wave * 64 + rit], ax = s_ax[wave * 64 + rit];
@@ -507,7 +532,7 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
           // workgroup is done - one atomic per query and workgroup reserves the room (an atomic that returns a value is a trip to the
           // memory side: per survivor it cost the early segments, where a few per cent of the pairs survive, more than the sweep itself)
           const uint32_t slot = atomicAdd(&s_cnt[qn], 1u);
-          if (slot < (uint32_t)a.s.cap) s_ent[(size_t)qn * a.s.cap + slot] = ent;
+          if (slot < (uint32_t)scap) s_ent[(size_t)qn * scap + slot] = ent;
           else if (a.s.append_lists) {  // the staging list is full: straight into the query's list
             const uint32_t gs = atomicAdd(a.s.append_counts + (size_t)(q0 + qn) * kAppendStride, 1u);
             const int64_t at = (int64_t)a.s.append_base[2 * (q0 + qn)] + gs;
@@ -516,18 +541,19 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
           }
         }
       }
-      if (a.s.append_lists) s_qcount[wave] = 0;  // this wave's queue is its own: ready for its next tile
+      s_qcount[wave] = 0;  // this wave's queue is its own: ready for its next group or tile
     }
+    }  // groups of this workgroup
   }
   if (a.s.append_lists) continue;  // workgroup-uniform: nothing to flush per chunk, nobody to wait for
   __syncthreads();
   for (int b = wave; b < nb; b += NW) {  // each wave writes the lists of its share of the queries
     uint32_t cnt = s_cnt[b];
-    if (cnt > (uint32_t)a.s.cap) {
+    if (cnt > (uint32_t)scap) {
       if (lane == 0) atomicOr(a.s.flags + q0 + b, kFlagOverflow);
-      cnt = (uint32_t)a.s.cap;
+      cnt = (uint32_t)scap;
     }
-    const uint64_t *__restrict__ src = s_ent + (size_t)b * a.s.cap;
+    const uint64_t *__restrict__ src = s_ent + (size_t)b * scap;
     uint64_t *__restrict__ out = a.s.entries + ((size_t)(q0 + b) * a.s.n_chunks + lc) * (size_t)a.s.cap;
     for (uint32_t i = lane; i < cnt; i += 64) {
       const uint64_t e = src[i];
@@ -538,21 +564,20 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
     if (lane == 0) a.s.counts[(size_t)(q0 + b) * a.s.n_chunks + lc] = cnt;
   }
   __syncthreads();                       // everybody has read the counters of this chunk ...
-  if (tid < kMfmaQueries) s_cnt[tid] = 0;
-  if (tid < NW) s_qcount[tid] = 0;
+  if (tid < nqb) s_cnt[tid] = 0;
   __syncthreads();                       // ... and sees them cleared before the next chunk's survivors arrive
   }  // chunks of this workgroup
   if (a.s.append_lists) {  // append mode: the workgroup's staged candidates go to the queries' lists (unordered inside the segment; the
                            // finalize launch takes its keys from there and the rare host replay sorts)
     __syncthreads();
     for (int b = wave; b < nb; b += NW) {
-      const uint32_t cnt = min(s_cnt[b], (uint32_t)a.s.cap);
+      const uint32_t cnt = min(s_cnt[b], (uint32_t)scap);
       if (cnt == 0) continue;  // wave-uniform
       uint32_t base = 0;
       if (lane == 0) base = atomicAdd(a.s.append_counts + (size_t)(q0 + b) * kAppendStride, cnt);
       base = __builtin_amdgcn_readfirstlane(base);
       const int64_t at0 = (int64_t)a.s.append_base[2 * (q0 + b)] + base;
-      const uint64_t *__restrict__ src = s_ent + (size_t)b * a.s.cap;
+      const uint64_t *__restrict__ src = s_ent + (size_t)b * scap;
       uint64_t *__restrict__ out = a.s.append_lists + (size_t)(q0 + b) * a.s.append_cap;
       for (uint32_t i = lane; i < cnt; i += 64) {
         if (at0 + i < a.s.append_cap) out[at0 + i] = src[i];
@@ -564,26 +589,48 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
 
 // ---------------------------------------------------------------------------------------------------------------------
 
-static size_t mfma_smem_bytes(int w16, int cap, bool fp) {
+static size_t mfma_smem_bytes(int w16, int stage_cap, bool fp, int gpb, int queue_cap) {
   constexpr int NW = kChunkRows / 64;
-  return (size_t)mfma_query_bytes(w16, fp) + (size_t)kMfmaQueries * 16 + (size_t)NW * 64 * 32 + (size_t)NW * kMfmaQueueCap * 4 + 32 +
-         kMfmaQueries * (sizeof(QueryParams) + 4 + 4) + 32 + (size_t)kMfmaQueries * (size_t)cap * 8 + 64;
+  const size_t nqb = (size_t)gpb * kMfmaQueries;
+  return (size_t)gpb * mfma_query_bytes(w16, fp) + nqb * 16 + (size_t)NW * 64 * 32 + (size_t)NW * queue_cap * 4 + 32 +
+         nqb * (sizeof(QueryParams) + 4 + 4) + 32 + nqb * (size_t)stage_cap * 8 + 64;
+}
+
+// Two groups per workgroup where the staging fits the CU as before (two workgroups per CU up to 1024-d, one beyond) - in append mode
+// only, where the staged lists may be shorter than the chunk slots (a full list overflows into the query's list in memory)
+// (the int8 form up to 1024-d stays at one group: with two its fragment reads are scheduled across the groups and spill)
+constexpr bool mfma_two_groups_built(int w16, bool fp) { return fp || w16 > 8; }
+static int mfma_groups_per_block(const ScanArgs &a, int groups, bool fp) {
+  if (groups < 2 || !a.append_lists || !mfma_two_groups_built(a.idx.w16, fp)) return 1;
+  // the chunk slots' capacity says how many candidates the plan expects here (cap_for: lam + 8 sqrt(lam) + 16 for lam candidates per
+  // chunk and query): up to 64 slots a tile and group has 4 lam <= 62 survivors on average, eight standard deviations below the queue
+  if (a.cap > 64) return 1;
+  const size_t two = mfma_smem_bytes(a.idx.w16, std::min<int>(a.cap, kMfmaStageCapTwo), fp, 2, kMfmaQueueCapTwo);
+  const size_t lds_alloc = (two + 1279) / 1280 * 1280;  // LDS is handed out in 1280-byte blocks
+  return (a.idx.w16 <= 8 ? 2 * lds_alloc <= 160 * 1024 : two <= 150 * 1024) ? 2 : 1;
 }
 
 template <int W, bool COMPACT, bool FP>
 static hipError_t launch_mfma_t(MfmaArgs a, int nq, int nc, hipStream_t s) {
-  const size_t smem = mfma_smem_bytes(W, a.s.cap, FP);
-  // The chip holds 512 of these workgroups at a time (2 per CU) and a workgroup's prologue (staging the queries: 18 KB at 768-d, the
-  // constants) costs about one chunk's worth of time.  Up to 12 chunks per workgroup: ONE round of workgroups, everything resident at
-  // once.  Longer sweeps: about sqrt(2 x prologue x chunks / slots) chunks each, where the prologues and the idle tail of the last
-  // workgroups cost the same.
   const int groups = (nq + kMfmaQueries - 1) / kMfmaQueries;
-  const int64_t units = (int64_t)nc * groups;
+  a.groups_per_block = mfma_groups_per_block(a.s, groups, FP);
+  a.stage_cap = a.groups_per_block == 2 ? std::min<int>(a.s.cap, kMfmaStageCapTwo) : a.s.cap;
+  a.queue_cap = a.groups_per_block == 2 ? kMfmaQueueCapTwo : kMfmaQueueCap;
+  const size_t smem = mfma_smem_bytes(W, a.stage_cap, FP, a.groups_per_block, a.queue_cap);
+  // The chip holds 512 of these workgroups at a time (2 per CU) and a workgroup's prologue (staging the queries: 18 KB per group at
+  // 768-d, the constants) costs about one chunk's worth of time.  Up to 12 chunks per workgroup: ONE round of workgroups, everything
+  // resident at once.  Longer sweeps: about sqrt(2 x prologue x chunks / slots) chunks each, where the prologues and the idle tail of
+  // the last workgroups cost the same.
+  const int grid_y = (groups + a.groups_per_block - 1) / a.groups_per_block;
+  const int64_t units = (int64_t)nc * grid_y;
   int64_t cpb = (units + 511) / 512;
   if (cpb > 12) cpb = std::min<int64_t>(kMfmaMaxChunksPerBlock, std::max<int64_t>(4, (int64_t)llround(sqrt((double)units / 220.0))));
   a.chunks_per_block = (int)cpb;
-  dim3 grid((unsigned)((nc + a.chunks_per_block - 1) / a.chunks_per_block), (unsigned)groups, 1), block(kChunkRows, 1, 1);
-  auto kern = bbq_scan_mfma_kernel<W, COMPACT, FP>;
+  dim3 grid((unsigned)((nc + a.chunks_per_block - 1) / a.chunks_per_block), (unsigned)grid_y, 1), block(kChunkRows, 1, 1);
+  auto kern = bbq_scan_mfma_kernel<W, COMPACT, FP, 1>;
+  if constexpr (mfma_two_groups_built(W, FP)) {
+    if (a.groups_per_block == 2) kern = bbq_scan_mfma_kernel<W, COMPACT, FP, 2>;
+  }
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
@@ -601,15 +648,19 @@ static hipError_t launch_mfma_w(const MfmaArgs &a, bool compact, bool fp, int nq
 bool mfma_sweep_supported(const ScanArgs &a) {
   const int w = a.idx.w16;
   if (a.idx.store_bits != 1 || !(w == 1 || w == 6 || w == 8 || w == 12)) return false;
-  return mfma_smem_bytes(w, a.cap, false) <= 150 * 1024;
+  return mfma_smem_bytes(w, a.cap, false, 1, kMfmaQueueCap) <= 150 * 1024;
 }
 
 int64_t mfma_query_bytes_per_group(int w16, bool fp) { return mfma_query_bytes(w16, fp); }
 
+int mfma_queries_per_tile_load(const ScanArgs &a, int n_queries, bool fp) {
+  return kMfmaQueries * mfma_groups_per_block(a, (n_queries + kMfmaQueries - 1) / kMfmaQueries, fp);
+}
+
 hipError_t launch_scan_mfma(const ScanArgs &sa, const uint8_t *qbytes, const float *qmax, float fp_scale, int n_queries, int n_chunks, hipStream_t s) {
   if (n_chunks <= 0 || n_queries <= 0) return hipSuccess;
   const bool fp = fp_scale > 0.0f;
-  MfmaArgs a{sa, qbytes, qmax, n_queries, 1, fp_scale};
+  MfmaArgs a{sa, qbytes, qmax, n_queries, 1, fp_scale, 1, sa.cap, kMfmaQueueCap};
   const bool compact = sa.idx.layout == kLayoutCompact;
   switch (sa.idx.w16) {
     case 1: return launch_mfma_w<1>(a, compact, fp, n_queries, n_chunks, s);
