@@ -574,31 +574,40 @@ void fill_query_mfma(const bbq_index *ix, uint8_t *dst, int q_in_batch, const ui
 // value carries 1/2, 1/4, 1/8, 1/2 against it: every product is q / 4 (q / 2 or q for smaller query values, see below).  e2m3 holds q / 2, q / 4 and q / 8 exactly for q <= 15
 // (exponent 0: m / 8; exponent e: (1 + m / 8) 2^(e-1)).  A lane's 32 six-bit codes are 24 bytes: the first 16 in [g][h][n][16 B],
 // the last 8 in [g][h][n][8 B] behind all of them (two aligned LDS reads per lane and step).
+static uint32_t fp6_code_of_eighths(int eighths) {
+  if (eighths < 8) return (uint32_t)eighths;                   // exponent field 0: m / 8
+  int e = 1;
+  while (eighths >= (8 << e)) ++e;                             // 2^(e-1) <= value < 2^e
+  return ((uint32_t)e << 3) | (uint32_t)((eighths >> (e - 1)) - 8);   // exact: the low e - 1 bits of eighths are zero for q <= 15
+}
+
 void fill_query_mfma_fp(const bbq_index *ix, uint8_t *dst, int q_in_batch, const uint8_t *q, int scale8) {
   const int steps = ix->w16 * 2, group = q_in_batch / 32, n = q_in_batch % 32;
   uint8_t *gb = dst + (size_t)group * mfma_query_bytes_per_group(ix->w16, true);
   uint8_t *gb2 = gb + (size_t)steps * 2 * 32 * 16;
+  // the value x 8: q/2, q/4, q/8, q/2 at scale8 = 2 (products q/4: values up to 15); twice that for values up to 7 (scale8 = 4,
+  // products q/2), four times for values up to 3 (scale8 = 8, products q): the finest grain e2m3's range (7.5) allows
+  uint8_t lut[4][16];
+  for (int cls = 0; cls < 4; ++cls)
+    for (int v = 0; v < 16; ++v) lut[cls][v] = (uint8_t)fp6_code_of_eighths(v * (cls == 1 ? 2 : cls == 2 ? 1 : 4) * (scale8 / 2));
+  // element i = 8 cls + j of a lane is bit p = 4 j + cls of its word: row byte j >> 1, bit 4 (j & 1) + cls, i.e. dimension
+  // 8 (j >> 1) + 7 - 4 (j & 1) - cls of the word's 32.  The eight six-bit codes of a class are 48 bits: bytes [6 cls, 6 cls + 6)
+  static const int off[8] = {7, 3, 15, 11, 23, 19, 31, 27};
   for (int g = 0; g < steps; ++g)
     for (int h = 0; h < 2; ++h) {
+      const int base = 32 * (2 * g + h);
       uint8_t bits[24];
-      memset(bits, 0, sizeof bits);
-      for (int i = 0; i < 32; ++i) {
-        const int p = 4 * (i & 7) + (i >> 3);
-        const int d = 32 * (2 * g + h) + 8 * (p >> 3) + 7 - (p & 7);
-        const int v = d < ix->dim ? q[d] : 0;                        // 0..15
-        // the value x 8: q/2, q/4, q/8, q/2 at scale8 = 2 (products q/4: values up to 15); twice that for values up to 7 (scale8 = 4,
-        // products q/2), four times for values up to 3 (scale8 = 8, products q): the finest grain e2m3's range (7.5) allows
-        const int eighths = v * ((i >> 3) == 1 ? 2 : (i >> 3) == 2 ? 1 : 4) * (scale8 / 2);
-        uint32_t code;
-        if (eighths < 8) code = (uint32_t)eighths;                   // exponent field 0: m / 8
-        else {
-          int e = 1;
-          while (eighths >= (8 << e)) ++e;                           // 2^(e-1) <= value < 2^e
-          code = ((uint32_t)e << 3) | (uint32_t)((eighths >> (e - 1)) - 8);   // exact: the low e - 1 bits of eighths are zero for q <= 15
+      for (int cls = 0; cls < 4; ++cls) {
+        uint64_t v48 = 0;
+        if (base + 32 <= ix->dim) {
+          for (int j = 0; j < 8; ++j) v48 |= (uint64_t)lut[cls][q[base + off[j] - cls] & 15] << (6 * j);
+        } else {
+          for (int j = 0; j < 8; ++j) {
+            const int d = base + off[j] - cls;
+            v48 |= (uint64_t)lut[cls][d < ix->dim ? (q[d] & 15) : 0] << (6 * j);
+          }
         }
-        const int at = 6 * i;
-        bits[at >> 3] |= (uint8_t)(code << (at & 7));
-        if ((at & 7) > 2) bits[(at >> 3) + 1] |= (uint8_t)(code >> (8 - (at & 7)));
+        for (int b = 0; b < 6; ++b) bits[6 * cls + b] = (uint8_t)(v48 >> (8 * b));
       }
       memcpy(gb + (((size_t)g * 2 + h) * 32 + n) * 16, bits, 16);
       memcpy(gb2 + (((size_t)g * 2 + h) * 32 + n) * 8, bits + 16, 8);
@@ -705,8 +714,11 @@ struct ExtOut {
   int64_t answers_stride = 0;
 };
 
+static double g_t_fill = 0, g_t_launch = 0, g_t_reclaim = 0, g_t_poll = 0;  // TEMP host trace
+static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const ExtOut *ext) {
   bbq_index *ix = c.ix;
+  const double t_a = now_us();
   uint64_t *d_lists_ext = ext ? ext->lists : nullptr;
   const int64_t list_cap_ext = ext ? ext->list_cap : 0;
   int32_t *d_counts_ext = ext ? ext->counts : nullptr;
@@ -748,6 +760,9 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const 
     }
   }
   hipStream_t st = s.stream;
+  const double t_b = now_us();
+  g_t_fill += t_b - t_a;
+  struct TL { double t0; ~TL() { g_t_launch += now_us() - t0; } } tl{t_b};
   HIPCHK(hipMemcpyAsync(s.d_block, s.h_block, (size_t)s.ctrl_bytes + bytes, hipMemcpyHostToDevice, st));  // control words := 0, queries
   s.ctrl_clean = false;
   uint64_t *d_lists = d_lists_ext ? d_lists_ext : s.d_lists;
@@ -1570,7 +1585,9 @@ static int search_batch_impl(bbq_index *ix, int32_t n_queries, const uint8_t *qq
   };
   for (int64_t i = 0; i < nsub; ++i) {
     Slot &s = ix->slots[i % nslots];
+    const double t_r = now_us();
     rc = reclaim_slot(c, s, out_idx, out_score, out_n);
+    g_t_reclaim += now_us() - t_r;
     if (rc != BBQ_OK) return fail_out(rc);
     const int nq = (int)std::min<int64_t>(Q, n_queries - i * Q);
     rc = ensure_slot(ix, s, nq, true);
@@ -1579,6 +1596,8 @@ static int search_batch_impl(bbq_index *ix, int32_t n_queries, const uint8_t *qq
     rc = enqueue_subbatch(cs, s, i * Q, nq, nullptr);
     if (rc != BBQ_OK) return fail_out(rc);
     // hand finished sub-batches to the replay workers as early as possible (their slot is needed again soon)
+    const double t_p = now_us();
+    struct TP { double t0; ~TP() { g_t_poll += now_us() - t0; } } tp{t_p};
     for (int j = 0; j < nslots; ++j) {
       Slot &t = ix->slots[j];
       if (&t != &s && t.busy && hipEventQuery(t.ev_done) == hipSuccess) {
@@ -1587,10 +1606,13 @@ static int search_batch_impl(bbq_index *ix, int32_t n_queries, const uint8_t *qq
       }
     }
   }
+  const double t_r2 = now_us();
   for (int64_t i = std::max<int64_t>(0, nsub - nslots); i < nsub; ++i) {  // oldest first
     rc = reclaim_slot(c, ix->slots[i % nslots], out_idx, out_score, out_n);
     if (rc != BBQ_OK) return fail_out(rc);
   }
+  g_t_reclaim += now_us() - t_r2;
+  if (getenv("BBQ_HOST_TRACE")) fprintf(stderr, "host trace (cumulative us): fill %.0f launch %.0f reclaim %.0f poll %.0f\n", g_t_fill, g_t_launch, g_t_reclaim, g_t_poll);
   return BBQ_OK;
 }
 
