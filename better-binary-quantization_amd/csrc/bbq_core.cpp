@@ -714,11 +714,8 @@ struct ExtOut {
   int64_t answers_stride = 0;
 };
 
-static double g_t_fill = 0, g_t_launch = 0, g_t_reclaim = 0, g_t_poll = 0;  // TEMP host trace
-static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const ExtOut *ext) {
   bbq_index *ix = c.ix;
-  const double t_a = now_us();
   uint64_t *d_lists_ext = ext ? ext->lists : nullptr;
   const int64_t list_cap_ext = ext ? ext->list_cap : 0;
   int32_t *d_counts_ext = ext ? ext->counts : nullptr;
@@ -760,9 +757,6 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const 
     }
   }
   hipStream_t st = s.stream;
-  const double t_b = now_us();
-  g_t_fill += t_b - t_a;
-  struct TL { double t0; ~TL() { g_t_launch += now_us() - t0; } } tl{t_b};
   HIPCHK(hipMemcpyAsync(s.d_block, s.h_block, (size_t)s.ctrl_bytes + bytes, hipMemcpyHostToDevice, st));  // control words := 0, queries
   s.ctrl_clean = false;
   uint64_t *d_lists = d_lists_ext ? d_lists_ext : s.d_lists;
@@ -1585,9 +1579,7 @@ static int search_batch_impl(bbq_index *ix, int32_t n_queries, const uint8_t *qq
   };
   for (int64_t i = 0; i < nsub; ++i) {
     Slot &s = ix->slots[i % nslots];
-    const double t_r = now_us();
     rc = reclaim_slot(c, s, out_idx, out_score, out_n);
-    g_t_reclaim += now_us() - t_r;
     if (rc != BBQ_OK) return fail_out(rc);
     const int nq = (int)std::min<int64_t>(Q, n_queries - i * Q);
     rc = ensure_slot(ix, s, nq, true);
@@ -1596,8 +1588,6 @@ static int search_batch_impl(bbq_index *ix, int32_t n_queries, const uint8_t *qq
     rc = enqueue_subbatch(cs, s, i * Q, nq, nullptr);
     if (rc != BBQ_OK) return fail_out(rc);
     // hand finished sub-batches to the replay workers as early as possible (their slot is needed again soon)
-    const double t_p = now_us();
-    struct TP { double t0; ~TP() { g_t_poll += now_us() - t0; } } tp{t_p};
     for (int j = 0; j < nslots; ++j) {
       Slot &t = ix->slots[j];
       if (&t != &s && t.busy && hipEventQuery(t.ev_done) == hipSuccess) {
@@ -1606,13 +1596,10 @@ static int search_batch_impl(bbq_index *ix, int32_t n_queries, const uint8_t *qq
       }
     }
   }
-  const double t_r2 = now_us();
   for (int64_t i = std::max<int64_t>(0, nsub - nslots); i < nsub; ++i) {  // oldest first
     rc = reclaim_slot(c, ix->slots[i % nslots], out_idx, out_score, out_n);
     if (rc != BBQ_OK) return fail_out(rc);
   }
-  g_t_reclaim += now_us() - t_r2;
-  if (getenv("BBQ_HOST_TRACE")) fprintf(stderr, "host trace (cumulative us): fill %.0f launch %.0f reclaim %.0f poll %.0f\n", g_t_fill, g_t_launch, g_t_reclaim, g_t_poll);
   return BBQ_OK;
 }
 
