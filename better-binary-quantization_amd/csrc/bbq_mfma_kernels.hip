@@ -250,10 +250,9 @@ __device__ __forceinline__ typename std::conditional<FP, f32x16m, i32x16m>::type
 template <int G, int STEPS, int W>
 __device__ __forceinline__ void fp_step(f32x16m &acc0, f32x16m &acc1, const u32x4m (&c)[W], u32x4m &bq, u32x2m &bq2, uint32_t addr16, uint32_t addr8) {
   // a lane supplies 32 of a step's 64 dimensions: ONE code word - word 2G of its row group's row n in the lower half-wave, word
-  // 2G + 1 in the upper.  swap(word 2G, word 2G + 1) of my own row: [0] = {row n: 2G | row n: 2G + 1}, [1] = the same of row 32 + n
-  const uint32_t wa = (G & 1) == 0 ? c[G >> 1].x : c[G >> 1].z;
-  const uint32_t wb = (G & 1) == 0 ? c[G >> 1].y : c[G >> 1].w;
-  const auto sw = __builtin_amdgcn_permlane32_swap(wa, wb, false, false);
+  // 2G + 1 in the upper.  The tile's words were swapped in place for that (swap_code_words): [0] = {row n: 2G | row n: 2G + 1}, [1] =
+  // the same of row 32 + n
+  const uint32_t sw[2] = {(G & 1) == 0 ? c[G >> 1].x : c[G >> 1].z, (G & 1) == 0 ? c[G >> 1].y : c[G >> 1].w};
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq), "+v"(bq2));   // this step's fragment has arrived
   i32x8m Q, R0, R1;   // 8 dwords wide for the builtin; FP6 uses 6 of them and FP4 4: the others stay undefined
   Q[0] = (int)bq.x; Q[1] = (int)bq.y; Q[2] = (int)bq.z; Q[3] = (int)bq.w; Q[4] = (int)bq2.x; Q[5] = (int)bq2.y;
@@ -271,6 +270,20 @@ __device__ __forceinline__ void fp_step(f32x16m &acc0, f32x16m &acc1, const u32x
   acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Q, R1, acc1, 2, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
   asm volatile("" : "+v"(acc0), "+v"(acc1));  // ordered with the reads: this step's MFMAs are issued before the next step begins
   if constexpr (G + 1 < STEPS) fp_step<G + 1, STEPS, W>(acc0, acc1, c, bq, bq2, addr16, addr8);
+}
+
+// FP form: swap(word 2s, word 2s + 1) of every lane's own row, in place, ONCE per tile: afterwards the first register of each pair
+// holds {rows 0..31: word 2s | rows 0..31: word 2s + 1}, the second the same of rows 32..63 - the B operands of step s for the two row
+// groups, for every group of queries the workgroup serves (per group and step it was a swap and, for all but the last group, two
+// copies: the swap overwrites both of its operands)
+template <int W>
+__device__ __forceinline__ void swap_code_words(u32x4m (&c)[W]) {
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    const auto s0 = __builtin_amdgcn_permlane32_swap(c[j].x, c[j].y, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(c[j].z, c[j].w, false, false);
+    c[j].x = s0[0]; c[j].y = s0[1]; c[j].z = s1[0]; c[j].w = s1[1];
+  }
 }
 
 // bytes of one group's staged query operands
@@ -401,16 +414,18 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
     // ---- the accumulators start at the (negated, biased) thresholds of their pairs:  C[query][row] = qk[query] . rk[row] + K[row],
     // itself a contraction (six terms: four products, K x 1, 0 x 0) - three v_mfma_f32_32x32x2_f32 per row group, which evaluate it
     // as a chain of f32 FMAs (as 128 v_fma_f32 per tile and wave it was a third of the kernel's vector instructions).  The B operand
-    // of k-step s is {rk[2s] in the lower half-wave, rk[2s + 1] in the upper} of the row group's row n: one swap of my own row's two
+    // of a k-step is {one constant in the lower half-wave, another in the upper} of the row group's row n: one swap of my own row's two
     // constants gives both row groups' operands ([0]: rows 0..31, [1]: rows 32..63).
-    const auto b0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r0), __float_as_uint(mine.r1), false, false);
-    const auto b1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r2), __float_as_uint(mine.r3), false, false);
+    // (the first step pairs the two constants that do not need the row's popcount)
+    const auto b0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r0), __float_as_uint(mine.r2), false, false);
+    const auto b1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r3), __float_as_uint(mine.r1), false, false);
     const auto b2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.K), 0u, false, false);
     float rb[2][3];
 #pragma unroll
     for (int rg = 0; rg < 2; ++rg) { rb[rg][0] = __uint_as_float(b0[rg]); rb[rg][1] = __uint_as_float(b1[rg]); rb[rg][2] = __uint_as_float(b2[rg]); }
     const int rows_here = (int)min((int64_t)kTileRows, a.s.idx.n_rows - tile * kTileRows);
     uint32_t *__restrict__ queue = s_queue + (size_t)wave * qcap;
+    if constexpr (FP) swap_code_words<W>(t.c);   // (the popcount above wanted the words as they were loaded)
     // (straight-line code over the groups: as a loop the tile's registers were carried around it and spilled.  A group that does not
     // exist - the last workgroup row of an odd number of groups - is computed all the same: its queries' start values are -inf)
 #pragma unroll
@@ -426,8 +441,8 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
     float aq0, aq1, aq2;
     {
       const f32x4m qkm = s_qk[gq + n + lds_off];
-      aq0 = h ? qkm.y : qkm.x;
-      aq1 = h ? qkm.w : qkm.z;
+      aq0 = h ? qkm.z : qkm.x;   // step 0: qk[0] r0 + qk[2] r2
+      aq1 = h ? qkm.y : qkm.w;   // step 1: qk[3] r3 + qk[1] r1
       aq2 = h ? 0.0f : 1.0f;
     }
     Acc acc0 = start_values<FP>(aq0, aq1, aq2, rb[0][0], rb[0][1], rb[0][2]);
@@ -438,6 +453,9 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
       const uint32_t addr16 = (uint32_t)(uintptr_t)(s_B + h * 32 + n + lds_off), addr8 = (uint32_t)(uintptr_t)(s_B2 + h * 32 + n + lds_off);
       u32x4m bq;
       u32x2m bq2;
+      // (the swapped words are the same for every group: named here, or their 96 masked forms are computed once and kept - spilled)
+#pragma unroll
+      for (int j = 0; j < W; ++j) asm volatile("" : "+v"(t.c[j]));
       asm volatile("ds_read_b128 %0, %2\n\tds_read_b64 %1, %3" : "=v"(bq), "=v"(bq2) : "v"(addr16), "v"(addr8));
       fp_step<0, STEPS, W>(acc0, acc1, t.c, bq, bq2, addr16, addr8);
     } else {
@@ -460,7 +478,11 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
     // ---- the codes are consumed by the last group: the next tile of this wave slot goes into the same registers while this one is tested
     if (g + 1 == G) {
       const int64_t tn = tile + kTilesPerChunk;
-      if (ci + 1 < cpb && lc + 1 < a.s.n_chunks && tn < n_tiles) load_tile_regs<W, COMPACT>(t, a.s.idx, tn, lane);
+      // (the lane passes through an empty asm: its share of the addresses is derived here, a few instructions per tile, instead of
+      // being carried around the loop in four registers that the two-group kernel does not have)
+      int lane_here = lane;
+      asm volatile("" : "+v"(lane_here));
+      if (ci + 1 < cpb && lc + 1 < a.s.n_chunks && tn < n_tiles) load_tile_regs<W, COMPACT>(t, a.s.idx, tn, lane_here);
     }
     // ---- any accumulator above the bias?
     // (compared as integers in both forms: positive floats order like their bits, a negative start value - a lane without a query - is

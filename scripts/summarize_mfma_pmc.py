@@ -1,8 +1,9 @@
 """summary of scripts/profile_mfma.sh's output (kernel trace + two --pmc passes of the shared sweep on the matrix cores):
-  python scripts/summarize_mfma_pmc.py gpurun_out/<dir> [profiles/rNN_mfma_pmc.json]
+  python scripts/summarize_mfma_pmc.py gpurun_out/<dir> [profiles/rNN_mfma_pmc.json] [dim] [queries per launch]
 The dominant launches are the bbq_scan_mfma_kernel launches with the largest grid; their tile count is taken from SQ_INSTS_MFMA
 (30 MFMAs per 64-row tile and 32 queries at 768-d with 4-bit queries: 2 row groups x (12 of the contraction + 3 of the start values)),
-so the summary does not depend on how many chunks a workgroup walks."""
+so the summary does not depend on how many chunks a workgroup walks; "per tile and wave" is per tile AND group of 32 queries (a workgroup
+serves two groups per tile load since round 4)."""
 import collections
 import csv
 import glob
@@ -12,7 +13,7 @@ import sys
 
 d = sys.argv[1]
 out = {"how": "scripts/profile_mfma.sh: rocprofv3 --kernel-trace --stats and two --pmc passes (8 SQ counters each) of "
-              "`python3 bench.py --steps 2 --warmup 1 ...` (10 M x 768, 32 queries per shared sweep); the dominant launches are the ones with the largest grid"}
+              "`python3 bench.py --steps 2 --warmup 1 ...` (10 M x 768, 64 queries per launch chain, 32 per matrix-core group); the dominant launches are the ones with the largest grid"}
 for p in ("pmc1", "pmc2"):
     fs = glob.glob(os.path.join(d, p, "*", "*counter_collection.csv"))
     if not fs:
@@ -34,6 +35,7 @@ us = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr if
 out["trace_avg_us"], out["trace_launches"] = sum(us) / len(us), len(us)
 pl = out["per_launch"]
 dim = int(sys.argv[3]) if len(sys.argv) > 3 else 768
+queries = int(sys.argv[4]) if len(sys.argv) > 4 else 64   # per launch: two groups of 32 share every tile load (32 before round 4's two-group kernel)
 # MFMAs per 64-row tile and 32 queries: 2 row groups x (dim / 64 of the contraction in its FP6 x FP4 form + 3 of the start values)
 tiles = pl["SQ_INSTS_MFMA"] / (2 * (dim / 64 + 3))
 out["rows_per_launch"], out["tiles_per_launch"] = tiles * 64, tiles
@@ -45,7 +47,8 @@ out["derived"] = {
     "cycles_per_valu_instruction": pl.get("SQ_ACTIVE_INST_VALU", 0) * 4 / max(pl.get("SQ_INSTS_VALU", 1), 1),
     "wave_time_split": {k_: pl.get(k_, 0) / max(pl.get("SQ_WAVE_CYCLES", 1), 1) for k_ in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")},
     "lds_bank_conflict_share": pl.get("SQ_LDS_BANK_CONFLICT", 0) / max(pl.get("SQ_LDS_IDX_ACTIVE", 1), 1),
-    "queries_per_s_of_this_launch_alone": 32 / (out["trace_avg_us"] * 1e-6),
+    "queries_per_launch": queries,
+    "queries_per_s_of_this_launch_alone": queries / (out["trace_avg_us"] * 1e-6),
     "note": "SQ_ACTIVE_* / SQ_WAIT_* / SQ_WAVE_CYCLES count quad-cycles (MI355X_MICROARCH.md), SQ_VALU_MFMA_BUSY_CYCLES cycles; SIMD time = "
             "launch duration x 1024 SIMDs x 2.1 GHz",
 }
