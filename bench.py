@@ -813,11 +813,14 @@ def main():
                    "roofline": {"frac_hbm": (stream_gbps / HBM_PEAK_GBS) if stream_gbps else None,
                                 "frac_matrix_peak": bq * N * dim * 2 / mx_peak if args.shared_sweep == 32 else None,
                                 "matrix_form": ("FP6 x FP4 (v_mfma_f32_32x32x64_f8f6f4)" if fp_form else "int8 (v_mfma_i32_32x32x32_i8)") if args.shared_sweep == 32 else None,
-                                "bound": "vector issue next to the matrix cores: the instructions outside the contraction do not hide behind it "
-                                         "(profiles/r04_mfma_pmc.json, scripts/ubench/valu_mfma_overlap.hip, DESIGN.md 'Shared sweeps')",
+                                "bound": "vector issue next to the matrix cores: vector and matrix instructions of different waves do not overlap on a SIMD "
+                                         "(profiles/r04_mfma_pmc.json: vector ALUs active 50 %, matrix cores busy 48 % of the SIMD time; "
+                                         "scripts/ubench/valu_mfma_overlap.hip; DESIGN.md 'Shared sweeps')",
                                 "index_stream_GBps": stream_gbps, "matrix_peak_ops": mx_peak,
-                                "bytes_per_row_of_the_sweep": (lb / max(stb["last_scan_rows"], 1) * args.shared_sweep) if stb.get("last_scan_rows") else None},
-                   "identical_to_unshared": same, "bound": "matrix cores + vector issue (32 queries share each row load)" if args.shared_sweep == 32 else "valu (popcount + f64 bound per query; HBM bytes amortised over the sweep)",
+                                # bytes the dominant launch reads per index row for ALL its queries (120 = one load of the 96-byte codes +
+                                # 24 B of exact corrections serves the launch's 64 queries)
+                                "bytes_per_row_of_the_launch": (lb / max(stb["last_scan_rows"], 1) * b_sub) if stb.get("last_scan_rows") else None},
+                   "identical_to_unshared": same, "bound": "matrix cores + vector issue (groups of 32 queries; two groups share each tile load)" if args.shared_sweep == 32 else "valu (popcount + f64 bound per query; HBM bytes amortised over the sweep)",
                    "index_stream_GBps": lb / (lms * 1e-3) / 1e9 if lms > 0 else None}
         batched["queries_per_launch"] = b_sub
         ix.set_option("sweep_share", 1)

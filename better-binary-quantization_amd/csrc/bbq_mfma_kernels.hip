@@ -12,7 +12,7 @@
 //
 // Round 4: the kernel was bound by vector issue (profiles/r03_mfma_pmc.json: 1 349 vector instructions per tile and wave next to
 // 48 MFMAs, the matrix cores 24 % busy) - 16 instructions per (row, query) pair of pre-filter and 9 per MFMA of bit -> int8
-// expansion.  Both are gone (profiles/r04_mfma_pmc.json: ~340 vector instructions and 30 MFMAs per tile and wave):
+// expansion.  Both are gone (profiles/r04_mfma_pmc.json: 269 vector instructions and 30 MFMAs per tile and group of 32 queries):
 //  * THE PRE-FILTER LIVES IN THE ACCUMULATOR.  "score > theta" is, for a row with upper > lower and a query with upper > lower,
 //    an inequality on the integer itself:  qcDist > T(query, row), where T is a sum of four (per-query constant) x (per-row
 //    constant) products (derivation at row_constants()).  The MFMA's C operand is initialised with the float
@@ -39,11 +39,13 @@
 //    One v_permlane32_swap hands BOTH row groups their operand words (own or half-wave partner's row).
 //  * Both row groups' accumulators are live at once, so a query fragment is read from LDS once for two MFMAs, and the next tile's
 //    loads are issued as soon as the contraction has consumed the codes - into the same registers.
+//  * A workgroup serves TWO groups of 32 queries per tile load (template G): see the kernel.
 // What binds it now (scripts/ubench/valu_mfma_overlap.hip, four waves per SIMD): a vector instruction issued in the shadow of the
-// SAME wave's MFMA is nearly free (five per MFMA: + 19 %), but a wave in a vector-only phase and a wave in an MFMA phase barely
-// overlap on one SIMD (a block of 320 v_fma_f32 and a block of 24 MFMAs: 710 ns together, 431 and 391 ns alone).  The contraction's
-// shadows are full (the operand expansion), so the ~190 vector instructions outside it - the row's popcount and constants, the
-// addresses of the next tile, the survivor test - add their time to the matrix cores' instead of hiding behind it.
+// SAME wave's MFMA is nearly free (five per MFMA: + 13-19 %), but a wave in a vector-only phase and a wave in an MFMA phase barely
+// overlap on one SIMD (a block of 320 v_fma_f32 and a block of 24 MFMAs: 660 ns together, 422 and 366 ns alone - also when every
+// second wave runs one block ahead).  The contraction's shadows are full (the operand expansion), so the ~150 vector instructions
+// outside it - the row's popcount and constants, the addresses of the next tile, the survivor test - add their time to the matrix
+// cores' instead of hiding behind it (the counters: vector ALUs active 50 %, matrix cores busy 48 % of the SIMD time).
 // Packed f32 instructions (v_pk_fma_f32) are NOT used: on gfx950 they issue at half rate (MI355X_MICROARCH.md, cycle constants).
 //
 // The rare survivors go through the exact f64 score of the one-sweep kernel, so the emitted candidates - and therefore the
