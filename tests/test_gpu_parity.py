@@ -605,6 +605,15 @@ def test_full_size_10m_x_768_properties():
             np.testing.assert_array_equal(si, idx)
             np.testing.assert_array_equal(ss.view(np.uint32), sc.view(np.uint32))
         ix.set_option("sweep_share", 1)
+        # (4b) 70 queries: the matrix-core sweep serves two groups of 32 per tile load (64 + a partial chain of 6)
+        qq70, qc70 = sys_path_bench.synth_queries(3, 70, dim)
+        ui, us, _ = ix.search_batch(qq70, qc70, 4, 1, k)
+        ix.set_option("sweep_share", 32)
+        mi, ms, _ = ix.search_batch(qq70, qc70, 4, 1, k)
+        ix.set_option("sweep_share", 1)
+        np.testing.assert_array_equal(mi, ui)
+        np.testing.assert_array_equal(ms.view(np.uint32), us.view(np.uint32))
+        assert ix.stats()["dense_fallbacks"] == 0
     finally:
         ix.close()
     # (5) inline layout
