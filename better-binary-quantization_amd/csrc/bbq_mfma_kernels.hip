@@ -489,11 +489,15 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
     // ---- any accumulator above the bias?
     // (compared as integers in both forms: positive floats order like their bits, a negative start value - a lane without a query - is
     // a negative integer, NaN cannot arise; v_max3_i32 takes two accumulators per instruction, the f32 maximum with its NaN rules one)
-    int mx = abits(acc0[0]);
+    // (written as a chain max(max(m, a), b): one v_max3_i32 per two accumulators - as max(m, max(a, b)) it compiled to three
+    // instructions per four)
+    int mx = max(max(abits(acc0[0]), abits(acc0[1])), abits(acc0[2]));
 #pragma unroll
-    for (int r = 1; r < 16; r += 2) mx = max(mx, max(abits(acc0[r]), r + 1 < 16 ? abits(acc0[r + 1]) : abits(acc0[r])));
+    for (int r = 3; r < 15; r += 2) mx = max(max(mx, abits(acc0[r])), abits(acc0[r + 1]));
+    mx = max(max(mx, abits(acc0[15])), abits(acc1[0]));
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) mx = max(mx, max(abits(acc1[r]), abits(acc1[r + 1])));
+    for (int r = 1; r < 15; r += 2) mx = max(max(mx, abits(acc1[r])), abits(acc1[r + 1]));
+    mx = max(mx, abits(acc1[15]));
     const bool any_lane = mx > (int)__float_as_uint(N::bias);
     if (__any(any_lane)) {
       // survivors: take qcDist from the difference to the accumulator's start value, which is derived again (the same instructions on
