@@ -823,6 +823,24 @@ def main():
                    "identical_to_unshared": same, "bound": "matrix cores + vector issue (groups of 32 queries; two groups share each tile load)" if args.shared_sweep == 32 else "valu (popcount + f64 bound per query; HBM bytes amortised over the sweep)",
                    "index_stream_GBps": lb / (lms * 1e-3) / 1e9 if lms > 0 else None}
         batched["queries_per_launch"] = b_sub
+        # the same mode with four times as many queries per call (the step's 256 queries are four launch chains: the first chain's small
+        # launches and the last chain's tail run alone; a longer call spends more of its time with several chains in flight)
+        big_calls = [(np.concatenate([b[0] for b in batches[i:i + 4]]), np.concatenate([b[1] for b in batches[i:i + 4]]))
+                     for i in range(args.warmup, len(batches) - 3, 4)]
+        if big_calls:
+            ix.search_batch(big_calls[0][0], big_calls[0][1], QB, SIM, k)
+            barrier()
+            tb4 = time.perf_counter()
+            for qq_b, qc_b in big_calls:
+                res_b4 = ix.search_batch(qq_b, qc_b, QB, SIM, k)
+            barrier()
+            dtb4 = time.perf_counter() - tb4
+            batched["value_at_4x_queries_per_call"] = len(big_calls) * 4 * Q / dtb4
+            batched["queries_per_call_4x"] = 4 * Q
+            i_last = args.warmup + 4 * (len(big_calls) - 1)   # the batches the last long call was made of
+            batched["identical_to_unshared_4x"] = bool(
+                (res_b4[0] == np.concatenate([r[0] for r in results[i_last:i_last + 4]])).all() and
+                (res_b4[1].view(np.uint32) == np.concatenate([r[1] for r in results[i_last:i_last + 4]]).view(np.uint32)).all())
         ix.set_option("sweep_share", 1)
         ix.set_option("batch_queries", min(args.sub_batch, Q))
 
