@@ -813,8 +813,8 @@ def main():
                    "roofline": {"frac_hbm": (stream_gbps / HBM_PEAK_GBS) if stream_gbps else None,
                                 "frac_matrix_peak": bq * N * dim * 2 / mx_peak if args.shared_sweep == 32 else None,
                                 "matrix_form": ("FP6 x FP4 (v_mfma_f32_32x32x64_f8f6f4)" if fp_form else "int8 (v_mfma_i32_32x32x32_i8)") if args.shared_sweep == 32 else None,
-                                "bound": "vector issue next to the matrix cores: vector and matrix instructions of different waves do not overlap on a SIMD "
-                                         "(profiles/r04_mfma_pmc.json: vector ALUs active 50 %, matrix cores busy 48 % of the SIMD time; "
+                                "bound": "vector issue next to the matrix cores: vector and matrix instructions of different waves barely overlap on a SIMD "
+                                         "(profiles/r04_mfma_pmc.json: vector ALUs active 58 %, matrix cores busy 56 % of the SIMD time at 1.8 GHz, 2 084 cycles per tile and group of 32 queries; "
                                          "scripts/ubench/valu_mfma_overlap.hip; DESIGN.md 'Shared sweeps')",
                                 "index_stream_GBps": stream_gbps, "matrix_peak_ops": mx_peak,
                                 # bytes the dominant launch reads per index row for ALL its queries (120 = one load of the 96-byte codes +

@@ -40,17 +40,30 @@ queries = int(sys.argv[4]) if len(sys.argv) > 4 else 64   # per launch: two grou
 tiles = pl["SQ_INSTS_MFMA"] / (2 * (dim / 64 + 3))
 out["rows_per_launch"], out["tiles_per_launch"] = tiles * 64, tiles
 out["per_tile_and_wave"] = {k_: pl[k_] / tiles for k_ in ("SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU") if k_ in pl}
-simd_cycles = out["trace_avg_us"] * 1e-6 * 1024 * 2.1e9   # 1024 SIMDs at the ~2.1 GHz the chip holds under this load
+# the clock under the counters: SQ_BUSY_CYCLES is summed over the chip's 32 shader engines (8 XCDs x 4), and the SQs are busy for the whole
+# launch - 1.8 GHz for this kernel, not the 2.4 GHz of the data sheet (a fixed 2.1 GHz here once made vector and matrix time look
+# like they add up to the whole launch).  Cross-check: SQ_VALU_MFMA_BUSY_CYCLES per MFMA must be the instructions' own 32 / 64 cycles.
+clock_hz = pl["SQ_BUSY_CYCLES"] / 32 / (out["trace_avg_us"] * 1e-6) if pl.get("SQ_BUSY_CYCLES") else 0.0
+if not 1.2e9 <= clock_hz <= 2.5e9:   # (a pass whose launches overlapped with another kernel's: take what the clean passes of this kernel gave)
+    clock_hz = 1.8e9
+simd_cycles = out["trace_avg_us"] * 1e-6 * 1024 * clock_hz
+valu = pl.get("SQ_ACTIVE_INST_VALU", 0) * 4 / simd_cycles
+mfma = pl.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / simd_cycles
 out["derived"] = {
-    "valu_active_share_of_simd_time": pl.get("SQ_ACTIVE_INST_VALU", 0) * 4 / simd_cycles,
-    "mfma_busy_share_of_simd_time": pl.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / simd_cycles,
+    "clock_GHz_from_SQ_BUSY_CYCLES": clock_hz / 1e9,
+    "mfma_busy_cycles_per_mfma": pl.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(pl.get("SQ_INSTS_MFMA", 1), 1),
+    "cycles_per_tile_and_group": simd_cycles / tiles,
+    "valu_active_share_of_simd_time": valu,
+    "mfma_busy_share_of_simd_time": mfma,
+    "overlap_of_the_two_at_least": max(0.0, valu + mfma - 1.0),
+    "resident_waves_per_simd": pl.get("SQ_WAVE_CYCLES", 0) * 4 / simd_cycles,
     "cycles_per_valu_instruction": pl.get("SQ_ACTIVE_INST_VALU", 0) * 4 / max(pl.get("SQ_INSTS_VALU", 1), 1),
     "wave_time_split": {k_: pl.get(k_, 0) / max(pl.get("SQ_WAVE_CYCLES", 1), 1) for k_ in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")},
     "lds_bank_conflict_share": pl.get("SQ_LDS_BANK_CONFLICT", 0) / max(pl.get("SQ_LDS_IDX_ACTIVE", 1), 1),
     "queries_per_launch": queries,
     "queries_per_s_of_this_launch_alone": queries / (out["trace_avg_us"] * 1e-6),
-    "note": "SQ_ACTIVE_* / SQ_WAIT_* / SQ_WAVE_CYCLES count quad-cycles (MI355X_MICROARCH.md), SQ_VALU_MFMA_BUSY_CYCLES cycles; SIMD time = "
-            "launch duration x 1024 SIMDs x 2.1 GHz",
+    "note": "SQ_ACTIVE_* / SQ_WAIT_* / SQ_WAVE_CYCLES count quad-cycles (MI355X_MICROARCH.md), SQ_VALU_MFMA_BUSY_CYCLES and SQ_BUSY_CYCLES cycles; "
+            "SIMD time = launch duration x 1024 SIMDs x the clock derived above",
 }
 if len(sys.argv) > 2 and sys.argv[2] != "-":
     json.dump(out, open(sys.argv[2], "w"), indent=1)
