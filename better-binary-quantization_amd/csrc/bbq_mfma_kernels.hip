@@ -144,13 +144,13 @@ __device__ __forceinline__ double z_threshold(uint32_t theta_key, const QueryPar
 // so for lx > 0 and ly > 0 (beta = cs * ly):
 //     z > zth   <=>   qc > T = (zth / beta) * (1 / lx)  -  (ay / ly) * (rho * D + x1)  -  y1 * rho  -  (1 / beta) * (ca * add / lx),    rho = ax / lx.
 // Per query (prologue, f64 -> f32):  qk = -S * {zth / beta, ay / ly, y1, 1 / beta}.   Per row (f32):  rk = {1 / lx, -(rho * D + x1), -rho, -ca * add / lx}.
-// The accumulator starts at  qk . rk + K  with K = bias + slack: the four products summed first, K last (start_values()).
+// The accumulator starts at  K + qk . rk  with K = bias + slack: K first, then the four products one by one, the one with the row's
+// popcount in it last (start_values(): the MFMAs that do not need the popcount are issued in front of it).
 //
-// Slack.  Let mag = S * sum_j max_q |q_j| * |r_j| (the row's magnitude budget, with |rho| * D + |x1| standing for |r_1|, plus
+// Slack.  Let mag = S * sum_j max_q |q_j| * |r_j| (the row's magnitude budget, with |rho| * D + (a bound of |x1|) standing for |r_1|, plus
 // S * the largest possible qcDist so that every term of s is covered).
-//  * the sum: four fused multiply-adds at the grain of the products (each within 2^-24 of the partial sum: together below 2^-22 * mag)
-//    and ONE addition whose result lies inside the binade (guaranteed by mag < mag_limit, else the row is "weird"): 0.5 ulp.  The budget
-//    below would also cover four FMAs onto K, 4 * 0.5 ulp (tests/test_prefilter_math_cpu.py checks both orders);
+//  * the sum: four fused multiply-adds onto K, each result inside the binade (guaranteed by mag < mag_limit, else the row is "weird"):
+//    4 * 0.5 ulp (tests/test_prefilter_math_cpu.py checks this order, the products-first order and a plain FMA chain);
 //  * the f32 images of the constants: q_j within 2^-24 (one rounding of an f64), 1 / lx within 2^-22 (v_rcp_f32 is good to 1 ulp, lx
 //    itself is rounded once), rho and add / lx within 2^-21.4, r_1 within 2^-21.3 of |rho| * D + |x1|: every product within 2^-21 of its
 //    magnitude, together below 2^-21 * mag;  the f64 evaluation of the reference score itself (~2^-50 of the same magnitudes) and
@@ -162,26 +162,31 @@ __device__ __forceinline__ double z_threshold(uint32_t theta_key, const QueryPar
 struct RowK {
   float r0, r1, r2, r3, K;
 };
+// `x1` is what r1 is made of; `x1_bound` >= |x1| is what the magnitude budget uses - the dimension for a row whose component sum is
+// its popcount: every constant but r1 is then known before the popcount, and the start-value MFMAs that do not need r1 run in front
+// of it (start_values: K first)
 template <bool FP>
-__device__ __forceinline__ RowK row_constants(double al, double au, double add, double x1, float D, int sim, const float *__restrict__ gmax) {
+__device__ __forceinline__ RowK row_constants_early(double al, double au, double add, float x1_bound, float D, int sim, const float *__restrict__ gmax, float &rho_out, bool &ok_out) {
   using N = MfmaNum<FP>;
-  const float lxf = (float)(au - al), alf = (float)al, addf = (float)add, x1f = (float)x1;
+  const float lxf = (float)(au - al), alf = (float)al, addf = (float)add;
   const float r0 = __builtin_amdgcn_rcpf(lxf);
   const float rho = alf * r0;
   RowK k;
   k.r0 = r0;
-  k.r1 = -fmaf(rho, D, x1f);
+  k.r1 = 0.0f;
   k.r2 = -rho;
   k.r3 = (sim == 0 ? addf : -addf) * r0;
-  // gmax: S * max over the group's queries of |zth / beta|, |ay / ly|, |y1|, 1 / beta, and S * max sum of query values
-  const float mag = fmaf(gmax[0], fabsf(r0), fmaf(gmax[1], fmaf(fabsf(rho), D, fabsf(x1f)), fmaf(gmax[2], fabsf(rho), fmaf(gmax[3], fabsf(k.r3), gmax[4]))));
+  // gmax: S * max over the workgroup's queries of |zth / beta|, |ay / ly|, |y1|, 1 / beta, and S * max sum of query values
+  const float mag = fmaf(gmax[0], fabsf(r0), fmaf(gmax[1], fmaf(fabsf(rho), D, x1_bound), fmaf(gmax[2], fabsf(rho), fmaf(gmax[3], fabsf(k.r3), gmax[4]))));
   const bool ok = lxf > 0.0f && mag < N::mag_limit;  // NaN anywhere: not ok
   if (ok) {
     k.K = N::bias + N::ulp * ceilf(fmaf(mag, 9.5367431640625e-07f / N::ulp, 2.25f));  // whole ulps above 2.25 ulp + 2^-20 * mag: 3 for an ordinary row
   } else {
-    k.r0 = k.r1 = k.r2 = k.r3 = 0.0f;
+    k.r0 = k.r2 = k.r3 = 0.0f;
     k.K = N::pass_all;
   }
+  rho_out = rho;
+  ok_out = ok;
   return k;
 }
 struct MfmaArgs {
@@ -233,17 +238,24 @@ __device__ __forceinline__ void load_tile_regs(TileRegs<W, COMPACT> &t, const In
 __device__ __forceinline__ int abits(float v) { return (int)__float_as_uint(v); }
 __device__ __forceinline__ int abits(int v) { return v; }
 
-// the 16 start values of a lane (16 queries x its row-group row): qk . rk + K as three chained v_mfma_f32_32x32x2_f32 on C = 0, K last
-// (the four products are summed at their own, much finer grain; only the last addition rounds at the binade's ulp).  The same call
-// on the same operands gives the same bits: the survivors' path calls it again.
-template <bool FP>
-__device__ __forceinline__ typename std::conditional<FP, f32x16m, i32x16m>::type start_values(float aq0, float aq1, float aq2, float b0, float b1, float b2) {
+// the 16 start values of a lane (16 queries x its row-group row): K + qk . rk as three chained v_mfma_f32_32x32x2_f32 on C = 0, K first
+// (every addition rounds at the binade's ulp: four roundings, which the slack covers).  The same call on the same operands gives the
+// same bits: the survivors' path calls it again.
+__device__ __forceinline__ f32x16m start_values_early(float aq0, float aq1, float b0, float b1) {   // the two steps without the popcount
   f32x16m c = {0};
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(aq0, b0, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(aq1, b1, c, 0, 0, 0);
+  return c;
+}
+template <bool FP>
+__device__ __forceinline__ typename std::conditional<FP, f32x16m, i32x16m>::type start_values_finish(f32x16m c, float aq2, float b2) {
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(aq2, b2, c, 0, 0, 0);
   if constexpr (FP) return c;
   else return __builtin_bit_cast(i32x16m, c);   // the int8 form accumulates onto the float's bits
+}
+template <bool FP>
+__device__ __forceinline__ typename std::conditional<FP, f32x16m, i32x16m>::type start_values(float aq0, float aq1, float aq2, float b0, float b1, float b2) {
+  return start_values_finish<FP>(start_values_early(aq0, aq1, b0, b1), aq2, b2);
 }
 
 // ---- one k-step of the FP form, as a template over the step index: the fragment reads are inline asm (ds_read with an immediate
@@ -401,12 +413,34 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
 
   if (tile < n_tiles) {  // wave-uniform
     // ---- my row's constants (tile row `lane`), then both row groups' through one swap each: [0] = row n, [1] = row 32 + n
+    // (every constant but r1 first: the start-value MFMAs that do not need the popcount are issued in front of it)
+    float rho;
+    bool row_ok;
+    RowK mine = row_constants_early<FP>(t.lu.x, t.lu.y, t.add, a.s.idx.has_x1 ? fabsf((float)t.x1) * 1.0000002f : Df, Df, sim, s_gmax, rho, row_ok);
+    // (K first; the last step is the only one that needs the row's popcount)
+    const auto b0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.K), __float_as_uint(mine.r0), false, false);
+    const auto b1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r2), __float_as_uint(mine.r3), false, false);
+    // the first group's first two steps, both row groups: four MFMAs of 64 cycles in whose shadow the popcount runs.  The empty asm ties
+    // the code words to their results: the popcount cannot be scheduled in front of them (left alone the compiler puts it there)
+    int lds_off0;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lds_off0));
+    float aqf[3];
+    {
+      const f32x4m qkm = s_qk[n + lds_off0];
+      aqf[0] = h ? qkm.x : 1.0f;    // step 0: K x 1 + qk[0] r0
+      aqf[1] = h ? qkm.w : qkm.z;   // step 1: qk[2] r2 + qk[3] r3
+      aqf[2] = h ? 0.0f : qkm.y;    // step 2: qk[1] r1 (the row's popcount is in r1)
+    }
+    f32x16m e0 = start_values_early(aqf[0], aqf[1], __uint_as_float(b0[0]), __uint_as_float(b1[0]));
+    f32x16m e1 = start_values_early(aqf[0], aqf[1], __uint_as_float(b0[1]), __uint_as_float(b1[1]));
+#pragma unroll
+    for (int j = 0; j < W; ++j) asm volatile("" : "+v"(e0), "+v"(e1), "+v"(t.c[j]));
     uint32_t ones = 0;
 #pragma unroll
     for (int j = 0; j < W; ++j) ones += __popc(t.c[j].x) + __popc(t.c[j].y) + __popc(t.c[j].z) + __popc(t.c[j].w);
     double x1row = (double)ones;                 // quantizedComponentSum of a 1-bit row is its popcount ...
     if (a.s.idx.has_x1) x1row = t.x1;            // ... unless the index says otherwise
-    const RowK mine = row_constants<FP>(t.lu.x, t.lu.y, t.add, x1row, Df, sim, s_gmax);
+    mine.r1 = row_ok ? -fmaf(rho, Df, (float)x1row) : 0.0f;
     s_lu[wave * 64 + lane] = t.lu;               // for the survivors' exact scores (any lane may score any row of the tile)
     {
       f64x2m ax;
@@ -418,10 +452,7 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
     // as a chain of f32 FMAs (as 128 v_fma_f32 per tile and wave it was a third of the kernel's vector instructions).  The B operand
     // of a k-step is {one constant in the lower half-wave, another in the upper} of the row group's row n: one swap of my own row's two
     // constants gives both row groups' operands ([0]: rows 0..31, [1]: rows 32..63).
-    // (the first step pairs the two constants that do not need the row's popcount)
-    const auto b0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r0), __float_as_uint(mine.r2), false, false);
-    const auto b1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r3), __float_as_uint(mine.r1), false, false);
-    const auto b2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.K), 0u, false, false);
+    const auto b2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine.r1), 0u, false, false);
     float rb[2][3];
 #pragma unroll
     for (int rg = 0; rg < 2; ++rg) { rb[rg][0] = __uint_as_float(b0[rg]); rb[rg][1] = __uint_as_float(b1[rg]); rb[rg][2] = __uint_as_float(b2[rg]); }
@@ -441,14 +472,19 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
     const u32x2m *__restrict__ s_B2 = reinterpret_cast<const u32x2m *>(smem + (size_t)g * QBYTES + (size_t)STEPS * 2 * 32 * 16);
     // A operands of the start-value contraction (start_values): query n's constants, k = 0 in the lower half-wave, k = 1 in the upper
     float aq0, aq1, aq2;
-    {
+    Acc acc0, acc1;
+    if (g == 0) {   // (compile time: the groups are unrolled) begun in front of the popcount
+      aq0 = aqf[0]; aq1 = aqf[1]; aq2 = aqf[2];
+      acc0 = start_values_finish<FP>(e0, aq2, rb[0][2]);
+      acc1 = start_values_finish<FP>(e1, aq2, rb[1][2]);
+    } else {
       const f32x4m qkm = s_qk[gq + n + lds_off];
-      aq0 = h ? qkm.z : qkm.x;   // step 0: qk[0] r0 + qk[2] r2
-      aq1 = h ? qkm.y : qkm.w;   // step 1: qk[3] r3 + qk[1] r1
-      aq2 = h ? 0.0f : 1.0f;
+      aq0 = h ? qkm.x : 1.0f;
+      aq1 = h ? qkm.w : qkm.z;
+      aq2 = h ? 0.0f : qkm.y;
+      acc0 = start_values<FP>(aq0, aq1, aq2, rb[0][0], rb[0][1], rb[0][2]);
+      acc1 = start_values<FP>(aq0, aq1, aq2, rb[1][0], rb[1][1], rb[1][2]);
     }
-    Acc acc0 = start_values<FP>(aq0, aq1, aq2, rb[0][0], rb[0][1], rb[0][2]);
-    Acc acc1 = start_values<FP>(aq0, aq1, aq2, rb[1][0], rb[1][1], rb[1][2]);
     // ---- the contraction: C[m = query][n = row of the group] += sum over the k-steps
     if constexpr (FP) {
       // LDS byte addresses of this lane's fragment of step 0 (the pointers are LDS pointers: their low 32 bits are the offset)

@@ -70,8 +70,8 @@ def fp_scale(max_q):
 def prefilter_pass(qcdist, lower, upper, add, x1, qc, cdp, dim, sim, one_bit, theta_score, qsum, form, rcp_ulps=0, max_q=15, start="mfma"):
     """bbq_mfma_kernels.hip: the prologue's per-query constants, row_constants(), start_values() and the final compare, one query
     against all rows.  rcp_ulps moves the reciprocal by that many ulps (v_rcp_f32 is good to one).  start: how the start value's terms
-    are summed - "mfma" as the kernel does (three v_mfma_f32_32x32x2_f32 on C = 0, an FMA per k, K x 1 last), "k_first" the other way
-    round (four FMAs onto K: every rounding at the binade's ulp) - the slack must cover both.  Returns (passes, ordinary rows,
+    are summed - "mfma" as the kernel does (three v_mfma_f32_32x32x2_f32 on C = 0, an FMA per k: K x 1 first, the term with the row's
+    popcount last), "k_first" a plain FMA chain onto K, "k_last" the products first - the slack must cover all of them.  Returns (passes, ordinary rows,
     flagged): flagged = the prologue hands the query to a sweep of its own (no usable threshold)."""
     N = FORMS[form]
     S, ulp, bias = (fp_scale(max_q) if form == "fp" else 1.0), F32(N["ulp"]), F32(N["bias"])
@@ -101,11 +101,15 @@ def prefilter_pass(qcdist, lower, upper, add, x1, qc, cdp, dim, sim, one_bit, th
         r1 = -fma32(rho, D, x1f)
         r2 = -rho
         r3 = ((addf if sim == 0 else -addf) * r0).astype(F32)
-        mag = fma32(g0, np.abs(r0), fma32(g1, fma32(np.abs(rho), D, np.abs(x1f)), fma32(g2, np.abs(rho), fma32(g3, np.abs(r3), g4))))
+        # (|x1| enters the budget through a bound known before the row's popcount: the dimension for 1-bit rows)
+        x1_bound = np.maximum(np.abs(x1f), D)
+        mag = fma32(g0, np.abs(r0), fma32(g1, fma32(np.abs(rho), D, x1_bound), fma32(g2, np.abs(rho), fma32(g3, np.abs(r3), g4))))
         ok = (lxf > 0) & (mag < F32(N["mag_limit"]))
         K = np.where(ok, bias + ulp * np.ceil(fma32(mag, F32(9.5367431640625e-07) / ulp, F32(2.25))), F32(N["pass_all"])).astype(F32)
         r0, r1, r2, r3 = [np.where(ok, v, F32(0.0)).astype(F32) for v in (r0, r1, r2, r3)]
-        if start == "mfma":
+        if start == "mfma":       # the kernel: K x 1, q0 r0 | q2 r2, q3 r3 | q1 r1 (the term with the popcount last)
+            init = fma32(qk[1], r1, fma32(qk[3], r3, fma32(qk[2], r2, fma32(qk[0], r0, fma32(F32(1.0), K, F32(0.0))))))
+        elif start == "k_last":   # the products at their own grain first, one rounding at the binade's
             init = fma32(F32(1.0), K, fma32(qk[3], r3, fma32(qk[2], r2, fma32(qk[1], r1, fma32(qk[0], r0, F32(0.0))))))
         else:
             init = fma32(qk[0], r0, fma32(qk[1], r1, fma32(qk[2], r2, fma32(qk[3], r3, K))))
@@ -157,7 +161,7 @@ def test_prefilter_never_rejects_a_candidate(sim, qb, form):
         for quantile in (0.5, 0.99, 0.9999):
             theta_score = np.float32(np.quantile(s32[ok], quantile))
             wins = ok & (key_of(s32) > key_of(np.array([theta_score]))[0])
-            for ulps, start in ((0, "mfma"), (1, "mfma"), (-1, "mfma"), (0, "k_first")):
+            for ulps, start in ((0, "mfma"), (1, "mfma"), (-1, "mfma"), (0, "k_first"), (0, "k_last")):
                 passed, ordinary, flagged = prefilter_pass(d.astype(np.float64), corr[:, 0], corr[:, 1], corr[:, 2], pop, qc, cdp, dim, sim,
                                                            one_bit, theta_score, qsum, form, ulps, int(qq.max()), start)
                 assert passed[wins].all(), "the pre-filter rejected %d winning pairs (flavour %d, quantile %g, rcp %+d ulp, %s)" % (
