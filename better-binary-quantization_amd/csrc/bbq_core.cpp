@@ -808,17 +808,17 @@ int enqueue_subbatch(const BatchCtx &c, Slot &s, int64_t q_first, int nq, const 
     // one big sweep at a time on the device - for the memory-bound sweeps, which share the Infinity Cache's budget.  The chains of the
     // matrix-core sweep are issue-bound and run side by side: serialised, the finalize launch and the launch gaps between a chain's two
     // large sweeps were idle time (128 -> 138 K q/s at 10 M x 768)
-    if (g.big && !use_mfma && ix->ctx->last_big_slot >= 0 && ix->ctx->last_big_slot != my_slot)
+    const bool mfma_here = use_mfma && !g.dense && mfma_sweep_supported(a);
+    if (g.big && !mfma_here && ix->ctx->last_big_slot >= 0 && ix->ctx->last_big_slot != my_slot)
       HIPCHK(hipStreamWaitEvent(st, ix->slots[ix->ctx->last_big_slot].ev_big, 0));
     if (g.dominant) HIPCHK(hipEventRecord(s.ev0, st));
-    const bool mfma_here = use_mfma && !g.dense && mfma_sweep_supported(a);
     if (mfma_here)
       HIPCHK(launch_scan_mfma(a, s.d_qbuf + off_qbytes, reinterpret_cast<const float *>(s.d_qbuf + off_qmax), mfma_fp ? mfma_scale8 / 8.0f : 0.0f, nq, (int)g.n_chunks, st));
     else if (!g.dense && ix->opt_share > 1 && shared_sweep_supported(a, ix->opt_share))
       HIPCHK(launch_scan_shared(a, c.planes, ix->opt_share, nq, (int)g.n_chunks, st));
     else
       HIPCHK(launch_scan(a, c.planes, g.dense, nq, (int)g.n_chunks, st));
-    if (g.big && !use_mfma) {
+    if (g.big && !mfma_here) {
       HIPCHK(hipEventRecord(s.ev_big, st));
       ix->ctx->last_big_slot = my_slot;
     }
