@@ -439,6 +439,45 @@ def test_matrix_core_sweep_hostile_rows_and_queries(sim, qb, dim):
             ix.close()
 
 
+@pytest.mark.parametrize("sim", [0, 1, 2])
+def test_matrix_core_sweep_explicit_component_sums(sim):
+    """rows whose quantizedComponentSum is NOT their popcount (the index then carries the sums explicitly, inline layout): the
+    matrix-core sweep takes the sum's magnitude into its budget before it has the sum's term (start values: K first, the term with the
+    component sum last) - every answer is the oracle's, 70 queries (two groups per tile load + a partial chain)."""
+    rng = np.random.default_rng(77 + sim)
+    n, dim, k, nq, qb = 40000, 768, 50, 70, 4
+    codes = rng.integers(0, 256, size=(n, dim // 8), dtype=np.uint8)
+    pop = np.unpackbits(codes, axis=1).sum(axis=1).astype(np.float64)
+    corr = np.zeros((n, 4))
+    corr[:, 0] = -0.04 * (0.9 + 0.2 * rng.random(n))
+    corr[:, 1] = 0.04 * (0.9 + 0.2 * rng.random(n))
+    corr[:, 2] = np.abs(rng.standard_normal(n)) * 1e-2 if sim == 0 else 1e-3 * rng.standard_normal(n)
+    corr[:, 3] = pop
+    odd = rng.choice(n, 5000, replace=False)
+    corr[odd, 3] = pop[odd] + rng.integers(-300, 2000, len(odd))           # sums beyond the dimension and negative ones included
+    corr[odd[:50], 3] = rng.standard_normal(50) * 1e6
+    cdp = 0.02
+    qq = rng.integers(0, 1 << qb, size=(nq, dim), dtype=np.uint8)
+    qc = np.empty((nq, 4))
+    qc[:, 0] = -0.15 * (0.9 + 0.2 * rng.random(nq))
+    qc[:, 1] = 0.148 * (0.9 + 0.2 * rng.random(nq))
+    qc[:, 2] = 0.7 * rng.random(nq) if sim == 0 else -0.0028 * rng.random(nq)
+    qc[:, 3] = qq.sum(axis=1)
+    ix = _make_index(codes, corr, dim, cdp, True)   # (asks for the compact layout: explicit sums make it the inline one)
+    try:
+        ix.set_option("sweep_share", 32)
+        ix.set_option("first_segment_rows", 2048)
+        ix.set_option("segment_growth", 4)
+        idx, sc, cnt = ix.search_batch(qq, qc, qb, sim, k)
+        for q in range(nq):
+            _, _, s32 = O.score_all(codes, corr, dim, qq[q], qc[q], qb, sim, cdp)
+            oi, osc = O.heap_topk(s32, k)
+            np.testing.assert_array_equal(idx[q], oi, err_msg="query %d" % q)
+            np.testing.assert_array_equal(canon32(sc[q]), canon32(osc))
+    finally:
+        ix.close()
+
+
 @pytest.mark.parametrize("name,shards,pilot", [("ties_cos_qb4", 3, 1024), ("big_20000x128_cos", 4, 2048), ("ties_euc_qb4", 2, 0),
                                                ("big_50000x768_cos", 5, 4096)])
 def test_sharded_scan_and_replay_single_process(name, shards, pilot):
