@@ -394,11 +394,11 @@ typedef struct {
 int bbq_get_stats(bbq_index *idx, bbq_stats *out);
 int bbq_reset_stats(bbq_index *idx);
 /* tuning knobs; returns BBQ_ERR_INVALID_ARG for unknown names or values out of range (DESIGN.md "Knobs"):
- *   batch_queries 0..1024 (0 = by index size: 32 from 6 M rows, 64 from 2.5 M, 128 below)   pipeline_slots 1..4 (3)   segment_growth 2..1024 (8)   first_segment_rows 1024..8192 (4096)
+ *   batch_queries 0..1024 (0 = by index size: 32 from 6 M rows, 64 from 2.5 M, 128 below; at least 64 with sweep_share 32)   pipeline_slots 1..4 (3)   segment_growth 2..1024 (8)   first_segment_rows 1024..8192 (4096)
  *   resident_mb -1..2^20 (MiB of its row range a sweep launch keeps cache-resident; -1: this index's share of 224 MiB, by size among the
  *     indexes active on its device; 0: stream everything)   resident_interleave 0|1 (1: the resident chunks are spread over the range)
  *   replay_threads 1..256 (half the host cores, at most 16)   flood_rows 0..2^24 (262144)   force_dense 0|1 (0)
- *   sweep_share 1|4|8|32 (1: every query sweeps the index itself; 32: shared sweep on the matrix cores)
+ *   sweep_share 1|4|8|32 (1: every query sweeps the index itself; 32: shared sweep on the matrix cores, groups of 32 queries, two groups per load of the rows)
  *   device_select 0|1 (1: for k <= 1024 the device selects and sorts the answer itself whenever no two scores in or at the edge of it
  *   compare equal - then the reference heap provably returns that order - and the host replays the heap only for the rest)
  *   latency_queries 0..1024 (4), latency_growth 2..4096 (64): calls with at most latency_queries queries walk the index in
