@@ -409,7 +409,10 @@ __global__ __launch_bounds__(kChunkRows, W <= 8 ? 4 : 2) void bbq_scan_mfma_kern
   const int lc = lc0 + ci;           // chunk index inside this launch
   if (lc >= a.s.n_chunks) break;     // block-uniform
   const int64_t chunk = a.s.chunk_begin + lc;
-  const int64_t tile = chunk * kTilesPerChunk + wave;
+  // (named scalar: left alone the tile number lives in a pair of vector registers and everything derived from it - the rows of the last
+  // tile, the next tile's address - is 64-bit vector arithmetic)
+  const int64_t tile_v = chunk * kTilesPerChunk + wave;
+  const int64_t tile = ((int64_t)__builtin_amdgcn_readfirstlane((int)(tile_v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_v);
 
   if (tile < n_tiles) {  // wave-uniform
     // ---- my row's constants (tile row `lane`), then both row groups' through one swap each: [0] = row n, [1] = row 32 + n
